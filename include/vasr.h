@@ -1,0 +1,164 @@
+/*
+ * vasr.h -- C ABI of libvasr_hip.so: the MI355X (gfx950) implementation of the
+ * viet-asr infer.py hot path.
+ *
+ * Nothing like this exists in the reference (it is Python on ATen ops only); each entry
+ * point below names the reference interface whose arithmetic it replaces, paths under
+ * /root/reference.  The boundary carries plain pointers, sizes and a hipStream_t: no torch
+ * types.  The library never allocates or frees caller-visible result buffers; weights are
+ * copied into a library-owned handle at vasr_load_weight()/vasr_finalize().
+ *
+ * All pointers named d_* are DEVICE pointers (HBM); h_* are HOST pointers.
+ * All functions return 0 on success or a negative vasr_status; vasr_last_error() gives a
+ * thread-local human readable message for the last failure.
+ * Re-entrancy: calls on distinct handles, or on one handle with distinct workspaces and
+ * streams, may run concurrently; there is no global mutable state besides the error string.
+ */
+#ifndef VASR_H_
+#define VASR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vasr_handle vasr_handle;
+typedef void* vasr_stream; /* hipStream_t */
+
+typedef enum {
+  VASR_OK = 0,
+  VASR_ERR_INVALID = -1,     /* bad argument (Python side raises ValueError) */
+  VASR_ERR_STATE = -2,       /* call order: weight missing, not finalized ... */
+  VASR_ERR_HIP = -3,         /* HIP runtime failure */
+  VASR_ERR_WORKSPACE = -4,   /* workspace too small */
+  VASR_ERR_UNSUPPORTED = -5  /* configuration the kernels do not cover */
+} vasr_status;
+
+/* One JasperBlock (nemo/collections/asr/parts/jasper.py:175-288), as the YAML spells it
+ * (configs/quartznet12x1_vi.yaml:25-165). */
+typedef struct {
+  int32_t filters;
+  int32_t repeat;
+  int32_t kernel;
+  int32_t stride;
+  int32_t dilation;
+  int32_t residual;  /* 0/1 */
+  int32_t separable; /* 0/1 */
+} vasr_block_desc;
+
+/* Front end = FilterbankFeatures.__init__ (parts/features.py:113-236) with the knobs the
+ * path uses: dither 0, pad_to 0 (infer.py:89-90), stft_conv false, mag_power 2, log guard
+ * "add", per_feature normalisation, frame_splicing 1. */
+typedef struct {
+  int32_t sample_rate;  /* 16000 */
+  int32_t n_fft;        /* 512 (only 512 is implemented) */
+  int32_t win_length;   /* 320 */
+  int32_t hop_length;   /* 160 */
+  int32_t n_mels;       /* 64 (only 64 is implemented) */
+  float preemph;        /* 0.97; <0 disables */
+  float log_guard;      /* 2^-24 */
+  int32_t normalize;    /* 1 = per_feature, 0 = none */
+  const float* h_window;     /* [win_length] or NULL -> symmetric hann */
+  const float* h_filterbank; /* [n_mels][n_fft/2+1] row-major, REQUIRED */
+} vasr_frontend_desc;
+
+typedef struct {
+  const vasr_frontend_desc* frontend; /* NULL -> handle has no front end */
+  int32_t feat_in;                    /* encoder input channels (64) */
+  int32_t n_blocks;                   /* 0 -> handle has no encoder */
+  const vasr_block_desc* blocks;
+  int32_t dec_feat_in;                /* 1024; 0 -> handle has no CTC head */
+  int32_t num_classes;                /* V+1, blank = V is the last class */
+} vasr_model_desc;
+
+/* ---- life cycle ------------------------------------------------------------------- */
+int vasr_create(const vasr_model_desc* desc, vasr_handle** out);
+void vasr_destroy(vasr_handle* h);
+
+/* Replaces TrainableNM.restore_from -> load_state_dict (nemo/backends/pytorch/nm.py:97-103):
+ * feed every float tensor of the module state_dict under its reference key, e.g.
+ * "encoder.3.mconv.1.conv.weight", "encoder.3.mconv.2.running_var",
+ * "encoder.3.res.0.0.conv.weight", "decoder_layers.0.bias".
+ * Keys ending in "num_batches_tracked" are accepted and ignored. */
+int vasr_load_weight(vasr_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim);
+
+/* Checks that every tensor arrived, folds eval-mode BatchNorm1d(eps=1e-3)
+ * (parts/jasper.py:392) into per-channel (scale, shift), packs the 1x1-conv weights
+ * K-major for the MFMA kernels and uploads everything.  Needed before any compute call. */
+int vasr_finalize(vasr_handle* h);
+
+/* ---- shapes ------------------------------------------------------------------------ */
+/* T = 1 + L / hop (torch.stft center=True, parts/features.py:181-188). */
+int64_t vasr_mel_frames(const vasr_handle* h, int64_t samples);
+/* T' after every strided block: floor((T + 2p - d(K-1) - 1)/s) + 1 (parts/jasper.py:108-111). */
+int64_t vasr_encoded_frames(const vasr_handle* h, int64_t mel_frames);
+/* Scratch needed by vasr_encoder_f32 / vasr_decoder_* / vasr_transcribe_greedy_f32 for a
+ * batch of B utterances padded to `samples` (or, if samples == 0, to mel_frames). */
+size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, int64_t mel_frames);
+
+/* ---- the path, stage by stage (each = one NeuralModule forward) ---------------------- */
+
+/* AudioToMelSpectrogramPreprocessor.forward == FilterbankFeatures.forward
+ * (audio_preprocessing.py:78-87, parts/features.py:245-301).
+ *   d_wav [B][L] f32 (rows zero padded), d_len [B] i64
+ *   -> d_mel [B][n_mels][T] f32 contiguous, d_seq [B] i64 = ceil(len/hop) */
+int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                     float* d_mel, int64_t* d_seq, vasr_stream stream);
+
+/* JasperEncoder.forward (jasper.py:198-204; JasperBlock.forward parts/jasper.py:408-448;
+ * MaskedConv1d.forward parts/jasper.py:113-132).
+ *   d_mel [B][feat_in][T] f32 contiguous, d_seq [B] i64
+ *   -> d_enc [B][C_last][T'] f32 contiguous, d_enc_len [B] f32 (quirk Q3: float lengths) */
+int vasr_encoder_f32(vasr_handle* h, const float* d_mel, const int64_t* d_seq, int batch, int64_t mel_frames,
+                     float* d_enc, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
+                     vasr_stream stream);
+
+/* JasperDecoderForCTC.forward (jasper.py:253-254): conv1x1+bias -> transpose -> log_softmax.
+ *   d_enc [B][dec_feat_in][T'] f32 contiguous -> d_logp [B][T'][V+1] f32 */
+int vasr_decoder_logsoftmax_f32(vasr_handle* h, const float* d_enc, int batch, int64_t enc_frames,
+                                float* d_logp, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
+
+/* GreedyCTCDecoder.forward (greedy_ctc_decoder.py:33-36): argmax(-1), first max wins.
+ *   d_logp [B][T'][V+1] f32 -> d_pred [B][T'] i64 */
+int vasr_greedy_argmax(const float* d_logp, int batch, int64_t frames, int num_classes, int64_t* d_pred,
+                       vasr_stream stream);
+
+/* __ctc_decoder_predictions_tensor inner loop (helpers.py:20-31): drop repeats and blanks over
+ * ALL frames (quirk Q4).  d_pred [B][T'] i64 -> d_ids [B][T'] i32 (compacted), d_id_len [B] i32 */
+int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blank_id, int32_t* d_ids,
+                      int32_t* d_id_len, vasr_stream stream);
+
+/* ---- the whole path in one call (the fast path bench.py times) ------------------------ */
+/* wav -> mel -> encoder -> CTC head -> log-softmax/argmax -> collapse, all intermediates in
+ * the workspace (padded time stride, no port tensors materialised).
+ *   d_pred   [B][T'] i64  (may be NULL)          d_ids [B][T'] i32, d_id_len [B] i32
+ *   d_logp   [B][T'][V+1] f32 (may be NULL: greedy only needs the argmax)
+ *   d_enc_len [B] f32 (may be NULL) */
+int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch,
+                               int64_t samples, int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len,
+                               float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
+                               vasr_stream stream);
+
+/* ---- introspection -------------------------------------------------------------------- */
+const char* vasr_last_error(void);
+const char* vasr_version(void);
+/* Algorithmic work of one call at (batch, samples): flops of the 1x1-conv GEMMs, flops and
+ * minimum HBM bytes (read input + write output + weights, fp32) of the depthwise layers.
+ * out[0]=pointwise_flops out[1]=depthwise_flops out[2]=depthwise_bytes out[3]=decoder_flops
+ * out[4]=frontend_flops (2.5 N log2 N per frame + mel) */
+int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]);
+/* Run ONE encoder layer kind in isolation for benchmarking/roofline measurement:
+ * kind 0 = depthwise (K, stride 1, dilation 1), 1 = pointwise GEMM (+BN+ReLU epilogue).
+ * Buffers are caller provided [B][C][Tp] with Tp = vasr_padded_frames(T). */
+int64_t vasr_padded_frames(int64_t frames);
+int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
+                         int64_t frames, int kernel, float* d_y, vasr_stream stream);
+int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
+                         int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VASR_H_ */

@@ -1,0 +1,45 @@
+"""The oracle is pinned against outputs of the real reference modules (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+from oracle import quartznet_oracle as O
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_matches_reference_outputs(name):
+    g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
+    assert (lens == g["lens"]).all()
+    r = O.forward_all(sig, lens, enc_sd, dec_sd, cfg["JasperEncoder"]["jasper"])
+    # same ATen primitives as the reference -> bit-exact on the same host; 2e-6 leaves room for
+    # a different CPU dispatch (AVX2 vs AVX512 kernels) on another box
+    assert np.abs(O.slaney_mel_filterbank() - g["fb"]).max() == 0.0
+    assert np.abs(r["mel"].numpy() - g["mel"]).max() <= 2e-5
+    assert (r["seq"].numpy() == g["seq"]).all()
+    assert r["enc_len"].dtype.is_floating_point and (r["enc_len"].numpy() == g["enc_len"]).all()   # quirk Q3
+    assert np.abs(r["enc"][:, ::37, ::5].numpy() - g["enc_slice"]).max() <= 1e-4
+    assert abs(float(r["enc"].double().sum()) - float(g["enc_sum"])) <= 1e-6 * float(g["enc_abs_sum"])
+    assert np.abs(r["logp"].numpy() - g["logp"]).max() <= 2e-4
+    assert (r["pred"].numpy() == g["pred"]).all()
+    assert O.ctc_decode_strings(r["pred"], cfg["labels"]) == [str(s) for s in g["hyp"]]
+
+
+def test_quirks_are_in_the_goldens():
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN_DIR, "vi12x1_b3_ragged.npz"))
+    # Q3: stride-2 length arithmetic, float encoded lengths
+    assert g["enc_len"].dtype == np.float32
+    assert list(g["seq"]) == [int(np.ceil(l / 160)) for l in g["lens"]]
+    assert list(g["enc_len"]) == [float((s - 1) // 2 + 1) for s in g["seq"]]
+    # Q2: len % 160 == 0 -> T = seq + 1
+    g2 = np.load(__import__("os").path.join(__import__("conftest").GOLDEN_DIR, "vi12x1_b2_q2_realdec.npz"))
+    assert g2["mel"].shape[2] == int(g2["seq"].max()) + 1
+    # Q4: padded frames of the shorter utterance are decoded (non-blank predictions past enc_len)
+    assert g["pred"].shape[1] == int(max(g["enc_len"]))
+
+
+def test_ctc_collapse_rules():
+    blank = 5
+    assert O.ctc_collapse_ids([5, 5, 1, 1, 5, 1, 2, 2, 5], blank) == [1, 1, 2]
+    assert O.ctc_collapse_ids([], blank) == []
+    assert O.ctc_collapse_ids([0, 0, 0], blank) == [0]
+    assert O.ctc_decode_strings(np.array([[0, 1, 1, 2, 0, 2]]), ["a", "b"]) == ["aba"]

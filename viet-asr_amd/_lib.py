@@ -1,0 +1,169 @@
+"""ctypes binding of libvasr_hip.so (include/vasr.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing, or a
+compute entry point is called without a HIP device, this module raises -- it never routes
+through torch eager ops or the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvasr_hip.so")
+
+
+class VasrError(RuntimeError):
+    pass
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("filters", "repeat", "kernel", "stride", "dilation", "residual", "separable")]
+
+
+class FrontendDesc(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32),
+                ("hop_length", C.c_int32), ("n_mels", C.c_int32), ("preemph", C.c_float),
+                ("log_guard", C.c_float), ("normalize", C.c_int32),
+                ("h_window", C.POINTER(C.c_float)), ("h_filterbank", C.POINTER(C.c_float))]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("frontend", C.POINTER(FrontendDesc)), ("feat_in", C.c_int32), ("n_blocks", C.c_int32),
+                ("blocks", C.POINTER(BlockDesc)), ("dec_feat_in", C.c_int32), ("num_classes", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/vasr.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "vasr_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_P)]),
+    "vasr_destroy": (None, [_P]),
+    "vasr_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    "vasr_finalize": (C.c_int, [_P]),
+    "vasr_mel_frames": (C.c_int64, [_P, C.c_int64]),
+    "vasr_encoded_frames": (C.c_int64, [_P, C.c_int64]),
+    "vasr_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int64, C.c_int64]),
+    "vasr_melspec_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),
+    "vasr_encoder_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
+    "vasr_decoder_logsoftmax_f32": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_size_t, _P]),
+    "vasr_greedy_argmax": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "vasr_ctc_collapse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
+    "vasr_transcribe_greedy_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
+                                             C.c_size_t, _P]),
+    "vasr_last_error": (C.c_char_p, []),
+    "vasr_version": (C.c_char_p, []),
+    "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
+    "vasr_padded_frames": (C.c_int64, [C.c_int64]),
+    "vasr_bench_depthwise": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared object once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VasrError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C viet-asr_amd/csrc`). There is no CPU fallback for this path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+_ERR_TYPES = {-1: ValueError, -5: NotImplementedError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().vasr_last_error().decode("utf-8", "replace")
+        raise _ERR_TYPES.get(rc, VasrError)(f"libvasr_hip: {msg} (status {rc})")
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Handle:
+    """Owns one vasr_handle: any subset of {front end, encoder, CTC head}."""
+
+    def __init__(self, frontend=None, feat_in=0, blocks=None, dec_feat_in=0, num_classes=0):
+        L = lib()
+        self._keep = []
+        md = ModelDesc()
+        if frontend is not None:
+            fe = FrontendDesc()
+            win = np.ascontiguousarray(frontend["window"], dtype=np.float32)
+            fb = np.ascontiguousarray(frontend["filterbank"], dtype=np.float32)
+            self._keep += [win, fb, fe]
+            fe.sample_rate, fe.n_fft = int(frontend["sample_rate"]), int(frontend["n_fft"])
+            fe.win_length, fe.hop_length = int(frontend["win_length"]), int(frontend["hop_length"])
+            fe.n_mels = int(frontend["n_mels"])
+            pre = frontend.get("preemph", 0.97)
+            fe.preemph = -1.0 if pre is None else float(pre)
+            fe.log_guard = float(frontend.get("log_guard", 2 ** -24))
+            fe.normalize = 1 if frontend.get("normalize", "per_feature") == "per_feature" else 0
+            if win.shape != (fe.win_length,) or fb.shape != (fe.n_mels, fe.n_fft // 2 + 1):
+                raise ValueError(f"window {win.shape} / filterbank {fb.shape} do not match the description")
+            fe.h_window, fe.h_filterbank = _fptr(win), _fptr(fb)
+            md.frontend = C.pointer(fe)
+        blocks = blocks or []
+        if blocks:
+            arr = (BlockDesc * len(blocks))()
+            for i, b in enumerate(blocks):
+                arr[i] = BlockDesc(*[int(b[k]) for k in
+                                     ("filters", "repeat", "kernel", "stride", "dilation", "residual", "separable")])
+            self._keep.append(arr)
+            md.blocks, md.n_blocks, md.feat_in = arr, len(blocks), int(feat_in)
+        md.dec_feat_in, md.num_classes = int(dec_feat_in), int(num_classes)
+        h = _P()
+        check(L.vasr_create(C.byref(md), C.byref(h)))
+        self.h = h
+        self.num_classes = int(num_classes)
+
+    def load_state_dict(self, sd):
+        """sd: {reference state_dict key: array-like}; integer tensors (num_batches_tracked) are skipped."""
+        L = lib()
+        for k, v in sd.items():
+            a = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v)
+            if a.dtype.kind != "f":
+                continue
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            check(L.vasr_load_weight(self.h, k.encode(), a.ctypes.data_as(_P), shape, a.ndim))
+
+    def finalize(self):
+        check(lib().vasr_finalize(self.h))
+
+    def mel_frames(self, samples):
+        return int(lib().vasr_mel_frames(self.h, int(samples)))
+
+    def encoded_frames(self, mel_frames):
+        return int(lib().vasr_encoded_frames(self.h, int(mel_frames)))
+
+    def workspace_bytes(self, batch, samples=0, mel_frames=0):
+        return int(lib().vasr_workspace_bytes(self.h, int(batch), int(samples), int(mel_frames)))
+
+    def algorithmic_work(self, batch, samples):
+        out = (C.c_double * 5)()
+        check(lib().vasr_algorithmic_work(self.h, int(batch), int(samples), out))
+        return dict(pointwise_flops=out[0], depthwise_flops=out[1], depthwise_bytes=out[2],
+                    decoder_flops=out[3], frontend_flops=out[4])
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vasr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,112 @@
+// CTC head epilogue and greedy decode for gfx950.
+//
+//   logsoftmax_argmax : F.log_softmax(conv_out.transpose(1, 2), dim=-1)   (reference jasper.py:254)
+//                       + GreedyCTCDecoder argmax(-1)                      (greedy_ctc_decoder.py:33-36)
+//   ctc_collapse      : inner loop of __ctc_decoder_predictions_tensor     (helpers.py:20-31)
+//
+// The GEMM leaves logits class-major [B][V+1][ld] (time contiguous).  One workgroup takes 64
+// consecutive frames: each lane walks the classes of its own frame (coalesced across lanes),
+// builds max / sum-exp / arg-max in registers, then the [64][V+1] tile is transposed through
+// LDS so that the frame-major log-prob tensor is written as one contiguous block.
+#include "vasr_internal.h"
+
+namespace vasr {
+
+namespace {
+
+constexpr int kMaxClasses = 128;
+
+// grid (ceil(T/64), B), block 64
+__global__ __launch_bounds__(64) void logsoftmax_argmax_kernel(const float* __restrict__ logits, int64_t row_ld,
+                                                               int64_t batch_stride, int frames, int V,
+                                                               float* __restrict__ logp,
+                                                               int64_t* __restrict__ pred) {
+  extern __shared__ float tile[];  // [64][V + 1]
+  const int lane = threadIdx.x, b = blockIdx.y;
+  const int t0 = blockIdx.x * 64, t = t0 + lane;
+  const float* x = logits + (int64_t)b * batch_stride + t;
+  const int n_t = min(64, frames - t0);
+  if (t < frames) {
+    float mx = -INFINITY;
+    for (int v = 0; v < V; ++v) mx = fmaxf(mx, x[(int64_t)v * row_ld]);
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += expf(x[(int64_t)v * row_ld] - mx);
+    const float ls = logf(s);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int v = 0; v < V; ++v) {
+      const float lp = (x[(int64_t)v * row_ld] - mx) - ls;
+      if (lp > best) { best = lp; arg = v; }  // strict >: first maximum wins (quirk Q6)
+      if (logp) tile[lane * (V + 1) + v] = lp;
+    }
+    if (pred) pred[(int64_t)b * frames + t] = arg;
+  }
+  if (logp) {
+    __syncthreads();
+    float* out = logp + ((int64_t)b * frames + t0) * V;
+    for (int i = lane; i < n_t * V; i += 64) out[i] = tile[(i / V) * (V + 1) + (i % V)];
+  }
+}
+
+// standalone GreedyCTCDecoder on a frame-major [B*T][V] tensor: 4 lanes... one lane per frame row
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logp, int64_t rows, int V,
+                                                     int64_t* __restrict__ pred) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* x = logp + r * V;
+  float best = x[0];
+  int arg = 0;
+  bool nan_hit = best != best;
+  for (int v = 1; v < V; ++v) {
+    const float f = x[v];
+    if (!nan_hit && (f > best || f != f)) { best = f; arg = v; nan_hit = f != f; }  // torch: NaN is a maximum
+  }
+  pred[r] = arg;
+}
+
+// One wavefront per utterance: ballot + popcount stream compaction over all frames (quirk Q4).
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int64_t* __restrict__ pred, int64_t frames,
+                                                          int blank, int32_t* __restrict__ ids,
+                                                          int32_t* __restrict__ id_len) {
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int64_t* p = pred + (int64_t)b * frames;
+  int32_t* out = ids + (int64_t)b * frames;
+  int count = 0;
+  for (int64_t t0 = 0; t0 < frames; t0 += 64) {
+    const int64_t t = t0 + lane;
+    bool keep = false;
+    int cur = blank;
+    if (t < frames) {
+      cur = (int)p[t];
+      const int prev = t > 0 ? (int)p[t - 1] : blank;  // previous = blank before the first frame
+      keep = (cur != prev || prev == blank) && cur != blank;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) out[count + __popcll(m & ((1ull << lane) - 1ull))] = cur;
+    count += __popcll(m);
+  }
+  if (lane == 0) id_len[b] = count;
+}
+
+}  // namespace
+
+void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
+                              int num_classes, float* logp, int64_t* pred, hipStream_t st) {
+  dim3 grid((frames + 63) / 64, batch);
+  const size_t lds = logp ? (size_t)64 * (num_classes + 1) * sizeof(float) : 0;
+  hipLaunchKernelGGL(logsoftmax_argmax_kernel, grid, dim3(64), lds, st, logits, row_ld, batch_stride, frames,
+                     num_classes, logp, pred);
+}
+
+void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes, int64_t* pred, hipStream_t st) {
+  const int64_t rows = (int64_t)batch * frames;
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logp, rows,
+                     num_classes, pred);
+}
+
+void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids, int32_t* id_len,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(batch), dim3(64), 0, st, pred, frames, blank, ids, id_len);
+}
+
+}  // namespace vasr

@@ -1,0 +1,638 @@
+// C ABI of libvasr_hip.so (see include/vasr.h): handle, weight intake, BN folding / packing,
+// workspace planning and the launch sequences for each stage of the path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vasr.h"
+#include "vasr_internal.h"
+
+using namespace vasr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(VASR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct ConvLayer {
+  int cin = 0, cout = 0, kernel = 1, stride = 1, dilation = 1, pad = 0;
+  int m_pad = 0;             // pointwise: rows of the packed weight (multiple of 128)
+  float* d_w = nullptr;      // depthwise [C][K]; pointwise K-major [cin][m_pad]
+  float* d_scale = nullptr;  // [m_pad]
+  float* d_shift = nullptr;  // [m_pad]
+  int step = -1;             // index in the MaskedConv1d length chain
+};
+
+struct SubBlock {
+  bool separable = true;
+  ConvLayer dw, pw;
+};
+
+struct Block {
+  vasr_block_desc d;
+  std::vector<SubBlock> subs;
+  bool has_res = false;
+  ConvLayer res;
+  int first_step = 0;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct vasr_handle {
+  bool has_frontend = false, has_encoder = false, has_decoder = false, finalized = false;
+  vasr_frontend_desc fe{};
+  std::vector<float> fe_window, fe_fb;
+  int feat_in = 0, dec_feat_in = 0, num_classes = 0;
+  std::vector<Block> blocks;
+  std::vector<LenStep> steps;
+  std::map<std::string, HostTensor> weights;
+  std::vector<void*> dev_allocs;
+  // device tables
+  FrontendTables ft{};
+  LenStep* d_steps = nullptr;
+  ConvLayer dec;
+  int c_mid_max = 0, c_last = 0;
+};
+
+namespace {
+
+template <class T>
+int upload(vasr_handle* h, const std::vector<T>& v, T** out) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, std::max<size_t>(v.size() * sizeof(T), 16)));
+  h->dev_allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<T*>(p);
+  return 0;
+}
+
+int same_pad(int k, int stride, int dil, int* pad) {
+  // get_same_padding (parts/jasper.py:60-65)
+  if (stride > 1 && dil > 1) return fail(VASR_ERR_INVALID, "Only stride OR dilation may be greater than 1");
+  *pad = dil > 1 ? (dil * k) / 2 - 1 : k / 2;
+  return 0;
+}
+
+int64_t conv_out_frames(int64_t t, const ConvLayer& c) {
+  return (t + 2 * c.pad - (int64_t)c.dilation * (c.kernel - 1) - 1) / c.stride + 1;
+}
+
+const HostTensor* find(const vasr_handle* h, const std::string& key) {
+  auto it = h->weights.find(key);
+  return it == h->weights.end() ? nullptr : &it->second;
+}
+
+int need(const vasr_handle* h, const std::string& key, size_t numel, const HostTensor** out) {
+  const HostTensor* t = find(h, key);
+  if (!t) return fail(VASR_ERR_STATE, "missing weight '%s'", key.c_str());
+  if (t->data.size() != numel)
+    return fail(VASR_ERR_INVALID, "weight '%s' has %zu elements, expected %zu", key.c_str(), t->data.size(), numel);
+  *out = t;
+  return 0;
+}
+
+// eval-mode BatchNorm1d(eps=1e-3) -> y = x * scale + shift  (parts/jasper.py:392)
+int fold_bn(vasr_handle* h, const std::string& prefix, int c, int c_pad, ConvLayer* L) {
+  const HostTensor *g, *b, *m, *v;
+  int rc;
+  if ((rc = need(h, prefix + ".weight", c, &g))) return rc;
+  if ((rc = need(h, prefix + ".bias", c, &b))) return rc;
+  if ((rc = need(h, prefix + ".running_mean", c, &m))) return rc;
+  if ((rc = need(h, prefix + ".running_var", c, &v))) return rc;
+  std::vector<float> sc(c_pad, 0.f), sh(c_pad, 0.f);
+  for (int i = 0; i < c; ++i) {
+    // same association as ATen's CPU eval path: alpha = w * invstd, beta = b - mean * alpha (fp32)
+    const float invstd = 1.0f / std::sqrt(v->data[i] + 1e-3f);
+    const float alpha = g->data[i] * invstd;
+    sc[i] = alpha;
+    sh[i] = b->data[i] - m->data[i] * alpha;
+  }
+  if ((rc = upload(h, sc, &L->d_scale))) return rc;
+  return upload(h, sh, &L->d_shift);
+}
+
+// [cout][cin][1] -> K-major [cin][m_pad]
+int pack_pointwise(vasr_handle* h, const std::string& key, int cout, int cin, ConvLayer* L) {
+  const HostTensor* w;
+  int rc;
+  if ((rc = need(h, key, (size_t)cout * cin, &w))) return rc;
+  if (cin % 32) return fail(VASR_ERR_UNSUPPORTED, "%s: in_channels %d is not a multiple of 32", key.c_str(), cin);
+  L->cin = cin;
+  L->cout = cout;
+  L->m_pad = (int)align_up(cout, 128);
+  std::vector<float> wt((size_t)cin * L->m_pad, 0.f);
+  for (int m = 0; m < cout; ++m)
+    for (int k = 0; k < cin; ++k) wt[(size_t)k * L->m_pad + m] = w->data[(size_t)m * cin + k];
+  return upload(h, wt, &L->d_w);
+}
+
+int build_frontend(vasr_handle* h) {
+  const vasr_frontend_desc& fe = h->fe;
+  const int nfft = fe.n_fft, nb = nfft / 2 + 1;
+  std::vector<float> win(nfft, 0.f);
+  const int off = (nfft - fe.win_length) / 2;  // torch.stft centres the window inside n_fft
+  for (int i = 0; i < fe.win_length; ++i) win[off + i] = h->fe_window[i];
+  std::vector<float> tw256(512), tw512(2 * 258, 0.f);
+  for (int m = 0; m < 256; ++m) {
+    tw256[2 * m] = (float)std::cos(-2.0 * M_PI * m / 256.0);
+    tw256[2 * m + 1] = (float)std::sin(-2.0 * M_PI * m / 256.0);
+  }
+  for (int k = 0; k <= 256; ++k) {
+    tw512[2 * k] = (float)std::cos(-2.0 * M_PI * k / 512.0);
+    tw512[2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / 512.0);
+  }
+  std::vector<float> mw((size_t)fe.n_mels * kMelTaps, 0.f);
+  std::vector<int32_t> lo(fe.n_mels, 0);
+  for (int f = 0; f < fe.n_mels; ++f) {
+    const float* row = &h->fe_fb[(size_t)f * nb];
+    int first = -1, last = -1;
+    for (int k = 0; k < nb; ++k)
+      if (row[k] != 0.f) { if (first < 0) first = k; last = k; }
+    if (first < 0) { lo[f] = 0; continue; }
+    if (last - first + 1 > kMelTaps)
+      return fail(VASR_ERR_UNSUPPORTED, "mel filter %d spans %d bins (> %d)", f, last - first + 1, kMelTaps);
+    lo[f] = first;
+    for (int k = first; k <= last; ++k) mw[(size_t)f * kMelTaps + (k - first)] = row[k];
+  }
+  float *d_win, *d_t256, *d_t512, *d_mw;
+  int32_t* d_lo;
+  int rc;
+  if ((rc = upload(h, win, &d_win)) || (rc = upload(h, tw256, &d_t256)) || (rc = upload(h, tw512, &d_t512)) ||
+      (rc = upload(h, mw, &d_mw)) || (rc = upload(h, lo, &d_lo)))
+    return rc;
+  h->ft = FrontendTables{d_win, d_t256, d_t512, d_mw, d_lo};
+  return 0;
+}
+
+int build_encoder(vasr_handle* h) {
+  int cin = h->feat_in, step = 0, rc;
+  h->steps.clear();
+  h->c_mid_max = cin;
+  for (size_t i = 0; i < h->blocks.size(); ++i) {
+    Block& B = h->blocks[i];
+    const vasr_block_desc& d = B.d;
+    int k = d.kernel;
+    if (k % 2 == 0) k += 1;  // compute_new_kernel_size (parts/jasper.py:52-57)
+    int pad;
+    if ((rc = same_pad(k, d.stride, d.dilation, &pad))) return rc;
+    B.first_step = step;
+    B.subs.resize(d.repeat);
+    int c = cin, j = 0;
+    char key[160];
+    for (int r = 0; r < d.repeat; ++r) {
+      SubBlock& S = B.subs[r];
+      S.separable = d.separable != 0;
+      if (S.separable) {
+        const HostTensor* w;
+        snprintf(key, sizeof key, "encoder.%zu.mconv.%d.conv.weight", i, j);
+        if ((rc = need(h, key, (size_t)c * k, &w))) return rc;
+        S.dw.cin = S.dw.cout = c;
+        S.dw.kernel = k; S.dw.stride = d.stride; S.dw.dilation = d.dilation; S.dw.pad = pad;
+        S.dw.step = step++;
+        h->steps.push_back(LenStep{k, d.stride, d.dilation, pad});
+        if ((rc = upload(h, w->data, &S.dw.d_w))) return rc;
+        snprintf(key, sizeof key, "encoder.%zu.mconv.%d.conv.weight", i, j + 1);
+        if ((rc = pack_pointwise(h, key, d.filters, c, &S.pw))) return rc;
+        S.pw.step = step++;
+        h->steps.push_back(LenStep{1, 1, 1, 0});
+        snprintf(key, sizeof key, "encoder.%zu.mconv.%d", i, j + 2);
+        if ((rc = fold_bn(h, key, d.filters, S.pw.m_pad, &S.pw))) return rc;
+        j += 3;
+      } else {
+        if (k != 1 || d.stride != 1)
+          return fail(VASR_ERR_UNSUPPORTED, "block %zu: non-separable conv with kernel %d is not implemented", i, k);
+        snprintf(key, sizeof key, "encoder.%zu.mconv.%d.conv.weight", i, j);
+        if ((rc = pack_pointwise(h, key, d.filters, c, &S.pw))) return rc;
+        S.pw.step = step++;
+        h->steps.push_back(LenStep{1, 1, 1, 0});
+        snprintf(key, sizeof key, "encoder.%zu.mconv.%d", i, j + 1);
+        if ((rc = fold_bn(h, key, d.filters, S.pw.m_pad, &S.pw))) return rc;
+        j += 2;
+      }
+      if (r != d.repeat - 1) j += 2;  // activation + dropout entries of the ModuleList
+      c = d.filters;
+    }
+    B.has_res = d.residual != 0;
+    if (B.has_res) {
+      snprintf(key, sizeof key, "encoder.%zu.res.0.0.conv.weight", i);
+      if ((rc = pack_pointwise(h, key, d.filters, cin, &B.res))) return rc;
+      snprintf(key, sizeof key, "encoder.%zu.res.0.1", i);
+      if ((rc = fold_bn(h, key, d.filters, B.res.m_pad, &B.res))) return rc;
+    }
+    if (d.filters % 128)
+      return fail(VASR_ERR_UNSUPPORTED, "block %zu: filters %d is not a multiple of 128", i, d.filters);
+    cin = d.filters;
+    // mid-pipeline buffers hold every block output but the last one, plus a last-block residual
+    if ((i + 1 < h->blocks.size() || B.has_res) && cin > h->c_mid_max) h->c_mid_max = cin;
+  }
+  h->c_last = cin;
+  return upload(h, h->steps, &h->d_steps);
+}
+
+int build_decoder(vasr_handle* h) {
+  int rc;
+  if ((rc = pack_pointwise(h, "decoder_layers.0.weight", h->num_classes, h->dec_feat_in, &h->dec))) return rc;
+  const HostTensor* b;
+  if ((rc = need(h, "decoder_layers.0.bias", h->num_classes, &b))) return rc;
+  std::vector<float> sc(h->dec.m_pad, 1.f), sh(h->dec.m_pad, 0.f);
+  for (int i = 0; i < h->num_classes; ++i) sh[i] = b->data[i];
+  if ((rc = upload(h, sc, &h->dec.d_scale))) return rc;
+  return upload(h, sh, &h->dec.d_shift);
+}
+
+// ---------------- workspace plan ----------------
+struct WsPlan {
+  size_t lens_tab, seq, melp, bufP, bufQ, bufD, bufR, encp, logits, pred, total;
+  int64_t T, Tp0, T1, Tp1;
+};
+
+int64_t enc_frames(const vasr_handle* h, int64_t t) {
+  for (const Block& B : h->blocks)
+    for (const SubBlock& S : B.subs)
+      if (S.separable) t = conv_out_frames(t, S.dw);
+  return t;
+}
+
+WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
+  WsPlan p{};
+  p.T = T;
+  p.Tp0 = pad_frames(T);
+  p.T1 = h->has_encoder ? enc_frames(h, T) : T;
+  // the first (strided) block may still run at T frames inside: size by the larger pitch
+  p.Tp1 = pad_frames(p.T1);
+  const int64_t tp_mid = h->has_encoder ? pad_frames(conv_out_frames(T, h->blocks[0].subs[0].separable
+                                                                          ? h->blocks[0].subs[0].dw
+                                                                          : h->blocks[0].subs[0].pw))
+                                        : p.Tp1;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+  p.lens_tab = take((h->steps.size() + 1) * (size_t)batch * 4);
+  p.seq = take((size_t)batch * 8);
+  p.melp = take((size_t)batch * (h->has_encoder ? h->feat_in : 64) * p.Tp0 * 4);
+  const size_t mid = (size_t)batch * h->c_mid_max * std::max(tp_mid, p.Tp1) * 4;
+  p.bufP = take(h->has_encoder ? mid : 0);
+  p.bufQ = take(h->has_encoder ? mid : 0);
+  p.bufD = take(h->has_encoder ? mid : 0);
+  p.bufR = take(h->has_encoder ? mid : 0);
+  const int c_enc = h->has_encoder ? h->c_last : h->dec_feat_in;
+  p.encp = take((size_t)batch * c_enc * p.Tp1 * 4);
+  p.logits = take(h->has_decoder ? (size_t)batch * h->num_classes * p.Tp1 * 4 : 0);
+  p.pred = take((size_t)batch * p.T1 * 8);
+  p.total = o;
+  return p;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(VASR_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// Encoder over an input [B][feat_in][x_ld]; writes [B][c_last][out_ld] (T1 valid frames).
+int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const int64_t* seq, int batch,
+                float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st) {
+  int32_t* lens_tab = reinterpret_cast<int32_t*>(ws + p.lens_tab);
+  auto lens = [&](int step) { return lens_tab + (size_t)step * batch; };
+  launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st);
+  float* P = reinterpret_cast<float*>(ws + p.bufP);
+  float* Q = reinterpret_cast<float*>(ws + p.bufQ);
+  float* D = reinterpret_cast<float*>(ws + p.bufD);
+  float* R = reinterpret_cast<float*>(ws + p.bufR);
+  const float* cur = x;
+  int64_t cur_ld = x_ld, cur_T = T;
+  for (size_t i = 0; i < h->blocks.size(); ++i) {
+    Block& B = h->blocks[i];
+    const bool last_block = i + 1 == h->blocks.size();
+    if (B.has_res) {
+      // res branch: MaskedConv1d(1x1)(block input, lens_orig) -> BN   (parts/jasper.py:428-436)
+      PwArgs a{};
+      a.wt = B.res.d_w; a.x = cur; a.lens = lens(B.first_step); a.scale = B.res.d_scale; a.shift = B.res.d_shift;
+      a.res = nullptr; a.y = R; a.M = B.res.m_pad; a.K = B.res.cin; a.batch = batch;
+      a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.m_store = B.res.m_pad; a.relu = 0;
+      launch_pointwise(a, st);
+    }
+    const int64_t res_ld = cur_ld;
+    for (size_t r = 0; r < B.subs.size(); ++r) {
+      SubBlock& S = B.subs[r];
+      const bool last_sub = r + 1 == B.subs.size();
+      const float* gx = cur;
+      int64_t gx_ld = cur_ld, g_T = cur_T;
+      const int32_t* g_lens = nullptr;
+      if (S.separable) {
+        const int64_t t_out = conv_out_frames(cur_T, S.dw);
+        const int64_t ld_out = pad_frames(t_out);
+        launch_depthwise(cur, cur_ld, (int)cur_T, S.dw.d_w, lens(S.dw.step), lens(S.dw.step + 1), batch, S.dw.cin,
+                         S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st);
+        gx = D; gx_ld = ld_out; g_T = t_out;
+      } else {
+        g_lens = lens(S.pw.step);  // block input is unmasked: predicate inside the GEMM
+      }
+      float* dst = (cur == P) ? Q : P;
+      int64_t dst_ld = gx_ld;
+      if (last_block && last_sub) { dst = out; dst_ld = out_ld; }
+      PwArgs a{};
+      a.wt = S.pw.d_w; a.x = gx; a.lens = g_lens; a.scale = S.pw.d_scale; a.shift = S.pw.d_shift;
+      a.res = (last_sub && B.has_res) ? R : nullptr;
+      a.y = dst; a.M = S.pw.m_pad; a.K = S.pw.cin; a.batch = batch;
+      a.ldx = gx_ld; a.ldy = dst_ld; a.ldr = res_ld; a.frames = (int)g_T; a.m_store = S.pw.m_pad; a.relu = 1;
+      if (a.res && res_ld != gx_ld)
+        return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
+      launch_pointwise(a, st);
+      cur = dst; cur_ld = dst_ld; cur_T = g_T;
+    }
+  }
+  return check_launch("encoder");
+}
+
+int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int batch, float* logits, float* logp,
+                int64_t* pred, hipStream_t st) {
+  PwArgs a{};
+  a.wt = h->dec.d_w; a.x = encp; a.lens = nullptr; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
+  a.res = nullptr; a.y = logits; a.M = h->dec.m_pad; a.K = h->dec.cin; a.batch = batch;
+  a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.m_store = h->num_classes; a.relu = 0;
+  launch_pointwise(a, st);
+  launch_logsoftmax_argmax(logits, ld, (int64_t)h->num_classes * ld, batch, (int)T1, h->num_classes, logp, pred, st);
+  return check_launch("decoder");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vasr_last_error(void) { return g_err.c_str(); }
+const char* vasr_version(void) { return "vasr-hip 0.1 (gfx950)"; }
+int64_t vasr_padded_frames(int64_t frames) { return pad_frames(frames); }
+
+int vasr_create(const vasr_model_desc* d, vasr_handle** out) {
+  if (!d || !out) return fail(VASR_ERR_INVALID, "null argument");
+  auto* h = new vasr_handle();
+  if (d->frontend) {
+    const vasr_frontend_desc& fe = *d->frontend;
+    if (fe.n_fft != 512 || fe.n_mels != 64) {
+      delete h;
+      return fail(VASR_ERR_UNSUPPORTED, "front end supports n_fft=512, n_mels=64 (got %d, %d)", fe.n_fft, fe.n_mels);
+    }
+    if (fe.win_length <= 0 || fe.win_length > fe.n_fft || fe.hop_length <= 0 || fe.hop_length > 512 ||
+        !fe.h_filterbank) {
+      delete h;
+      // FilterbankFeatures.__init__ raises ValueError for non-positive window sizes (features.py:137-149)
+      return fail(VASR_ERR_INVALID, "invalid window/hop/filterbank in front-end description");
+    }
+    h->has_frontend = true;
+    h->fe = fe;
+    h->fe_window.resize(fe.win_length);
+    for (int i = 0; i < fe.win_length; ++i)
+      h->fe_window[i] = fe.h_window ? fe.h_window[i]
+                                    : (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / (fe.win_length - 1)));
+    h->fe_fb.assign(fe.h_filterbank, fe.h_filterbank + (size_t)fe.n_mels * (fe.n_fft / 2 + 1));
+    h->fe.h_window = nullptr;
+    h->fe.h_filterbank = nullptr;
+  }
+  if (d->n_blocks > 0) {
+    if (!d->blocks || d->feat_in <= 0) { delete h; return fail(VASR_ERR_INVALID, "encoder needs blocks and feat_in"); }
+    h->has_encoder = true;
+    h->feat_in = d->feat_in;
+    for (int i = 0; i < d->n_blocks; ++i) {
+      const vasr_block_desc& b = d->blocks[i];
+      if (b.filters <= 0 || b.repeat <= 0 || b.kernel <= 0 || b.stride <= 0 || b.dilation <= 0) {
+        delete h;
+        return fail(VASR_ERR_INVALID, "block %d has a non-positive field", i);
+      }
+      Block B;
+      B.d = b;
+      h->blocks.push_back(B);
+    }
+  }
+  if (d->num_classes > 0) {
+    if (d->dec_feat_in <= 0 || d->num_classes > 128) {
+      delete h;
+      return fail(VASR_ERR_UNSUPPORTED, "decoder needs dec_feat_in > 0 and at most 128 classes incl. blank");
+    }
+    h->has_decoder = true;
+    h->dec_feat_in = d->dec_feat_in;
+    h->num_classes = d->num_classes;
+  }
+  *out = h;
+  return 0;
+}
+
+void vasr_destroy(vasr_handle* h) {
+  if (!h) return;
+  for (void* p : h->dev_allocs) (void)hipFree(p);
+  delete h;
+}
+
+int vasr_load_weight(vasr_handle* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!h || !key || (!data && ndim > 0)) return fail(VASR_ERR_INVALID, "null argument");
+  if (h->finalized) return fail(VASR_ERR_STATE, "handle already finalized");
+  const size_t n = strlen(key);
+  if (n >= 19 && strcmp(key + n - 19, "num_batches_tracked") == 0) return 0;
+  size_t numel = 1;
+  HostTensor t;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return fail(VASR_ERR_INVALID, "negative dimension in '%s'", key);
+    numel *= (size_t)shape[i];
+    t.shape.push_back(shape[i]);
+  }
+  t.data.assign(data, data + numel);
+  h->weights[key] = std::move(t);
+  return 0;
+}
+
+int vasr_finalize(vasr_handle* h) {
+  if (!h) return fail(VASR_ERR_INVALID, "null handle");
+  if (h->finalized) return 0;
+  int rc;
+  if (h->has_frontend && (rc = build_frontend(h))) return rc;
+  if (h->has_encoder && (rc = build_encoder(h))) return rc;
+  if (h->has_decoder && (rc = build_decoder(h))) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  h->weights.clear();
+  h->finalized = true;
+  return 0;
+}
+
+int64_t vasr_mel_frames(const vasr_handle* h, int64_t samples) {
+  const int hop = (h && h->has_frontend) ? h->fe.hop_length : 160;
+  return 1 + samples / hop;
+}
+
+int64_t vasr_encoded_frames(const vasr_handle* h, int64_t mel_frames) {
+  if (!h || !h->has_encoder || !h->finalized) return mel_frames;
+  return enc_frames(h, mel_frames);
+}
+
+size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, int64_t mel_frames) {
+  if (!h || !h->finalized || batch <= 0) return 0;
+  const int64_t T = samples > 0 ? vasr_mel_frames(h, samples) : mel_frames;
+  return plan_ws(h, batch, T).total;
+}
+
+int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                     float* d_mel, int64_t* d_seq, vasr_stream stream) {
+  if (!h || !h->has_frontend || !h->finalized) return fail(VASR_ERR_STATE, "no finalized front end in this handle");
+  if (batch <= 0 || !d_wav || !d_len || !d_mel || !d_seq) return fail(VASR_ERR_INVALID, "bad argument");
+  if (samples <= h->fe.n_fft / 2)
+    return fail(VASR_ERR_INVALID, "reflect padding needs more than n_fft/2 = %d samples (got %lld)",
+                h->fe.n_fft / 2, (long long)samples);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = (int)vasr_mel_frames(h, samples);
+  launch_seq_len(d_len, batch, h->fe.hop_length, d_seq, st);
+  launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, d_mel, T, T, st);
+  launch_normalize(d_mel, T, d_seq, batch, h->fe.n_mels, T, h->fe.normalize, st);
+  return check_launch("melspec");
+}
+
+int vasr_encoder_f32(vasr_handle* h, const float* d_mel, const int64_t* d_seq, int batch, int64_t mel_frames,
+                     float* d_enc, float* d_enc_len, void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  if (!h || !h->has_encoder || !h->finalized) return fail(VASR_ERR_STATE, "no finalized encoder in this handle");
+  if (batch <= 0 || mel_frames <= 0 || !d_mel || !d_seq || !d_enc || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
+  const WsPlan p = plan_ws(h, batch, mel_frames);
+  if (ws_bytes < p.total) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, p.total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(d_ws);
+  const Block& b0 = h->blocks[0];
+  if (b0.subs[0].separable && !b0.has_res)
+    // block 0 reads the port tensor in place (the generic depthwise kernel copes with the unpadded pitch)
+    return run_encoder(h, d_mel, mel_frames, mel_frames, d_seq, batch, d_enc, p.T1, d_enc_len, ws, p, st);
+  float* melp = reinterpret_cast<float*>(ws + p.melp);
+  launch_repad(d_mel, mel_frames, batch * h->feat_in, (int)mel_frames, melp, p.Tp0, st);
+  return run_encoder(h, melp, p.Tp0, mel_frames, d_seq, batch, d_enc, p.T1, d_enc_len, ws, p, st);
+}
+
+int vasr_decoder_logsoftmax_f32(vasr_handle* h, const float* d_enc, int batch, int64_t enc_frames_, float* d_logp,
+                                void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  if (!h || !h->has_decoder || !h->finalized) return fail(VASR_ERR_STATE, "no finalized decoder in this handle");
+  if (batch <= 0 || enc_frames_ <= 0 || !d_enc || !d_logp || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(enc_frames_);
+  const size_t enc_bytes = align_up((size_t)batch * h->dec_feat_in * ld * 4, 256);
+  const size_t need_bytes = enc_bytes + (size_t)batch * h->num_classes * ld * 4;
+  if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* encp = static_cast<float*>(d_ws);
+  float* logits = reinterpret_cast<float*>(static_cast<char*>(d_ws) + enc_bytes);
+  launch_repad(d_enc, enc_frames_, batch * h->dec_feat_in, (int)enc_frames_, encp, ld, st);
+  return run_decoder(h, encp, ld, enc_frames_, batch, logits, d_logp, nullptr, st);
+}
+
+int vasr_greedy_argmax(const float* d_logp, int batch, int64_t frames, int num_classes, int64_t* d_pred,
+                       vasr_stream stream) {
+  if (!d_logp || !d_pred || batch <= 0 || frames <= 0 || num_classes <= 0) return fail(VASR_ERR_INVALID, "bad argument");
+  launch_argmax(d_logp, batch, frames, num_classes, d_pred, static_cast<hipStream_t>(stream));
+  return check_launch("argmax");
+}
+
+int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blank_id, int32_t* d_ids,
+                      int32_t* d_id_len, vasr_stream stream) {
+  if (!d_pred || !d_ids || !d_id_len || batch <= 0 || frames < 0) return fail(VASR_ERR_INVALID, "bad argument");
+  launch_ctc_collapse(d_pred, batch, frames, blank_id, d_ids, d_id_len, static_cast<hipStream_t>(stream));
+  return check_launch("ctc_collapse");
+}
+
+int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                               int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                               void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  if (!h || !h->finalized || !h->has_frontend || !h->has_encoder || !h->has_decoder)
+    return fail(VASR_ERR_STATE, "handle needs a finalized front end, encoder and decoder");
+  if (batch <= 0 || !d_wav || !d_len || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
+  if (samples <= h->fe.n_fft / 2)
+    return fail(VASR_ERR_INVALID, "reflect padding needs more than n_fft/2 = %d samples (got %lld)",
+                h->fe.n_fft / 2, (long long)samples);
+  const int64_t T = vasr_mel_frames(h, samples);
+  const WsPlan p = plan_ws(h, batch, T);
+  if (ws_bytes < p.total) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, p.total);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(d_ws);
+  int64_t* seq = reinterpret_cast<int64_t*>(ws + p.seq);
+  float* melp = reinterpret_cast<float*>(ws + p.melp);
+  float* encp = reinterpret_cast<float*>(ws + p.encp);
+  float* logits = reinterpret_cast<float*>(ws + p.logits);
+  int64_t* pred = d_pred ? d_pred : reinterpret_cast<int64_t*>(ws + p.pred);
+  launch_seq_len(d_len, batch, h->fe.hop_length, seq, st);
+  launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, melp, p.Tp0,
+                     (int)T, st);
+  launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
+  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st);
+  if (rc) return rc;
+  if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st))) return rc;
+  if (d_ids && d_id_len) launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
+  return check_launch("transcribe");
+}
+
+int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]) {
+  if (!h || !h->finalized || !out) return fail(VASR_ERR_INVALID, "bad argument");
+  for (int i = 0; i < 5; ++i) out[i] = 0.0;
+  int64_t T = vasr_mel_frames(h, samples);
+  if (h->has_frontend) {
+    const double per_frame = 2.5 * 512 * 9 + 2.0 * 257 + 2.0 * 64 * 23;
+    out[4] = per_frame * (double)T * batch;
+  }
+  int64_t t = T;
+  for (const Block& B : h->blocks) {
+    const int64_t t_in = t;
+    for (const SubBlock& S : B.subs) {
+      if (S.separable) {
+        const int64_t to = conv_out_frames(t, S.dw);
+        out[1] += 2.0 * S.dw.kernel * S.dw.cin * (double)to * batch;
+        out[2] += 4.0 * ((double)S.dw.cin * t + (double)S.dw.cin * to) * batch + 4.0 * S.dw.cin * S.dw.kernel;
+        t = to;
+      }
+      out[0] += 2.0 * S.pw.cin * S.pw.cout * (double)t * batch;
+    }
+    if (B.has_res) out[0] += 2.0 * B.res.cin * B.res.cout * (double)t_in * batch;
+  }
+  if (h->has_decoder) out[3] = 2.0 * h->dec_feat_in * h->num_classes * (double)t * batch;
+  return 0;
+}
+
+int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
+                         int64_t frames, int kernel, float* d_y, vasr_stream stream) {
+  if (!d_x || !d_w || !d_lens || !d_y) return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(frames);
+  launch_depthwise(d_x, ld, (int)frames, d_w, d_lens, d_lens, batch, channels, kernel, 1, 1, kernel / 2, d_y, ld,
+                   static_cast<hipStream_t>(stream));
+  return check_launch("bench_depthwise");
+}
+
+int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift, int batch,
+                         int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
+  if (!d_x || !d_wt || !d_scale || !d_shift || !d_y || cout % 128 || cin % 32)
+    return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(frames);
+  PwArgs a{};
+  a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
+  a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
+  a.m_store = cout; a.relu = 1;
+  launch_pointwise(a, static_cast<hipStream_t>(stream));
+  return check_launch("bench_pointwise");
+}
+
+}  // extern "C"

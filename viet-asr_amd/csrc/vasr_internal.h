@@ -1,0 +1,71 @@
+// Internal launch interface between vasr_api.cpp and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vasr {
+
+// Activations live in HBM as [B][C][ld] fp32 with the time axis contiguous and
+// ld = pad_frames(T): every row starts 512-B aligned and every 128-frame GEMM tile stays
+// inside one utterance.  Columns t >= T are padding (never consumed unmasked).
+constexpr int kTimeTile = 128;
+static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
+
+// ---- front end (frontend.hip) ----
+struct FrontendTables {
+  const float* window;   // [512] window already centred/zero padded to n_fft
+  const float* tw256;    // [256][2] e^{-2 pi i m/256}
+  const float* tw512;    // [257][2] e^{-2 pi i k/512}
+  const float* mel_w;    // [64][kMelTaps] packed non-zero filter weights
+  const int32_t* mel_lo; // [64] first fft bin of each filter
+};
+constexpr int kMelTaps = 32;  // >= max non-zeros per Slaney filter at 64 mels / 512 fft (23)
+
+void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, int hop,
+                        float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
+                        hipStream_t st);
+void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st);
+void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,
+                      int normalize, hipStream_t st);
+
+// ---- encoder (encoder_dw.hip, encoder_pw.hip) ----
+struct LenStep { int32_t kernel, stride, dilation, pad; };
+// lens_tab[s][b] = mask length seen by the s-th MaskedConv1d of the main chain; row n_steps = after
+// the last one; enc_len[b] = the reference's float length (quirk Q3).
+void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
+                      float* enc_len, hipStream_t st);
+
+void launch_repad(const float* src, int64_t src_ld, int rows, int frames, float* dst, int64_t dst_ld,
+                  hipStream_t st);
+
+// depthwise masked conv: y[b][c][t] = sum_k w[c][k] * xm[b][c][t*stride + k*dil - pad],
+// xm = x where t < lens_in[b] else 0; y forced to 0 for t >= lens_out[b]; all columns < ldy written.
+void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
+                      const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
+                      int pad, float* y, int64_t ldy, hipStream_t st);
+
+struct PwArgs {
+  const float* wt;        // [K][M] K-major packed weights, M % 128 == 0, K % 32 == 0
+  const float* x;         // [B][K][ldx]
+  const int32_t* lens;    // [B] input mask (nullptr = unmasked)
+  const float* scale;     // [M]
+  const float* shift;     // [M]
+  const float* res;       // [B][M][ldr] added before the ReLU (nullptr = none)
+  float* y;               // [B][M][ldy]
+  int32_t M, K, batch;
+  int64_t ldx, ldy, ldr;
+  int32_t frames;         // columns < frames are stored
+  int32_t m_store;        // rows < m_store are stored (decoder: V+1 of 128)
+  int32_t relu;
+};
+void launch_pointwise(const PwArgs& a, hipStream_t st);
+
+// ---- CTC head / decode (decode.hip) ----
+// logits [B][ldm rows][ld] (row v, column t) -> logp [B][T][V] (optional), pred [B][T] (optional)
+void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
+                              int num_classes, float* logp, int64_t* pred, hipStream_t st);
+void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes, int64_t* pred, hipStream_t st);
+void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids,
+                         int32_t* id_len, hipStream_t st);
+
+}  // namespace vasr

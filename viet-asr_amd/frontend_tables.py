@@ -1,0 +1,88 @@
+"""Host-side constants of the mel front end: window and mel filterbank.
+
+In the reference these are module buffers built in FilterbankFeatures.__init__
+(nemo/collections/asr/parts/features.py:171-205): ``torch.hann_window(win, periodic=False)`` and
+``librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)``.  librosa is a third-party package that is
+neither in the reference tree nor in this image, so the Slaney-scale filterbank is rebuilt here
+from its published definition (float64 maths, float32 result), as librosa does with
+``htk=False, norm='slaney'``.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def mel_filterbank(sr=16000, n_fft=512, n_mels=64, fmin=0.0, fmax=None):
+    """Triangular mel filters on the Slaney scale with area normalisation; [n_mels, n_fft//2+1] f32."""
+    fmax = float(sr) / 2 if fmax is None else float(fmax)
+    lin_step = 200.0 / 3.0            # Hz per mel below 1 kHz
+    brk_hz = 1000.0
+    brk_mel = brk_hz / lin_step
+    log_step = math.log(6.4) / 27.0   # mel step above 1 kHz
+
+    def to_mel(hz):
+        return hz / lin_step if hz < brk_hz else brk_mel + math.log(hz / brk_hz) / log_step
+
+    def to_hz(mel):
+        return lin_step * mel if mel < brk_mel else brk_hz * math.exp(log_step * (mel - brk_mel))
+
+    edges = np.array([to_hz(m) for m in np.linspace(to_mel(float(fmin)), to_mel(fmax), n_mels + 2)])
+    bins = np.linspace(0.0, float(sr) / 2, n_fft // 2 + 1)
+    fb = np.zeros((n_mels, bins.size))
+    for i in range(n_mels):
+        lo, ce, hi = edges[i], edges[i + 1], edges[i + 2]
+        rise = (bins - lo) / (ce - lo)
+        fall = (hi - bins) / (hi - ce)
+        fb[i] = np.maximum(0.0, np.minimum(rise, fall)) * (2.0 / (hi - lo))
+    return fb.astype(np.float32)
+
+
+def frontend_description(pre_cfg):
+    """AudioToMelSpectrogramPreprocessor kwargs (audio_preprocessing.py:314-373) -> library front-end dict.
+
+    Mirrors the constructor's argument handling and its ValueErrors; dither and pad_to are
+    accepted and must be inference values (infer.py:89-90 forces dither=0, pad_to=0).
+    """
+    c = dict(pre_cfg)
+    sr = int(c.get("sample_rate", 16000))
+    ws, wst = c.get("window_size", 0.02), c.get("window_stride", 0.01)
+    nws, nwst = c.get("n_window_size"), c.get("n_window_stride")
+    if ws and nws:
+        raise ValueError("received both window_size and n_window_size. Only one should be specified.")
+    if wst and nwst:
+        raise ValueError("received both window_stride and n_window_stride. Only one should be specified.")
+    if ws:
+        nws = int(ws * sr)
+    if wst:
+        nwst = int(wst * sr)
+    if not isinstance(nws, int) or not isinstance(nwst, int) or nws <= 0 or nwst <= 0:
+        raise ValueError("got an invalid value for either n_window_size or n_window_stride. "
+                         "Both must be positive ints.")
+    n_fft = c.get("n_fft") or 2 ** math.ceil(math.log2(nws))
+    if c.get("stft_conv", False):
+        raise NotImplementedError("stft_conv=True (torch_stft conv STFT) is not implemented; the vi config "
+                                  "uses stft_conv=false")
+    if c.get("log", True) is not True or c.get("log_zero_guard_type", "add") != "add":
+        raise NotImplementedError("only log=True with log_zero_guard_type='add' is implemented")
+    if float(c.get("mag_power", 2.0)) != 2.0 or int(c.get("frame_splicing", 1)) != 1:
+        raise NotImplementedError("only mag_power=2, frame_splicing=1 are implemented")
+    guard = c.get("log_zero_guard_value", 2 ** -24)
+    if isinstance(guard, str):
+        guard = {"tiny": torch.finfo(torch.float32).tiny, "eps": torch.finfo(torch.float32).eps}[guard]
+    window = c.get("window", "hann")
+    fns = {"hann": torch.hann_window, "hamming": torch.hamming_window, "blackman": torch.blackman_window,
+           "bartlett": torch.bartlett_window}
+    if window not in fns:
+        raise NotImplementedError(f"window {window!r} is not implemented")
+    win = fns[window](nws, periodic=False).to(torch.float32).numpy()
+    n_mels = int(c.get("features", 64))
+    fb = mel_filterbank(sr, n_fft, n_mels, c.get("lowfreq", 0) or 0.0, c.get("highfreq") or sr / 2)
+    norm = c.get("normalize", "per_feature")
+    if norm not in ("per_feature", None, False, ""):
+        raise NotImplementedError(f"normalize={norm!r} is not implemented (per_feature or none)")
+    if float(c.get("pad_value", 0)) != 0.0:
+        raise NotImplementedError("pad_value other than 0 is not implemented")
+    return dict(sample_rate=sr, n_fft=int(n_fft), win_length=nws, hop_length=nwst, n_mels=n_mels,
+                preemph=c.get("preemph", 0.97), log_guard=float(guard),
+                normalize="per_feature" if norm == "per_feature" else "none", window=win, filterbank=fb)
