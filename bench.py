@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job throughput of the viet-asr hot path on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model quartznet15x5] [--batch 64] [--seconds 10]
+
+One *step* = one pass of the hot path (wav already resident in HBM -> mel -> QuartzNet encoder ->
+CTC head -> greedy argmax -> CTC collapse) over one batch of synthetic 16 kHz audio per GPU, then
+the gather of the collapsed id sequences to every rank (the reference's _infer gathers each
+returned tensor with all_gather, nemo/backends/pytorch/actions.py:774-807).  Utterances are
+independent, so ranks shard them with no other data-path collective: weak scaling, per-GPU work
+fixed.  Workload at any N: BASELINE.json configs[2] = QuartzNet15x5, batch 64 x 10 s per GPU
+(the configuration the metric/target is quoted on).
+
+Prints ONE JSON line on rank 0 with the driver contract keys plus
+  roofline      -- dominant kernel (1x1-conv fp32 MFMA GEMM): algorithmic flops / HIP-event time
+  depthwise     -- depthwise-conv kernels: algorithmic HBM bytes / HIP-event time vs 8 TB/s
+  cpu_baseline  -- the CPU oracle (same ATen ops as the reference) on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import viet_asr_amd  # noqa: E402,F401
+from viet_asr_amd import configs, synth  # noqa: E402
+from viet_asr_amd.engine import QuartzNetCTC  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # same guide, HBM3E spec peak
+
+
+def cpu_baseline(model, seed, seconds, budget_s=20.0):
+    """Time the CPU oracle (port of the reference path on the same ATen CPU ops) on a bounded sample."""
+    from oracle import quartznet_oracle as O   # checker / baseline only -- never on the product path
+    cfg = configs.builtin(model)
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd = synth.encoder_state_dict(jas, 64, seed)
+    dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
+    b = 8
+    sig, lens = synth.audio_batch(b, int(seconds * 16000), seed, ragged=False)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.forward_all(sig, lens, enc_sd, dec_sd, jas)          # warm-up
+        warm = time.perf_counter() - t0
+        times = []
+        while len(times) < 3 and sum(times) + warm < budget_s:
+            t0 = time.perf_counter()
+            r = O.forward_all(sig, lens, enc_sd, dec_sd, jas)
+            O.ctc_decode_strings(r["pred"], cfg["labels"])
+            times.append(time.perf_counter() - t0)
+    best = min(times) if times else warm
+    return {"value": round(b * seconds / best, 2), "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
+            "sample": f"{model} greedy, batch {b} x {seconds:g} s, best of {max(len(times), 1)} after 1 warm-up",
+            "utts_per_sec": round(b / best, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="quartznet15x5")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--ragged", action="store_true", help="lengths uniform in [L/2, L] instead of full clips")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)   # RCCL over xGMI
+
+    seed = 3
+    cfg = configs.builtin(a.model)
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd = synth.encoder_state_dict(jas, 64, seed)
+    dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
+    eng = QuartzNetCTC(cfg, enc_sd, dec_sd, device=dev)
+    samples = int(a.seconds * 16000)
+    sig, lens = synth.audio_batch(a.batch, samples, seed + 100 * rank, ragged=a.ragged)
+    wav = torch.from_numpy(sig).to(dev)
+    ln = torch.from_numpy(lens).to(dev)
+    audio_sec_per_step = float(lens.sum()) / 16000.0
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        r = eng.forward(wav, ln, want_logp=False, want_pred=False)
+        if dist is not None:
+            # result gather, one collective per returned tensor like actions.py:774-807
+            if gathered is None:
+                gathered = (torch.empty((world,) + tuple(r["ids"].shape), dtype=torch.int32, device=dev),
+                            torch.empty((world, a.batch), dtype=torch.int32, device=dev))
+            dist.all_gather_into_tensor(gathered[0], r["ids"])
+            dist.all_gather_into_tensor(gathered[1], r["id_len"])
+        return r
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([audio_sec_per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        audio_all = float(tot.item())
+    else:
+        audio_all = audio_sec_per_step
+
+    # ---- second pass, same K steps, with per-kernel-class HIP events on the launch stream ----
+    eng.handle.profile_begin()
+    for _ in range(a.steps):
+        eng.forward(wav, ln, want_logp=False, want_pred=False)
+    torch.cuda.synchronize()
+    prof = eng.handle.profile_end()
+    work = eng.handle.algorithmic_work(a.batch, samples)
+
+    if rank == 0:
+        hyp = eng.texts(r["ids"], r["id_len"])
+        pw_ms = prof["pointwise"]["ms"] / a.steps
+        dw_ms = prof["depthwise"]["ms"] / a.steps
+        pw_tflops = work["pointwise_flops"] / (pw_ms * 1e-3) / 1e12
+        dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
+        out = {
+            "metric": "real_time_factor", "value": round(audio_all * a.steps / elapsed, 1),
+            "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.model} greedy CTC, batch={a.batch}x{a.seconds:g}s 16kHz mono per GPU"
+                                   f"{' (ragged lengths)' if a.ragged else ''}, wav in HBM -> collapsed ids",
+                       "batch_per_gpu": a.batch, "clip_seconds": a.seconds, "parallelism": f"utterance-shard x{world}"},
+            "utts_per_sec": round(a.batch * world * a.steps / elapsed, 1),
+            "roofline": {"kernel": "pw_gemm_kernel (1x1 conv fp32 MFMA GEMM + BN/residual/ReLU epilogue)",
+                         "bound": "mfma", "achieved": round(pw_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(pw_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
+                         "launches_per_step": prof["pointwise"]["launches"] // a.steps},
+            "depthwise": {"kernel": "dw_conv_kernel<K>", "bound": "hbm", "achieved": round(dw_gbs, 1),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4),
+                          "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
+                          "launches_per_step": prof["depthwise"]["launches"] // a.steps},
+            "other_ms_per_step": {"frontend": round(prof["frontend"]["ms"] / a.steps, 3),
+                                  "head": round(prof["head"]["ms"] / a.steps, 3)},
+            "sample_transcript": hyp[0][:32],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.model, seed, a.seconds)
+        print(json.dumps(out, ensure_ascii=False))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

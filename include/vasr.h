@@ -149,12 +149,23 @@ const char* vasr_version(void);
  * out[0]=pointwise_flops out[1]=depthwise_flops out[2]=depthwise_bytes out[3]=decoder_flops
  * out[4]=frontend_flops (2.5 N log2 N per frame + mel) */
 int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]);
+/* Per-kernel-class timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figures).  Between begin and end every launch of vasr_transcribe_greedy_f32 /
+ * vasr_encoder_f32 / vasr_decoder_* is bracketed by an event pair; end() synchronises on the events
+ * and returns the summed milliseconds and launch counts per class:
+ *   [0] front end (seq_len + STFT/mel + CMVN)  [1] depthwise convs  [2] pointwise GEMMs
+ *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse) */
+int vasr_profile_begin(vasr_handle* h);
+int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]);
 /* Run ONE encoder layer kind in isolation for benchmarking/roofline measurement:
  * kind 0 = depthwise (K, stride 1, dilation 1), 1 = pointwise GEMM (+BN+ReLU epilogue).
  * Buffers are caller provided [B][C][Tp] with Tp = vasr_padded_frames(T). */
 int64_t vasr_padded_frames(int64_t frames);
 int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
                          int64_t frames, int kernel, float* d_y, vasr_stream stream);
+/* Host helper: [cout][cin] row-major weights -> the MFMA fragment order the pointwise kernel streams
+ * ([m_pad/32][cin/8][64 lanes][4], rows past cout zero); h_out holds m_pad*cin floats. */
+int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out);
 int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
                          int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 

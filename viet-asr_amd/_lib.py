@@ -8,6 +8,9 @@ import ctypes as C
 import os
 
 import numpy as np
+import torch  # noqa: F401  -- must be imported BEFORE the .so: torch ships its own HIP runtime, and the
+#                library has to bind to that already-loaded copy (loading /opt/rocm's first leaves two
+#                runtimes in the process and hipMalloc then reports "no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvasr_hip.so")
@@ -54,7 +57,10 @@ SIGNATURES = {
     "vasr_last_error": (C.c_char_p, []),
     "vasr_version": (C.c_char_p, []),
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
+    "vasr_profile_begin": (C.c_int, [_P]),
+    "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vasr_padded_frames": (C.c_int64, [C.c_int64]),
+    "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_bench_depthwise": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
@@ -156,6 +162,15 @@ class Handle:
         check(lib().vasr_algorithmic_work(self.h, int(batch), int(samples), out))
         return dict(pointwise_flops=out[0], depthwise_flops=out[1], depthwise_bytes=out[2],
                     decoder_flops=out[3], frontend_flops=out[4])
+
+    def profile_begin(self):
+        check(lib().vasr_profile_begin(self.h))
+
+    def profile_end(self):
+        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        check(lib().vasr_profile_end(self.h, ms, n))
+        names = ("frontend", "depthwise", "pointwise", "head")
+        return {k: dict(ms=ms[i], launches=int(n[i])) for i, k in enumerate(names)}
 
     def close(self):
         if getattr(self, "h", None):

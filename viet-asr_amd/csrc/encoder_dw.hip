@@ -16,6 +16,7 @@ namespace vasr {
 namespace {
 
 constexpr int kTile = 512;  // outputs per wavefront (2 groups x 64 lanes x 4)
+using v4f = __attribute__((ext_vector_type(4))) float;  // native vector: one ds_read_b128 / global dwordx4
 
 template <int K>
 struct DwGeom {
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ lens_out, int channels,
                                                       float* __restrict__ y, int64_t ldy) {
   using G = DwGeom<K>;
-  __shared__ __attribute__((aligned(16))) float lds[4 * G::WIN];
+  __shared__ v4f lds4[4 * G::WIN / 4];  // vector-typed so every window access is a provable ds_*_b128
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x * 4 + wave;
@@ -44,19 +45,19 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
   const int len_out = lens_out[b];
   const int64_t row = (int64_t)b * channels + c;
   const float* xr = x + row * ldx;
-  float* win = lds + wave * G::WIN;
+  v4f* win4 = lds4 + wave * (G::WIN / 4);
 
   // ---- stage masked window: LDS index i <-> frame t_start - PADL + i ----
   for (int i4 = lane; i4 < G::WIN / 4; i4 += 64) {
     const int t = t_start - G::PADL + 4 * i4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    v4f v = {0.f, 0.f, 0.f, 0.f};
     if (t >= 0 && t < len_in && t + 3 < ldx) {
-      v = *reinterpret_cast<const float4*>(xr + t);
+      v = *reinterpret_cast<const v4f*>(xr + t);
       if (t + 1 >= len_in) v.y = 0.f;     // MaskedConv1d: x.masked_fill(t >= lens, 0)  (jasper.py:113-118)
       if (t + 2 >= len_in) v.z = 0.f;
       if (t + 3 >= len_in) v.w = 0.f;
     }
-    *reinterpret_cast<float4*>(win + 4 * i4) = v;
+    win4[i4] = v;
   }
   __syncthreads();
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     float xw[4 * G::NQ];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(win + base + 4 * q);
+      const v4f v = win4[g * 64 + lane + q];
       xw[4 * q + 0] = v.x; xw[4 * q + 1] = v.y; xw[4 * q + 2] = v.z; xw[4 * q + 3] = v.w;
     }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -82,12 +83,12 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     const int t = t_start + base;
     if (t < ldy) {
       // the following 1x1 MaskedConv1d masks with lens_out: zero here so the GEMM needs no predicate
-      float4 o;
+      v4f o;
       o.x = (t + 0 < len_out) ? a0 : 0.f;
       o.y = (t + 1 < len_out) ? a1 : 0.f;
       o.z = (t + 2 < len_out) ? a2 : 0.f;
       o.w = (t + 3 < len_out) ? a3 : 0.f;
-      *reinterpret_cast<float4*>(y + row * ldy + t) = o;
+      *reinterpret_cast<v4f*>(y + row * ldy + t) = o;
     }
   }
 }

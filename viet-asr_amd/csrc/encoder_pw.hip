@@ -6,18 +6,24 @@
 //   [-> + residual branch output (:438-439)]  ->  ReLU (:405 / mout :444)
 // and the CTC head's Conv1d(1024, V+1, 1, bias=True) (jasper.py:249).
 //
-//   Y[b][m][t] = act( scale[m] * sum_k Wt[k][m] * Xm[b][k][t] + shift[m] (+ R[b][m][t]) )
+//   Y[b][m][t] = act( scale[m] * sum_k W[m][k] * Xm[b][k][t] + shift[m] (+ R[b][m][t]) )
 //
 // Exact-fp32 arithmetic on the matrix cores: v_mfma_f32_32x32x2_f32 accumulates as a k-ordered
-// fmaf chain (no TF32/xf32 exists on gfx950), which keeps greedy argmax parity with the fp32
-// reference.  Workgroup tile 128(M) x 128(T) x 32(K), 4 wavefronts in a 2x2 grid, each owning a
-// 64x64 block = 2x2 MFMA tiles (64 accumulator VGPRs).  Weights are pre-packed K-major so both
-// operand tiles land in LDS with 16-byte coalesced loads and are read back conflict-free
-// (32 consecutive floats per half-wave).  Global loads of tile k+1 are issued before the MFMAs
-// of tile k (register-staged prefetch).
+// fmaf chain (gfx950 has no TF32/xf32), which keeps greedy argmax parity with the fp32 reference.
 //
-// Work-group ids are remapped so that the M-tiles sharing one activation tile run on the same
-// XCD (the 8 XCDs have private L2s; block b lands on XCD b % 8).
+// Structure ("weights stream, activations stay"):
+//   * 8 wavefronts per workgroup, each owning a 64(M) x 64(T) output block = 2x2 MFMA tiles
+//     (64 accumulator VGPRs).  Wave grid WM x WN = 8x1 / 4x2 / 2x4 so one workgroup covers
+//     512x64, 256x128 or 128x256 outputs: for the 256- and 512-channel layers ONE workgroup
+//     computes every output channel of its time tile, so each activation element is fetched
+//     from HBM exactly once per layer.
+//   * The activation (B) operand goes through LDS in 32 KB K-chunks, double buffered: one
+//     barrier per chunk (64..256 MFMAs per wave between barriers).
+//   * The weight (A) operand never touches LDS: weights are pre-packed at vasr_finalize() in MFMA
+//     fragment order ([m-tile][k-group][lane][4]) so that every lane fetches its operands for four
+//     k-steps with one coalesced 16-byte load straight from L2, one k-group ahead of use.
+//   * Work-group ids are remapped so that neighbours in (m-block, time-tile) order share an XCD
+//     (private L2 per XCD; block b lands on XCD b % 8).
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -25,27 +31,25 @@ namespace vasr {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDA = BM + 4;  // +4 floats: keeps 16-B alignment, breaks the 512-B row pitch for the stores
-constexpr int LDB = BN + 4;
+constexpr int kChunkFloats = 8192;  // 32 KB of activations per LDS buffer
 
-template <bool MASK>
-__device__ __forceinline__ float4 load_b(const float* __restrict__ p, int t, int len) {
-  float4 v = *reinterpret_cast<const float4*>(p);
-  if (MASK) {
-    if (t + 0 >= len) v.x = 0.f;
-    if (t + 1 >= len) v.y = 0.f;
-    if (t + 2 >= len) v.z = 0.f;
-    if (t + 3 >= len) v.w = 0.f;
-  }
-  return v;
-}
+template <int WM>
+struct PwGeom {
+  static constexpr int WN = 8 / WM;
+  static constexpr int BM = 64 * WM;
+  static constexpr int BN = 64 * WN;
+  static constexpr int BKC = kChunkFloats / BN;  // 128 / 64 / 32 rows of K per chunk
+  static constexpr int GROUPS = BKC / 8;         // k-groups (8 k = 4 MFMA k-steps) per chunk
+  static constexpr int ROWS_PER_PASS = 512 / (BN / 4);
+  static constexpr int PASSES = BKC / ROWS_PER_PASS;  // == 4 dwordx4 per thread per chunk
+};
 
-template <bool MASK, bool RES>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a, int tiles_m, int tiles_t, int n_blocks) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+template <int WM, bool MASK, bool RES>
+__global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+  using G = PwGeom<WM>;
+  __shared__ v4f Bs4[2][kChunkFloats / 4];
 
   // ---- XCD-aware remap: consecutive logical ids -> same XCD ----
   int bid = blockIdx.x;
@@ -53,19 +57,26 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a, int tiles_m, int
     const int q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, slot = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int mt = bid % tiles_m;
-  const int nt = bid / tiles_m;
+  const int mb = bid % blocks_m;
+  const int nt = bid / blocks_m;
   const int b = nt / tiles_t;
-  const int t0 = (nt % tiles_t) * BN;
-  const int m0 = mt * BM;
+  const int t0 = (nt % tiles_t) * G::BN;
+  const int m0 = mb * G::BM;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int ld_row = tid >> 5, ld_col = (tid & 31) * 4;  // 8 rows x 128 cols per pass, 4 passes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64;
+  const int kh = lane >> 5, l31 = lane & 31;
   const int len = MASK ? a.lens[b] : 0;
 
-  const float* __restrict__ wt = a.wt + m0;
-  const float* __restrict__ xb = a.x + (int64_t)b * a.K * a.ldx + t0;
+  // B staging: thread -> (row, 4 consecutive columns) of the [BKC][BN] chunk
+  constexpr int C4 = G::BN / 4;
+  const int ld_row = tid / C4, ld_c4 = tid % C4;
+  const float* __restrict__ xb = a.x + (int64_t)b * a.K * a.ldx + t0 + ld_c4 * 4;
+  // A fragments: packed [M/32][K/8][64 lanes] float4, this wave's two m-tiles
+  const int kgroups = a.K / 8;
+  const v4f* __restrict__ ap0 = reinterpret_cast<const v4f*>(a.wt) + ((int64_t)((m0 + wm) / 32) * kgroups) * 64 + lane;
+  const v4f* __restrict__ ap1 = ap0 + (int64_t)kgroups * 64;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -75,80 +86,121 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a, int tiles_m, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  v4f rb[G::PASSES];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int kr = k0 + ld_row + 8 * p;
-      ra[p] = *reinterpret_cast<const float4*>(wt + (int64_t)kr * a.M + ld_col);
-      rb[p] = load_b<MASK>(xb + (int64_t)kr * a.ldx + ld_col, t0 + ld_col, len);
+    for (int p = 0; p < G::PASSES; ++p) {
+      const int kr = k0 + ld_row + G::ROWS_PER_PASS * p;
+      v4f v = *reinterpret_cast<const v4f*>(xb + (int64_t)kr * a.ldx);
+      if (MASK) {  // MaskedConv1d: x.masked_fill(t >= lens, 0)  (jasper.py:113-118)
+        const int t = t0 + ld_c4 * 4;
+        if (t + 0 >= len) v.x = 0.f;
+        if (t + 1 >= len) v.y = 0.f;
+        if (t + 2 >= len) v.z = 0.f;
+        if (t + 3 >= len) v.w = 0.f;
+      }
+      rb[p] = v;
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(&As[(ld_row + 8 * p) * LDA + ld_col]) = ra[p];
-      *reinterpret_cast<float4*>(&Bs[(ld_row + 8 * p) * LDB + ld_col]) = rb[p];
-    }
+    for (int p = 0; p < G::PASSES; ++p) Bs4[buf][(ld_row + G::ROWS_PER_PASS * p) * C4 + ld_c4] = rb[p];
   };
 
-  const int nk = a.K / BK;
+  const int nchunks = a.K / G::BKC;
   gload(0);
-  sstore();
+  v4f a0 = ap0[0], a1 = ap1[0];
+  sstore(0);
   __syncthreads();
-  const int kh = lane >> 5, l31 = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) gload((c + 1) * G::BKC);
+    const float* __restrict__ Bs = reinterpret_cast<const float*>(Bs4[c & 1]) + wn + l31;
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 2) {
-      const float a0 = As[(ks + kh) * LDA + wm + l31];
-      const float a1 = As[(ks + kh) * LDA + wm + 32 + l31];
-      const float b0 = Bs[(ks + kh) * LDB + wn + l31];
-      const float b1 = Bs[(ks + kh) * LDB + wn + 32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int g = 0; g < G::GROUPS; ++g) {
+      // fetch next k-group's weights (clamped at the very end: a harmless re-read)
+      const int gi = c * G::GROUPS + g;
+      const int gn = gi + 1 < kgroups ? gi + 1 : gi;
+      const v4f n0 = ap0[(int64_t)gn * 64], n1 = ap1[(int64_t)gn * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = g * 8 + 2 * s + kh;
+        const float b0 = Bs[kk * G::BN];
+        const float b1 = Bs[kk * G::BN + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1, acc[1][1], 0, 0, 0);
+      }
+      a0 = n0;
+      a1 = n1;
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      sstore();
+    if (c + 1 < nchunks) {
+      sstore((c + 1) & 1);
       __syncthreads();
     }
   }
 
-  // ---- epilogue: BN affine (+ residual) + ReLU, 128-B row segments per half-wave ----
-  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // ---- epilogue: BN affine (+ residual) + ReLU; each half-wave writes 128-byte row segments ----
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const bool full = (t0 + G::BN <= a.store_cols) && (m0 + G::BM <= a.m_store);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      const float sc = a.scale[m], sh = a.shift[m];
+    for (int q = 0; q < 4; ++q) {
+      const int mq = m0 + wm + i * 32 + 8 * q + 4 * kh;
+      const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq);
+      const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int t = t0 + wn + j * 32 + l31;
-        float v = fmaf(acc[i][j][r], sc, sh);
-        if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (t < a.frames && m < a.m_store) a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = mq + rr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = t0 + wn + j * 32 + l31;
+          float v = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
+          if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (full || (t < a.store_cols && m < a.m_store)) a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
+        }
       }
     }
   }
 }
 
+template <int WM>
+void launch_t(const PwArgs& a, hipStream_t st) {
+  using G = PwGeom<WM>;
+  const int blocks_m = a.M / G::BM;
+  const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
+  const int n_blocks = blocks_m * tiles_t * a.batch;
+  dim3 grid(n_blocks), block(512);
+  const bool mask = a.lens != nullptr, res = a.res != nullptr;
+  if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+}
+
 }  // namespace
 
 void launch_pointwise(const PwArgs& a, hipStream_t st) {
-  const int tiles_m = a.M / BM;
-  const int tiles_t = (int)((a.ldx + BN - 1) / BN);
-  const int n_blocks = tiles_m * tiles_t * a.batch;
-  dim3 grid(n_blocks), block(256);
-  const bool mask = a.lens != nullptr, res = a.res != nullptr;
-  if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<true, true>), grid, block, 0, st, a, tiles_m, tiles_t, n_blocks);
-  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<true, false>), grid, block, 0, st, a, tiles_m, tiles_t, n_blocks);
-  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<false, true>), grid, block, 0, st, a, tiles_m, tiles_t, n_blocks);
-  else hipLaunchKernelGGL((pw_gemm_kernel<false, false>), grid, block, 0, st, a, tiles_m, tiles_t, n_blocks);
+  // M % 128 == 0, K % 32 == 0 and ldx % 256 == 0 are guaranteed by vasr_finalize()/pad_frames()
+  if (a.M % 512 == 0 && a.K % 128 == 0) launch_t<8>(a, st);
+  else if (a.M % 256 == 0 && a.K % 64 == 0) launch_t<4>(a, st);
+  else launch_t<2>(a, st);
+}
+
+// [cout][cin] row-major -> MFMA A-fragment order [m_pad/32][cin/8][64 lanes][4]:
+//   lane (l31, kh), element s  <-  W[mt*32 + l31][g*8 + 2*s + kh]
+void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float* out) {
+  const int kgroups = cin / 8;
+  for (int mt = 0; mt < m_pad / 32; ++mt)
+    for (int g = 0; g < kgroups; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) {
+          const int m = mt * 32 + (lane & 31), k = g * 8 + 2 * s + (lane >> 5);
+          out[(((size_t)mt * kgroups + g) * 64 + lane) * 4 + s] = m < cout ? w[(size_t)m * cin + k] : 0.f;
+        }
 }
 
 }  // namespace vasr

@@ -80,6 +80,11 @@ struct vasr_handle {
   LenStep* d_steps = nullptr;
   ConvLayer dec;
   int c_mid_max = 0, c_last = 0;
+  // optional per-kernel-class HIP-event timing (vasr_profile_begin/end)
+  bool profiling = false;
+  struct ProfRec { hipEvent_t a, b; int cls; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -139,7 +144,7 @@ int fold_bn(vasr_handle* h, const std::string& prefix, int c, int c_pad, ConvLay
   return upload(h, sh, &L->d_shift);
 }
 
-// [cout][cin][1] -> K-major [cin][m_pad]
+// [cout][cin][1] -> MFMA A-fragment order
 int pack_pointwise(vasr_handle* h, const std::string& key, int cout, int cin, ConvLayer* L) {
   const HostTensor* w;
   int rc;
@@ -149,8 +154,7 @@ int pack_pointwise(vasr_handle* h, const std::string& key, int cout, int cin, Co
   L->cout = cout;
   L->m_pad = (int)align_up(cout, 128);
   std::vector<float> wt((size_t)cin * L->m_pad, 0.f);
-  for (int m = 0; m < cout; ++m)
-    for (int k = 0; k < cin; ++k) wt[(size_t)k * L->m_pad + m] = w->data[(size_t)m * cin + k];
+  pack_pointwise_weights(w->data.data(), cout, cin, L->m_pad, wt.data());
   return upload(h, wt, &L->d_w);
 }
 
@@ -310,6 +314,28 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
   return p;
 }
 
+// Brackets one launch (or a short launch group) with HIP events on the launch stream.
+struct ProfScope {
+  vasr_handle* h; hipStream_t st; hipEvent_t a{}, b{}; int cls;
+  static hipEvent_t get(vasr_handle* h) {
+    hipEvent_t e;
+    if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  ProfScope(vasr_handle* h_, int cls_, hipStream_t st_) : h(h_), st(st_), cls(cls_) {
+    if (!h->profiling) return;
+    a = get(h); b = get(h);
+    (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (!h->profiling) return;
+    (void)hipEventRecord(b, st);
+    h->prof.push_back({a, b, cls});
+  }
+};
+enum { kProfFrontend = 0, kProfDepthwise = 1, kProfPointwise = 2, kProfHead = 3 };
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(VASR_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
@@ -336,7 +362,9 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       PwArgs a{};
       a.wt = B.res.d_w; a.x = cur; a.lens = lens(B.first_step); a.scale = B.res.d_scale; a.shift = B.res.d_shift;
       a.res = nullptr; a.y = R; a.M = B.res.m_pad; a.K = B.res.cin; a.batch = batch;
-      a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.m_store = B.res.m_pad; a.relu = 0;
+      a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
+      a.m_store = B.res.m_pad; a.relu = 0;
+      ProfScope ps(h, kProfPointwise, st);
       launch_pointwise(a, st);
     }
     const int64_t res_ld = cur_ld;
@@ -349,6 +377,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       if (S.separable) {
         const int64_t t_out = conv_out_frames(cur_T, S.dw);
         const int64_t ld_out = pad_frames(t_out);
+        ProfScope ps(h, kProfDepthwise, st);
         launch_depthwise(cur, cur_ld, (int)cur_T, S.dw.d_w, lens(S.dw.step), lens(S.dw.step + 1), batch, S.dw.cin,
                          S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st);
         gx = D; gx_ld = ld_out; g_T = t_out;
@@ -363,9 +392,13 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.res = (last_sub && B.has_res) ? R : nullptr;
       a.y = dst; a.M = S.pw.m_pad; a.K = S.pw.cin; a.batch = batch;
       a.ldx = gx_ld; a.ldy = dst_ld; a.ldr = res_ld; a.frames = (int)g_T; a.m_store = S.pw.m_pad; a.relu = 1;
+      a.store_cols = (dst_ld % kTimeTile == 0) ? (int)dst_ld : (int)g_T;  // port tensors are not padded
       if (a.res && res_ld != gx_ld)
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
-      launch_pointwise(a, st);
+      {
+        ProfScope ps(h, kProfPointwise, st);
+        launch_pointwise(a, st);
+      }
       cur = dst; cur_ld = dst_ld; cur_T = g_T;
     }
   }
@@ -377,7 +410,9 @@ int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int b
   PwArgs a{};
   a.wt = h->dec.d_w; a.x = encp; a.lens = nullptr; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
   a.res = nullptr; a.y = logits; a.M = h->dec.m_pad; a.K = h->dec.cin; a.batch = batch;
-  a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.m_store = h->num_classes; a.relu = 0;
+  a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
+  a.relu = 0;
+  ProfScope ps(h, kProfHead, st);
   launch_pointwise(a, st);
   launch_logsoftmax_argmax(logits, ld, (int64_t)h->num_classes * ld, batch, (int)T1, h->num_classes, logp, pred, st);
   return check_launch("decoder");
@@ -447,6 +482,8 @@ int vasr_create(const vasr_model_desc* d, vasr_handle** out) {
 void vasr_destroy(vasr_handle* h) {
   if (!h) return;
   for (void* p : h->dev_allocs) (void)hipFree(p);
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -576,15 +613,46 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
   float* encp = reinterpret_cast<float*>(ws + p.encp);
   float* logits = reinterpret_cast<float*>(ws + p.logits);
   int64_t* pred = d_pred ? d_pred : reinterpret_cast<int64_t*>(ws + p.pred);
-  launch_seq_len(d_len, batch, h->fe.hop_length, seq, st);
-  launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, melp, p.Tp0,
-                     (int)T, st);
-  launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
+  {
+    ProfScope ps(h, kProfFrontend, st);
+    launch_seq_len(d_len, batch, h->fe.hop_length, seq, st);
+    launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, melp, p.Tp0,
+                       (int)T, st);
+    launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
+  }
   int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st);
   if (rc) return rc;
   if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st))) return rc;
-  if (d_ids && d_id_len) launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
+  if (d_ids && d_id_len) {
+    ProfScope ps(h, kProfHead, st);
+    launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
+  }
   return check_launch("transcribe");
+}
+
+int vasr_profile_begin(vasr_handle* h) {
+  if (!h) return fail(VASR_ERR_INVALID, "null handle");
+  for (auto& r : h->prof) { h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b); }
+  h->prof.clear();
+  h->profiling = true;
+  return 0;
+}
+
+int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]) {
+  if (!h || !ms || !launches) return fail(VASR_ERR_INVALID, "bad argument");
+  h->profiling = false;
+  for (int i = 0; i < 4; ++i) { ms[i] = 0.0; launches[i] = 0; }
+  for (auto& r : h->prof) {
+    HIP_TRY(hipEventSynchronize(r.b));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cls] += t;
+    launches[r.cls] += 1;
+    h->ev_pool.push_back(r.a);
+    h->ev_pool.push_back(r.b);
+  }
+  h->prof.clear();
+  return 0;
 }
 
 int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]) {
@@ -622,6 +690,12 @@ int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_le
   return check_launch("bench_depthwise");
 }
 
+int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out) {
+  if (!h_w || !h_out || cout <= 0 || cin % 8 || m_pad % 32 || m_pad < cout) return fail(VASR_ERR_INVALID, "bad argument");
+  pack_pointwise_weights(h_w, cout, cin, m_pad, h_out);
+  return 0;
+}
+
 int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift, int batch,
                          int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
   if (!d_x || !d_wt || !d_scale || !d_shift || !d_y || cout % 128 || cin % 32)
@@ -630,7 +704,7 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   PwArgs a{};
   a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
-  a.m_store = cout; a.relu = 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
   launch_pointwise(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise");
 }

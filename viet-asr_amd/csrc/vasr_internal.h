@@ -6,9 +6,9 @@
 namespace vasr {
 
 // Activations live in HBM as [B][C][ld] fp32 with the time axis contiguous and
-// ld = pad_frames(T): every row starts 512-B aligned and every 128-frame GEMM tile stays
+// ld = pad_frames(T): every row starts 1-KB aligned and every (64..256)-frame GEMM tile stays
 // inside one utterance.  Columns t >= T are padding (never consumed unmasked).
-constexpr int kTimeTile = 128;
+constexpr int kTimeTile = 256;
 static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
 
 // ---- front end (frontend.hip) ----
@@ -45,7 +45,7 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
                       int pad, float* y, int64_t ldy, hipStream_t st);
 
 struct PwArgs {
-  const float* wt;        // [K][M] K-major packed weights, M % 128 == 0, K % 32 == 0
+  const float* wt;        // weights in MFMA fragment order (pack_pointwise_weights), M % 128 == 0, K % 32 == 0
   const float* x;         // [B][K][ldx]
   const int32_t* lens;    // [B] input mask (nullptr = unmasked)
   const float* scale;     // [M]
@@ -54,11 +54,14 @@ struct PwArgs {
   float* y;               // [B][M][ldy]
   int32_t M, K, batch;
   int64_t ldx, ldy, ldr;
-  int32_t frames;         // columns < frames are stored
+  int32_t frames;         // valid columns
+  int32_t store_cols;     // columns < store_cols are stored: ldy for padded internal buffers, frames for ports
   int32_t m_store;        // rows < m_store are stored (decoder: V+1 of 128)
   int32_t relu;
 };
 void launch_pointwise(const PwArgs& a, hipStream_t st);
+// host: [cout][cin] row-major -> fragment order [m_pad/32][cin/8][64][4] (zero rows past cout)
+void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float* out);
 
 // ---- CTC head / decode (decode.hip) ----
 // logits [B][ldm rows][ld] (row v, column t) -> logp [B][T][V] (optional), pred [B][T] (optional)
