@@ -44,7 +44,7 @@ for C, K in ((256, 33), (256, 39), (512, 51), (512, 63), (512, 75)):
     ref = torch.nn.functional.conv1d(x[:2, :, :T], w[:, None, :], padding=K // 2, groups=C)
     print(f"      max err vs torch {float((y[:2, :, :T] - ref).abs().max()):.2e}")
 print("pointwise (B=64, T=501):")
-for cin, cout in ((64, 256), (256, 256), (256, 512), (512, 512), (512, 1024)):
+for cin, cout in ((64, 256), (256, 256), (256, 512), (512, 512), (512, 1024), (2048, 512), (8192, 512), (2048, 256)):
     x = torch.randn(B, cin, ld, device=dev)
     y = torch.empty(B, cout, ld, device=dev)
     w = (torch.randn(cout, cin) / cin ** 0.5).contiguous()

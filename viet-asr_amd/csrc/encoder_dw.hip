@@ -3,12 +3,15 @@
 // Replaces the groups == channels MaskedConv1d of every separable JasperBlock
 // (reference nemo/collections/asr/parts/jasper.py:113-132 mask + conv, :360-373 layer order).
 //
-// HBM-bound by design (2*K flops per 8 bytes): one wavefront owns one (utterance, channel) row
-// segment of 512 outputs.  The masked input window is staged once into LDS with 16-byte
-// coalesced loads; every lane then pulls a register window of K+3 samples with ds_read_b128 and
-// produces two groups of 4 consecutive outputs, so that each input sample is read from HBM
-// exactly once and both the LDS reads and the 16-byte output stores are conflict free / fully
-// coalesced.  The K taps of the row's channel are wave-uniform and travel through SGPRs.
+// HBM-bound by design (2*K flops per 8 bytes): one wavefront owns (utterance, channel) row
+// segments of 512 outputs and walks 4 channels, prefetching the next row from HBM while it
+// computes the current one.  The masked input window is staged once into LDS with 16-byte
+// coalesced loads; every lane then pulls a register window of K+4 samples with ds_read_b128 and
+// produces two groups of 4 consecutive outputs on packed-fp32 FMAs, so that each input sample is
+// read from HBM exactly once and both the LDS reads and the 16-byte output stores are conflict
+// free / fully coalesced.  The K taps of the row's channel are wave-uniform and travel through SGPRs.
+#include <cstdlib>
+
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -18,78 +21,147 @@ namespace {
 constexpr int kTile = 512;  // outputs per wavefront (2 groups x 64 lanes x 4)
 using v4f = __attribute__((ext_vector_type(4))) float;  // native vector: one ds_read_b128 / global dwordx4
 
-template <int K>
+template <int K, int DIL = 1>
 struct DwGeom {
-  static constexpr int PAD = K / 2;
+  static constexpr int PAD = DIL > 1 ? (DIL * K) / 2 - 1 : K / 2;  // get_same_padding (jasper.py:60-65)
   static constexpr int PADL = (PAD + 3) & ~3;
   static constexpr int OFF = PADL - PAD;
   static constexpr int NQ = (OFF + K + 3 + 3) / 4;       // float4 reads per lane per group
   static constexpr int WIN = 256 + 252 + 4 * NQ;         // floats of LDS per wavefront
 };
 
-// grid (C/4, B, ceil(ldy/512)), block 256 = 4 wavefronts = 4 channels
-template <int K>
+using v2f = __attribute__((ext_vector_type(2))) float;
+
+// Each wavefront owns a private LDS window, so no workgroup barrier is needed: the LDS pipeline
+// executes one wavefront's ds_write / ds_read in issue order; this only pins the compiler.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One sub-group of 4 consecutive outputs, taps [K0, K1), on packed-fp32 FMAs.
+// v_pk_fma_f32 wants its two lanes in one even-aligned register pair, but output pair (r, r+1) at
+// tap k needs x[r+k], x[r+k+1], which is an aligned pair only when r+k is even.  So taps whose
+// window offset e = OFF+k is even accumulate output pairs (0,1),(2,3); odd-e taps accumulate the
+// shifted pairs (-1,0),(1,2),(3,4) (the two outer halves are discarded): 2.5 packed FMAs per tap
+// per 4 outputs instead of 4 scalar ones, with no register shuffles.
+struct DwAcc { v2f e01, e23, om0, o12, o34; };
+
+template <int K0, int K1, int OFF, int DIL, class W>
+__device__ __forceinline__ void dw_taps(const v4f* __restrict__ win, const W& wc, DwAcc& a) {
+  constexpr int Q0 = (OFF + DIL * K0 - 1 < 0 ? 0 : OFF + DIL * K0 - 1) / 4;   // first / last float4 of the window
+  constexpr int Q1 = (OFF + DIL * (K1 - 1) + 4) / 4;
+  v2f xw[2 * (Q1 - Q0 + 1)];
+#pragma unroll
+  for (int q = Q0; q <= Q1; ++q) {
+    const v4f v = win[q];
+    xw[2 * (q - Q0)] = v.xy;
+    xw[2 * (q - Q0) + 1] = v.zw;
+  }
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const float wk = wc[k - K0];
+    const v2f w2 = {wk, wk};
+    const int e = OFF + DIL * k - 4 * Q0;
+    if ((OFF + DIL * k) % 2 == 0) {
+      a.e01 = __builtin_elementwise_fma(w2, xw[e / 2], a.e01);
+      a.e23 = __builtin_elementwise_fma(w2, xw[e / 2 + 1], a.e23);
+    } else {
+      a.om0 = __builtin_elementwise_fma(w2, xw[(e - 1) / 2], a.om0);
+      a.o12 = __builtin_elementwise_fma(w2, xw[(e + 1) / 2], a.o12);
+      a.o34 = __builtin_elementwise_fma(w2, xw[(e + 3) / 2], a.o34);
+    }
+  }
+}
+
+// grid (C/(4*ROWS), B, ceil(ldy/512)), block 256 = 4 wavefronts; each wavefront walks ROWS channels
+// of one utterance, prefetching the next row's window into registers while it computes the current.
+template <int K, int ROWS, int DIL = 1>
 __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels,
                                                       float* __restrict__ y, int64_t ldy) {
-  using G = DwGeom<K>;
-  __shared__ v4f lds4[4 * G::WIN / 4];  // vector-typed so every window access is a provable ds_*_b128
+  using G = DwGeom<K, DIL>;
+  constexpr int NQE = (G::OFF + DIL * (K - 1) + 4 + 1 + 3) / 4;  // +1: the odd-tap pairing reads one sample further
+  constexpr int NLD = ((256 + 252 + 4 * NQE) / 4 + 63) / 64;  // staging float4s per lane (3)
+  constexpr int WIN4 = NLD * 64;  // float4s of LDS per wavefront, rounded up so staging needs no predicate
+  __shared__ v4f lds4[4 * WIN4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = blockIdx.x * 4 + wave;
+  const int c0 = (blockIdx.x * 4 + wave) * ROWS;
   const int b = blockIdx.y;
   const int t_start = blockIdx.z * kTile;
   const int len_in = lens_in[b];
   const int len_out = lens_out[b];
-  const int64_t row = (int64_t)b * channels + c;
-  const float* xr = x + row * ldx;
-  v4f* win4 = lds4 + wave * (G::WIN / 4);
+  v4f* win4 = lds4 + wave * WIN4;
 
-  // ---- stage masked window: LDS index i <-> frame t_start - PADL + i ----
-  for (int i4 = lane; i4 < G::WIN / 4; i4 += 64) {
-    const int t = t_start - G::PADL + 4 * i4;
-    v4f v = {0.f, 0.f, 0.f, 0.f};
-    if (t >= 0 && t < len_in && t + 3 < ldx) {
-      v = *reinterpret_cast<const v4f*>(xr + t);
-      if (t + 1 >= len_in) v.y = 0.f;     // MaskedConv1d: x.masked_fill(t >= lens, 0)  (jasper.py:113-118)
-      if (t + 2 >= len_in) v.z = 0.f;
-      if (t + 3 >= len_in) v.w = 0.f;
+  // masked window of one row: LDS float4 index i4 <-> frames t_start - PADL + 4*i4 .. +3.
+  // Branch-free (clamped address + selects) so that all staging loads are in flight together.
+  v4f stage[NLD];
+  auto gload = [&](int c) {
+    const float* xr = x + ((int64_t)b * channels + c) * ldx;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+      int tc = t < 0 ? 0 : t;
+      tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
+      stage[j] = *reinterpret_cast<const v4f*>(xr + tc);
     }
-    win4[i4] = v;
-  }
-  __syncthreads();
+  };
+  // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding
+  auto masked = [&](int j) {
+    const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+    v4f v = stage[j];
+    v.x = (t >= 0 && t + 0 < len_in) ? v.x : 0.f;
+    v.y = (t >= 0 && t + 1 < len_in) ? v.y : 0.f;
+    v.z = (t >= 0 && t + 2 < len_in) ? v.z : 0.f;
+    v.w = (t >= 0 && t + 3 < len_in) ? v.w : 0.f;
+    return v;
+  };
 
-  const float* wc = w + (int64_t)c * K;  // wave-uniform -> scalar loads
+  gload(c0);
+#pragma unroll 1
+  for (int r = 0; r < ROWS; ++r) {
+    const int c = c0 + r;
+    // taps of this row's channel: wave-uniform -> scalar loads.  For the short kernels they are pinned
+    // here so that their latency overlaps the staging loads already in flight instead of following
+    // the LDS round trip (for K > 44 pinning all taps at once would spill SGPRs).
+    const float* wg = w + (int64_t)c * K;
+    float wc[K <= 44 ? K : 1];
+    if constexpr (K <= 44) {
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int base = g * 256 + lane * 4;
-    float xw[4 * G::NQ];
+      for (int k = 0; k < K; ++k) wc[k] = wg[k];
 #pragma unroll
-    for (int q = 0; q < G::NQ; ++q) {
-      const v4f v = win4[g * 64 + lane + q];
-      xw[4 * q + 0] = v.x; xw[4 * q + 1] = v.y; xw[4 * q + 2] = v.z; xw[4 * q + 3] = v.w;
+      for (int k = 0; k < K; ++k) asm volatile("" : "+s"(wc[k]));
     }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float wk = wc[k];
-      a0 = fmaf(wk, xw[G::OFF + k + 0], a0);
-      a1 = fmaf(wk, xw[G::OFF + k + 1], a1);
-      a2 = fmaf(wk, xw[G::OFF + k + 2], a2);
-      a3 = fmaf(wk, xw[G::OFF + k + 3], a3);
-    }
-    const int t = t_start + base;
-    if (t < ldy) {
-      // the following 1x1 MaskedConv1d masks with lens_out: zero here so the GEMM needs no predicate
+    for (int j = 0; j < NLD; ++j) win4[lane + 64 * j] = masked(j);
+    if (r + 1 < ROWS) gload(c + 1);   // in flight while this row is computed
+    wave_sync();
+    float* yr = y + ((int64_t)b * channels + c) * ldy;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      DwAcc acc{{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      if constexpr (K <= 44) dw_taps<0, K, G::OFF, DIL>(win4 + g * 64 + lane, wc, acc);
+      else dw_taps<0, K, G::OFF, DIL>(win4 + g * 64 + lane, wg, acc);
       v4f o;
-      o.x = (t + 0 < len_out) ? a0 : 0.f;
-      o.y = (t + 1 < len_out) ? a1 : 0.f;
-      o.z = (t + 2 < len_out) ? a2 : 0.f;
-      o.w = (t + 3 < len_out) ? a3 : 0.f;
-      *reinterpret_cast<v4f*>(y + row * ldy + t) = o;
+      o.x = acc.e01.x + acc.om0.y;
+      o.y = acc.e01.y + acc.o12.x;
+      o.z = acc.e23.x + acc.o12.y;
+      o.w = acc.e23.y + acc.o34.x;
+      const int t = t_start + g * 256 + lane * 4;
+      if (t < ldy) {
+        // the following 1x1 MaskedConv1d masks with lens_out: zero here so the GEMM needs no predicate
+        if (t + 0 >= len_out) o.x = 0.f;
+        if (t + 1 >= len_out) o.y = 0.f;
+        if (t + 2 >= len_out) o.z = 0.f;
+        if (t + 3 >= len_out) o.w = 0.f;
+        *reinterpret_cast<v4f*>(yr + t) = o;
+      }
     }
+    wave_sync();
   }
 }
 
@@ -149,8 +221,21 @@ __global__ __launch_bounds__(256) void repad_kernel(const float* __restrict__ sr
 template <int K>
 void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
                  int channels, float* y, int64_t ldy, hipStream_t st) {
-  dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
-  hipLaunchKernelGGL(dw_conv_kernel<K>, grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+  const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
+  static const int rows_env = getenv("VASR_DW_ROWS") ? atoi(getenv("VASR_DW_ROWS")) : 1;
+  if (channels % 32 == 0 && rows_env == 8) {
+    dim3 grid(channels / 32, batch, tiles);
+    hipLaunchKernelGGL((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+  } else if (channels % 8 == 0 && rows_env == 2) {
+    dim3 grid(channels / 8, batch, tiles);
+    hipLaunchKernelGGL((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+  } else if (channels % 16 == 0 && rows_env != 1) {
+    dim3 grid(channels / 16, batch, tiles);
+    hipLaunchKernelGGL((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+  } else {
+    dim3 grid(channels / 4, batch, tiles);
+    hipLaunchKernelGGL((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+  }
 }
 
 }  // namespace
@@ -158,9 +243,15 @@ void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li,
 void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
                       const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
                       int pad, float* y, int64_t ldy, hipStream_t st) {
-  const bool fast = stride == 1 && dilation == 1 && pad == kernel / 2 && channels % 4 == 0 && ldx % 4 == 0 &&
-                    ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  if (aligned && stride == 1 && dilation == 2 && kernel == 87 && pad == 86) {
+    dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
+    hipLaunchKernelGGL((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
+                       y, ldy);
+    return;
+  }
+  const bool fast = aligned && stride == 1 && dilation == 1 && pad == kernel / 2;
   if (fast) {
     switch (kernel) {
       case 33: return launch_dw_t<33>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
 
   // ---- epilogue: BN affine (+ residual) + ReLU; each half-wave writes 128-byte row segments ----
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (a.relu & 2) return;  // debug: skip the epilogue (tools/bench_layers.py ablation)
   const bool full = (t0 + G::BN <= a.store_cols) && (m0 + G::BM <= a.m_store);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
           const int t = t0 + wn + j * 32 + l31;
           float v = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
           if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
-          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.relu & 1) v = fmaxf(v, 0.f);
           if (full || (t < a.store_cols && m < a.m_store)) a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
         }
       }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -704,7 +705,7 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   PwArgs a{};
   a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
   launch_pointwise(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise");
 }
