@@ -36,6 +36,23 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E spec peak
 
 
+def pmc_traffic(prefix):
+    """Launch-weighted mean HBM bytes per launch of the kernels whose name starts with ``prefix``, from the newest
+    committed PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+    tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    n = b = 0
+    for k, v in d.items():
+        if k.startswith(prefix) and "fetch_bytes_corrected_per_launch" in v and "write_bytes_per_launch" in v:
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_corrected_per_launch"] + v["write_bytes_per_launch"])
+    return (round(b / n) if n else None), os.path.basename(files[-1])
+
+
 def cpu_baseline(model, seed, seconds, budget_s=20.0):
     """Time the CPU oracle (port of the reference path on the same ATen CPU ops) on a bounded sample."""
     from oracle import quartznet_oracle as O   # checker / baseline only -- never on the product path
@@ -153,6 +170,9 @@ def main():
         dw_ms = prof["depthwise"]["ms"] / a.steps
         pw_tflops = work["pointwise_flops"] / (pw_ms * 1e-3) / 1e12
         dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
+        default_workload = a.model == "quartznet15x5" and a.batch == 64 and a.seconds == 10.0 and not a.ragged
+        pw_traffic, traffic_src = pmc_traffic("pw_gemm_kernel") if default_workload else (None, None)
+        dw_traffic, _ = pmc_traffic("dw_conv_kernel") if default_workload else (None, None)
         out = {
             "metric": "real_time_factor", "value": round(audio_all * a.steps / elapsed, 1),
             "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -164,11 +184,12 @@ def main():
             "utts_per_sec": round(a.batch * world * a.steps / elapsed, 1),
             "roofline": {"kernel": "pw_gemm_kernel (1x1 conv fp32 MFMA GEMM + BN/residual/ReLU epilogue)",
                          "bound": "mfma", "achieved": round(pw_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(pw_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(pw_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pw_traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps},
             "depthwise": {"kernel": "dw_conv_kernel<K>", "bound": "hbm", "achieved": round(dw_gbs, 1),
-                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": dw_traffic,
                           "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
                           "launches_per_step": prof["depthwise"]["launches"] // a.steps},
             "other_ms_per_step": {"frontend": round(prof["frontend"]["ms"] / a.steps, 3),

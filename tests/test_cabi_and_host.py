@@ -1,0 +1,159 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/vasr.h declares, argument
+validation works without a GPU, and the host-side NeuralModule mirror behaves like the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from viet_asr_amd import _lib, configs, synth
+from viet_asr_amd import asr as nemo_asr
+from viet_asr_amd.core import (DeviceType, NeuralModuleFactory, NeuralPortNameMismatchError,
+                               NeuralPortNmTensorMismatchError, NmTensor)
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "vasr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vasr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 20 and "vasr_transcribe_greedy_f32" in names
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vasr.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.lib().vasr_version()
+
+
+def test_create_validates_arguments_without_a_gpu():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.vasr_create(None, C.byref(h)) == -1 and b"null" in L.vasr_last_error()
+    with pytest.raises(NotImplementedError):          # n_fft other than 512 -> VASR_ERR_UNSUPPORTED
+        _lib.Handle(frontend=dict(sample_rate=16000, n_fft=1024, win_length=320, hop_length=160, n_mels=64,
+                                  window=np.ones(320, np.float32), filterbank=np.zeros((64, 513), np.float32)))
+    with pytest.raises(ValueError):                   # non-positive block field -> VASR_ERR_INVALID
+        _lib.Handle(feat_in=64, blocks=[dict(filters=256, repeat=0, kernel=33, stride=1, dilation=1, residual=0,
+                                             separable=1)])
+    hd = _lib.Handle(dec_feat_in=1024, num_classes=29)
+    assert hd.workspace_bytes(4, mel_frames=100) == 0          # not finalized yet
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.VasrError):                     # missing weights / no device: loud failure
+            hd.finalize()
+
+
+def test_pointwise_weight_packing_layout():
+    L = _lib.lib()
+    cout, cin, m_pad = 29, 64, 128
+    w = np.arange(cout * cin, dtype=np.float32).reshape(cout, cin)
+    out = np.empty(m_pad * cin, dtype=np.float32)
+    _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, cin, m_pad, out.ctypes.data))
+    p = out.reshape(m_pad // 32, cin // 8, 64, 4)
+    for mt, g, lane, s in [(0, 0, 0, 0), (0, 3, 37, 2), (0, 7, 63, 3), (3, 1, 5, 1)]:
+        m, k = mt * 32 + (lane & 31), g * 8 + 2 * s + (lane >> 5)
+        assert p[mt, g, lane, s] == (w[m, k] if m < cout else 0.0)
+    with pytest.raises(ValueError):
+        _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, 63, m_pad, out.ctypes.data))
+
+
+def test_builtin_configs_and_state_dict_layout():
+    for name, n_blocks, n_labels, n_keys in (("quartznet12x1_vi", 15, 90, 182), ("quartznet15x5", 18, 28, 635)):
+        cfg = configs.builtin(name)
+        jas = cfg["JasperEncoder"]["jasper"]
+        assert len(jas) == n_blocks and len(cfg["labels"]) == n_labels
+        NeuralModuleFactory(placement=DeviceType.CPU)
+        enc = nemo_asr.JasperEncoder(feat_in=64, **cfg["JasperEncoder"])
+        sd = synth.encoder_state_dict(jas, 64, 0)
+        assert len(enc.state_dict()) == n_keys                      # 182 / 635 keys
+        assert set(enc.state_dict()) == set(sd)
+        for k, v in enc.state_dict().items():
+            assert tuple(v.shape) == tuple(np.shape(sd[k])), k
+        enc.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})      # strict, like restore_from
+    with pytest.raises(ValueError):
+        configs.builtin("quartznet99")
+    legacy = configs.normalize_definition({"sample_rate": 16000, "AudioPreprocessing": {"feat_type": "logfbank", "n_fft": 512}})
+    assert "feat_type" not in legacy["AudioToMelSpectrogramPreprocessor"]
+
+
+def _wire(placement=DeviceType.CPU):
+    cfg = configs.builtin("quartznet12x1_vi")
+    nf = NeuralModuleFactory(placement=placement)
+    dl = nemo_asr.AudioDataLayer(sample_rate=16000)
+    pre = nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(cfg["AudioToMelSpectrogramPreprocessor"], dither=0, pad_to=0))
+    enc = nemo_asr.JasperEncoder(feat_in=64, **cfg["JasperEncoder"])
+    dec = nemo_asr.JasperDecoderForCTC(feat_in=1024, num_classes=len(cfg["labels"]))
+    greedy = nemo_asr.GreedyCTCDecoder()
+    return cfg, nf, dl, pre, enc, dec, greedy
+
+
+def test_dag_wiring_ports_and_type_checks():
+    cfg, nf, dl, pre, enc, dec, greedy = _wire()
+    sig, sig_len = dl()
+    assert isinstance(sig, NmTensor) and sig.name == "audio_signal"
+    mel, mel_len = pre(input_signal=sig, length=sig_len)
+    encoded, enc_len = enc(audio_signal=mel, length=mel_len)        # MelSpectrogramType is-a SpectrogramType
+    logp = dec(encoder_output=encoded)
+    pred = greedy(log_probs=logp)
+    assert list(pre.output_ports) == ["processed_signal", "processed_length"]
+    assert list(enc.output_ports) == ["outputs", "encoded_lengths"]
+    assert str(enc) == "JasperEncoder" and str(dec) == "JasperDecoderForCTC"       # checkpoint file stems
+    with pytest.raises(NeuralPortNameMismatchError):
+        enc(audio=mel, length=mel_len)
+    with pytest.raises(NeuralPortNmTensorMismatchError):
+        dec(encoder_output=mel_len)                                  # lengths into an acoustic port
+    with pytest.raises(NeuralPortNmTensorMismatchError):
+        greedy(log_probs=encoded)                                    # ('B','D','T') into ('B','T','D')
+    chain = nf._trainer.topo_sort([pred])
+    assert [type(e[0]).__name__ for e in chain] == ["AudioDataLayer", "AudioToMelSpectrogramPreprocessor",
+                                                    "JasperEncoder", "JasperDecoderForCTC", "GreedyCTCDecoder"]
+
+
+def test_constructor_errors_mirror_the_reference():
+    NeuralModuleFactory(placement=DeviceType.CPU)
+    with pytest.raises(ValueError):     # audio_preprocessing.py:339-344
+        nemo_asr.AudioToMelSpectrogramPreprocessor(window_size=0.02, n_window_size=320)
+    with pytest.raises(ValueError):     # parts/features.py:222-227
+        nemo_asr.AudioToMelSpectrogramPreprocessor(log_zero_guard_type="bogus")
+    with pytest.raises(ValueError):     # parts/jasper.py:61-62
+        nemo_asr.JasperEncoder(jasper=[dict(filters=256, repeat=1, kernel=[33], stride=[2], dilation=[2], dropout=0.0,
+                                            residual=False, separable=True)], activation="relu", feat_in=64)
+    with pytest.raises(NotImplementedError):
+        nemo_asr.AudioToMelSpectrogramPreprocessor(stft_conv=True)
+    if not torch.cuda.is_available():
+        with pytest.raises(ValueError):     # neural_factory.py:320-330
+            NeuralModuleFactory(placement=DeviceType.GPU)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the loud failure on a box without a HIP device")
+def test_no_silent_cpu_fallback():
+    cfg, nf, dl, pre, enc, dec, greedy = _wire()
+    x = torch.zeros(1, 4000)
+    n = torch.tensor([4000])
+    for call in (lambda: pre(force_pt=True, input_signal=x, length=n),
+                 lambda: enc(force_pt=True, audio_signal=torch.zeros(1, 64, 26), length=torch.tensor([25])),
+                 lambda: dec(force_pt=True, encoder_output=torch.zeros(1, 1024, 13)),
+                 lambda: greedy(force_pt=True, log_probs=torch.zeros(1, 13, 91))):
+        with pytest.raises(_lib.VasrError):
+            call()
+    from viet_asr_amd.engine import QuartzNetCTC
+    with pytest.raises(_lib.VasrError):
+        QuartzNetCTC(cfg, {}, {})
+
+
+def test_synthetic_audio_is_padded_like_the_collate():
+    sig, lens = synth.audio_batch(5, 16000, seed=9, ragged=True)
+    assert sig.shape == (5, 16000) and lens.max() == 16000 and lens.min() >= 8000
+    for b in range(5):
+        assert not sig[b, lens[b]:].any()
+    dl = nemo_asr.AudioDataLayer(16000) if NeuralModuleFactory(placement=DeviceType.CPU) else None
+    dl.set_batch([sig[b, :lens[b]] for b in range(5)])
+    a, l = next(iter(dl))
+    assert torch.equal(a, torch.from_numpy(sig)) and l.tolist() == lens.tolist()
+    with pytest.raises(StopIteration):
+        next(dl)

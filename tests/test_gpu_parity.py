@@ -33,3 +33,130 @@ def test_fused_path_matches_reference_goldens(gpu, name):
     assert (r["enc_len"].cpu().numpy() == g["enc_len"]).all()
     assert (r["pred"].cpu().numpy() == g["pred"]).all()
     assert eng.texts(r["ids"], r["id_len"]) == [str(s) for s in g["hyp"]]
+
+
+def _oracle(cfg, sig, lens, enc_sd, dec_sd):
+    from oracle import quartznet_oracle as O
+    return O.forward_all(sig, lens, enc_sd, dec_sd, cfg["JasperEncoder"]["jasper"])
+
+
+@pytest.mark.parametrize("name", ["vi12x1_b3_ragged", "en15x5_b2_ragged"])
+def test_neural_module_dag_matches_goldens(gpu, name):
+    """The reference's own wiring (infer.py:146-160 with the greedy decoder) through our factory."""
+    from viet_asr_amd import asr as nemo_asr
+    from viet_asr_amd.core import DeviceType, NeuralModuleFactory
+    from viet_asr_amd.helpers import post_process_predictions
+    g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
+    nf = NeuralModuleFactory(placement=DeviceType.GPU)
+    dl = nemo_asr.AudioDataLayer(sample_rate=16000)
+    pre = nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(cfg["AudioToMelSpectrogramPreprocessor"], dither=0, pad_to=0))
+    enc = nemo_asr.JasperEncoder(feat_in=64, **cfg["JasperEncoder"])
+    dec = nemo_asr.JasperDecoderForCTC(feat_in=1024, num_classes=len(cfg["labels"]))
+    greedy = nemo_asr.GreedyCTCDecoder()
+    enc.load_state_dict({k: torch.as_tensor(v) for k, v in enc_sd.items()})
+    dec.load_state_dict({k: torch.as_tensor(v) for k, v in dec_sd.items()})
+    a, al = dl()
+    mel, ml = pre(input_signal=a, length=al)
+    e, el = enc(audio_signal=mel, length=ml)
+    lp = dec(encoder_output=e)
+    pred = greedy(log_probs=lp)
+    dl.set_batch([sig[b, : lens[b]] for b in range(len(lens))])
+    out = nf.infer(tensors=[mel, ml, el, lp, pred], verbose=False)
+    mel_v, ml_v, el_v, lp_v, pred_v = [o[0] for o in out]
+    assert np.abs(mel_v.numpy() - g["mel"]).max() <= MEL_TOL
+    assert ml_v.dtype == torch.int64 and (ml_v.numpy() == g["seq"]).all()
+    assert el_v.dtype == torch.float32 and (el_v.numpy() == g["enc_len"]).all()          # quirk Q3
+    assert np.abs(lp_v.numpy() - g["logp"]).max() <= LOGP_TOL
+    assert pred_v.dtype == torch.int64 and (pred_v.numpy() == g["pred"]).all()
+    assert post_process_predictions([pred_v], cfg["labels"]) == [str(s) for s in g["hyp"]]
+
+
+def test_stage_entry_points_against_oracle(gpu):
+    """Each C-ABI stage fed with the ORACLE's input for that stage (errors do not compound)."""
+    from viet_asr_amd import _lib, configs, stages, synth
+    from viet_asr_amd.engine import blocks_from_config
+    from viet_asr_amd.frontend_tables import frontend_description
+    from oracle import quartznet_oracle as O
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 21), synth.decoder_state_dict(1024, 91, 21)
+    sig, lens = synth.audio_batch(5, 48000, 21, ragged=True)
+    lens[1] = 160 * 199              # Q2: exact multiple of the hop
+    sig[1, lens[1]:] = 0
+    ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
+    hp = _lib.Handle(frontend=frontend_description(cfg["AudioToMelSpectrogramPreprocessor"])); hp.finalize()
+    he = _lib.Handle(feat_in=64, blocks=blocks_from_config(jas)); he.load_state_dict(enc_sd); he.finalize()
+    hd = _lib.Handle(dec_feat_in=1024, num_classes=91); hd.load_state_dict(dec_sd); hd.finalize()
+    mel, seq = stages.melspec(hp, torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu))
+    assert (seq.cpu() == ref["seq"]).all()
+    assert (mel.cpu() - ref["mel"]).abs().max() <= MEL_TOL
+    assert (mel.cpu()[ref["mel"] == 0] == 0).all()                   # masked frames are exactly pad_value
+    enc, elen = stages.encoder(he, ref["mel"].to(gpu), ref["seq"].to(gpu), 1024)
+    assert (elen.cpu() == ref["enc_len"]).all()
+    scale = float(ref["enc"].abs().max())
+    assert (enc.cpu() - ref["enc"]).abs().max() <= 2e-5 * max(scale, 1.0)
+    logp = stages.decoder(hd, ref["enc"].to(gpu))
+    assert (logp.cpu() - ref["logp"]).abs().max() <= 2e-4
+    assert (stages.greedy_argmax(ref["logp"].to(gpu)).cpu() == ref["pred"]).all()
+    ids, n = stages.ctc_collapse(ref["pred"].to(gpu), 90)
+    for b in range(5):
+        assert ids[b, : n[b]].cpu().tolist() == O.ctc_collapse_ids(ref["pred"][b].numpy(), 90)
+
+
+def test_edge_cases(gpu):
+    from viet_asr_amd import configs, stages, synth
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, 91, 5)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    # shortest input torch.stft accepts (reflect pad needs > n_fft/2 samples), one very short row in a batch
+    sig, lens = synth.audio_batch(3, 2000, 5, ragged=False)
+    lens[:] = [2000, 257, 1]
+    for b in range(3):
+        sig[b, lens[b]:] = 0
+    ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
+    r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
+    lp = r["logp"].cpu()
+    # a row with seq_len == 1 has NaN statistics in the reference (unbiased std of one frame): same here
+    assert torch.isnan(ref["logp"][2]).all() == torch.isnan(lp[2]).all()
+    ok = ~torch.isnan(ref["logp"])
+    assert (lp[ok] - ref["logp"][ok]).abs().max() <= LOGP_TOL
+    assert (r["pred"].cpu()[:2] == ref["pred"][:2]).all()
+    with pytest.raises(ValueError):          # torch.stft refuses reflect padding of <= n_fft/2 samples
+        eng.forward(torch.zeros(1, 256, device=gpu), torch.tensor([256], device=gpu))
+    # all-blank and all-repeat rows through the collapse
+    pred = torch.tensor([[90] * 7, [3] * 7, [3, 90, 3, 3, 90, 90, 4]], device=gpu)
+    ids, n = stages.ctc_collapse(pred, 90)
+    assert n.tolist() == [0, 1, 3] and ids[2, :3].tolist() == [3, 3, 4]
+    # argmax ties: lowest index wins (quirk Q6)
+    lp0 = torch.zeros(1, 2, 29, device=gpu)
+    lp0[0, 1, 5] = lp0[0, 1, 9] = 1.0
+    assert stages.greedy_argmax(lp0).tolist() == [[0, 5]]
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json config 2 size (12x1_vi, B=32 x 10 s): properties that need no oracle run."""
+    from viet_asr_amd import configs, stages, synth
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 2), synth.decoder_state_dict(1024, 91, 2)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    sig, lens = synth.audio_batch(32, 160000, 2, ragged=True)
+    wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    r1 = eng.forward(wav, ln, want_logp=True)
+    r2 = eng.forward(wav, ln, want_logp=True)
+    assert torch.equal(r1["pred"], r2["pred"]) and torch.equal(r1["logp"], r2["logp"])     # deterministic
+    assert r1["logp"].shape == (32, 501, 91)
+    assert (torch.logsumexp(r1["logp"], -1).abs().max() < 1e-4)                            # rows are log-distributions
+    assert torch.equal(r1["logp"].argmax(-1), r1["pred"])
+    assert r1["enc_len"].tolist() == [float((int(np.ceil(l / 160)) - 1) // 2 + 1) for l in lens]
+    # batch independence up to the padded-row reflect quirk (Q5): full-length rows do not depend on the others
+    full = [b for b in range(32) if lens[b] == 160000][:1]
+    solo = eng.forward(wav[full], ln[full], want_logp=True)
+    assert (solo["logp"][0] - r1["logp"][full[0]]).abs().max() <= 1e-5
+    # collapse is idempotent on its own output re-expanded with blanks
+    ids, n = r1["ids"], r1["id_len"]
+    row = ids[0, : n[0]].long()
+    expanded = torch.stack([row, torch.full_like(row, 90)], 1).reshape(1, -1)
+    ids2, n2 = stages.ctc_collapse(expanded, 90)
+    assert ids2[0, : n2[0]].tolist() == row.tolist()

@@ -1,0 +1,78 @@
+"""VietASR: counterpart of the reference's infer.py:57-171 on the HIP modules.
+
+Same constructor and ``transcribe(audio_signal) -> str``.  Differences, all additive:
+  * ``decoder="greedy"`` (the variant infer.py:113 has commented out) next to the reference's
+    ``"beam"`` wiring (infer.py:132-139, 159-160);
+  * ``transcribe_batch(list_of_signals)`` runs the fused one-call path (engine.QuartzNetCTC);
+  * config files in either spelling (``AudioToMelSpectrogramPreprocessor`` / ``AudioPreprocessing``)
+    or a builtin model name are accepted.
+Audio decoding / resampling (librosa.load in the reference CLI, infer.py:200) stays with the caller.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import asr as nemo_asr
+from . import configs
+from .core import DeviceType, NeuralModuleFactory
+from .engine import QuartzNetCTC
+from .helpers import post_process_predictions
+
+
+class VietASR:
+    def __init__(self, config_file, encoder_checkpoint, decoder_checkpoint, device="gpu", lm_path=None,
+                 beam_width=20, lm_alpha=0.5, lm_beta=1.5, decoder="beam"):
+        if os.path.exists(str(config_file)):
+            model_definition = configs.load_model_definition(config_file)
+        else:
+            model_definition = configs.builtin(config_file)        # raises ValueError for unknown names
+        assert os.path.exists(encoder_checkpoint), f"encoder checkpoint not found: {encoder_checkpoint}"
+        assert os.path.exists(decoder_checkpoint), f"decoder checkpoint not found: {decoder_checkpoint}"
+        pre = model_definition["AudioToMelSpectrogramPreprocessor"]
+        pre["dither"] = 0          # infer.py:89
+        pre["pad_to"] = 0          # infer.py:90
+        if device != "gpu" or not torch.cuda.is_available():
+            raise RuntimeError("viet-asr_amd runs on a HIP device only (device='gpu'); there is no CPU path")
+        self.model_definition = model_definition
+        self.labels = labels = model_definition["labels"]
+        self.neural_factory = NeuralModuleFactory(placement=DeviceType.GPU)
+        self.data_layer = nemo_asr.AudioDataLayer(sample_rate=pre["sample_rate"])
+        self.preprocessor = nemo_asr.AudioToMelSpectrogramPreprocessor(**pre)
+        self.encoder = nemo_asr.JasperEncoder(feat_in=pre["features"], **model_definition["JasperEncoder"])
+        self.decoder = nemo_asr.JasperDecoderForCTC(
+            feat_in=model_definition["JasperEncoder"]["jasper"][-1]["filters"], num_classes=len(labels))
+        self.encoder.restore_from(encoder_checkpoint)
+        self.decoder.restore_from(decoder_checkpoint)
+
+        audio_signal, audio_signal_len = self.data_layer()
+        processed_signal, processed_signal_len = self.preprocessor(input_signal=audio_signal, length=audio_signal_len)
+        encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_len)
+        log_probs = self.decoder(encoder_output=encoded)
+        self.mode = decoder
+        if decoder == "greedy":
+            self.greedy = nemo_asr.GreedyCTCDecoder()
+            self.infer_tensors = [self.greedy(log_probs=log_probs)]
+        elif decoder == "beam":
+            if lm_path and not os.path.exists(lm_path):
+                lm_path = None
+            self.beam = nemo_asr.BeamSearchDecoderWithLM(vocab=labels, beam_width=beam_width, alpha=lm_alpha,
+                                                         beta=lm_beta, lm_path=lm_path,
+                                                         num_cpus=max(1, os.cpu_count()))
+            self.infer_tensors = [self.beam(log_probs=log_probs, log_probs_length=encoded_len)]
+        else:
+            raise ValueError(f"decoder must be 'greedy' or 'beam', got {decoder!r}")
+        self._fused = None
+
+    def transcribe(self, audio_signal):
+        self.data_layer.set_signal(audio_signal)
+        evaluated = self.neural_factory.infer(tensors=self.infer_tensors, verbose=False)
+        if self.mode == "greedy":
+            return post_process_predictions(evaluated[0], self.labels)[0]
+        return evaluated[0][0]
+
+    def transcribe_batch(self, signals):
+        """Greedy transcripts of a list of 1-D signals through the fused one-call path."""
+        if self._fused is None:
+            self._fused = QuartzNetCTC(self.model_definition, self.encoder.state_dict(), self.decoder.state_dict())
+        return self._fused.transcribe([np.asarray(s, dtype=np.float32) for s in signals])
