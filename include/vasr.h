@@ -141,6 +141,29 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
 
+/* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */
+/* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,
+ * algorithm restated in oracle/beam_oracle.py).  Unlike the reference any batch size is accepted.
+ *   d_logp [B][T'][V+1] f32 log-probabilities, blank = V (last class); space_id = index of ' ' in the labels
+ *   -> d_ids [B][T'] i32 label ids of the best hypothesis (words separated by space_id), d_id_len [B] i32,
+ *      d_score [B] f32 combined (acoustic + LM) natural-log score of that hypothesis.
+ * beam_width <= 128, V+1 <= 128.  token_min_logp / beam_prune_logp: pyctcdecode defaults are -5 / -10. */
+typedef struct vasr_lm vasr_lm;
+size_t vasr_beam_workspace_bytes(int batch, int64_t frames);
+int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
+                         int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
+                         int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_workspace,
+                         size_t workspace_bytes, vasr_stream stream);
+/* Back-off n-gram model as two open-addressing hash tables (keys built with vasr_beam_hash_*; 0 = empty slot,
+ * stored keys have bit 0 set): word-hash -> word id, and hash(n, id_1..id_n) -> (log10 p, log10 back-off).
+ * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel. */
+int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
+                   const float* h_nval, int ncap, int order, int bos_id, int eos_id, int unk_id, float alpha,
+                   float beta, float unk_offset, vasr_lm** out);
+void vasr_lm_destroy(vasr_lm* lm);
+uint64_t vasr_beam_hash_init(void);
+uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v);
+
 /* ---- introspection -------------------------------------------------------------------- */
 const char* vasr_last_error(void);
 const char* vasr_version(void);

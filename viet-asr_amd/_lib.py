@@ -54,6 +54,14 @@ SIGNATURES = {
     "vasr_ctc_collapse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "vasr_transcribe_greedy_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
                                              C.c_size_t, _P]),
+    "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
+                                       _P, _P, _P, _P, C.c_size_t, _P]),
+    "vasr_lm_create": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.c_float, C.c_float, C.POINTER(_P)]),
+    "vasr_lm_destroy": (None, [_P]),
+    "vasr_beam_hash_init": (C.c_uint64, []),
+    "vasr_beam_hash_step": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "vasr_last_error": (C.c_char_p, []),
     "vasr_version": (C.c_char_p, []),
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),

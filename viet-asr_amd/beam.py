@@ -1,0 +1,172 @@
+"""Host side of the device prefix beam search (csrc/beam.hip): n-gram tables, launch, id -> text.
+
+Counterpart of what ``BeamSearchDecoderWithLM.__init__`` builds with ``pyctcdecode.build_ctcdecoder(vocab,
+kenlm_model_path, alpha, beta)`` (nemo/collections/asr/beam_search_decoder.py:82-87).  The language model is
+read from ARPA text; KenLM's binary formats (``*.binary``; the reference's own files are missing anyway,
+.MISSING_LARGE_BLOBS:4-7) are a third-party on-disk layout and are refused with a clear error.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_MASK = (1 << 64) - 1
+_FNV_PRIME = 1099511628211
+
+
+def _hstep(h, v):
+    return ((h ^ ((v + 1) & _MASK)) * _FNV_PRIME) & _MASK
+
+
+def read_arpa(path):
+    """-> (order, {tuple(words): (log10 p, log10 backoff)})"""
+    with open(path, "rb") as f:
+        head = f.read(64)
+    if not head.lstrip().startswith(b"\\data\\"):
+        raise NotImplementedError(f"{path}: only ARPA text n-gram models are supported (KenLM binary formats are not)")
+    ngrams, order, cur = {}, 0, 0
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if not line or line == "\\data\\" or line.startswith("ngram "):
+                continue
+            if line == "\\end\\":
+                break
+            if line.startswith("\\") and line.endswith("-grams:"):
+                cur = int(line[1:line.index("-")])
+                order = max(order, cur)
+                continue
+            parts = line.split()
+            words = tuple(parts[1:1 + cur])
+            ngrams[words] = (float(parts[0]), float(parts[1 + cur]) if len(parts) > 1 + cur else 0.0)
+    return order, ngrams
+
+
+def _table(keys, cap):
+    slots = np.zeros(cap, dtype=np.uint64)
+    where = {}
+    for k in keys:
+        k |= 1
+        i = k % cap
+        while slots[i] != 0:
+            if int(slots[i]) == k:
+                raise ValueError("64-bit hash collision while building the n-gram tables")
+            i = (i + 1) % cap
+        slots[i] = k
+        where[k] = i
+    return slots, where
+
+
+def _cap(n):
+    c = 16
+    while c < 2 * n + 1:
+        c *= 2
+    return c + 1  # odd capacity: the kernel probes with `hash % cap`
+
+
+class DeviceLM:
+    """Uploads an ARPA model as the two hash tables vasr_lm_create() expects."""
+
+    def __init__(self, path, labels, alpha, beta, unk_offset=-10.0):
+        order, ngrams = read_arpa(path)
+        if order > 5:
+            raise NotImplementedError("n-gram order > 5")
+        L = _lib.lib()
+        h0 = int(L.vasr_beam_hash_init())
+        assert _hstep(h0, 3) == int(L.vasr_beam_hash_step(h0, 3)), "host/device hash mismatch"
+        lab = {c: i for i, c in enumerate(labels)}
+        words = sorted({w for ng in ngrams for w in ng})
+        for special in ("<s>", "</s>", "<unk>"):
+            if special not in words:
+                words.append(special)
+        wid = {w: i for i, w in enumerate(words)}
+        # word string -> hash over its label ids; words with characters outside the labels can never be emitted
+        vkeys, vvals = [], []
+        for w in words:
+            if w in ("<s>", "</s>", "<unk>") or any(ch not in lab for ch in w):
+                continue
+            h = h0
+            for ch in w:
+                h = _hstep(h, lab[ch])
+            vkeys.append(h)
+            vvals.append(wid[w])
+        vcap = _cap(len(vkeys))
+        vslots, vwhere = _table(vkeys, vcap)
+        vid = np.full(vcap, -1, dtype=np.int32)
+        for k, v in zip(vkeys, vvals):
+            vid[vwhere[k | 1]] = v
+        nkeys, nvals = [], []
+        for ng, (p, bo) in ngrams.items():
+            h = _hstep(h0, len(ng))
+            for w in ng:
+                h = _hstep(h, wid[w])
+            nkeys.append(h)
+            nvals.append((p, bo))
+        ncap = _cap(len(nkeys))
+        nslots, nwhere = _table(nkeys, ncap)
+        nval = np.zeros((ncap, 2), dtype=np.float32)
+        for k, v in zip(nkeys, nvals):
+            nval[nwhere[k | 1]] = v
+        self.order, self.n_words, self.n_ngrams = order, len(words), len(ngrams)
+        self._h = C.c_void_p()
+        _lib.check(L.vasr_lm_create(vslots.ctypes.data, vid.ctypes.data, vcap, nslots.ctypes.data, nval.ctypes.data,
+                                    ncap, order, wid["<s>"], wid["</s>"], wid["<unk>"], float(alpha), float(beta),
+                                    float(unk_offset), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().vasr_lm_destroy(self._h)
+        except Exception:
+            pass
+
+
+class BeamSearchDecoder:
+    def __init__(self, labels, lm_path=None, alpha=0.5, beta=1.5, token_min_logp=-5.0, beam_prune_logp=-10.0):
+        self.labels = list(labels)
+        if len(self.labels) + 1 > 128:
+            raise NotImplementedError("beam search supports at most 127 labels + blank")
+        self.space_id = self.labels.index(" ") if " " in self.labels else -1
+        self.token_min_logp, self.beam_prune_logp = token_min_logp, beam_prune_logp
+        self.lm_path, self.alpha, self.beta = lm_path, alpha, beta
+        self._lm = None
+        self._ws = None
+
+    def _get_lm(self):
+        if self.lm_path and self._lm is None:
+            self._lm = DeviceLM(self.lm_path, self.labels, self.alpha, self.beta)
+        return self._lm
+
+    def decode_ids(self, log_probs, beam_width):
+        """log_probs [B,T,V+1] cuda f32 -> (ids [B,T] i32, id_len [B] i32, score [B] f32)."""
+        if log_probs.device.type != "cuda":
+            raise _lib.VasrError("viet-asr_amd kernels need HIP-resident tensors; there is no CPU fallback for this path")
+        x = log_probs.to(torch.float32).contiguous()
+        B, T, V1 = x.shape
+        if V1 != len(self.labels) + 1:
+            raise ValueError(f"log_probs has {V1} classes, expected {len(self.labels)} labels + blank")
+        L = _lib.lib()
+        need = int(L.vasr_beam_workspace_bytes(B, T))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ids = torch.empty((B, T), dtype=torch.int32, device=x.device)
+        n = torch.empty((B,), dtype=torch.int32, device=x.device)
+        score = torch.empty((B,), dtype=torch.float32, device=x.device)
+        lm = self._get_lm()
+        _lib.check(L.vasr_beam_search_f32(x.data_ptr(), B, T, V1, self.space_id, int(beam_width),
+                                          float(self.token_min_logp), float(self.beam_prune_logp),
+                                          lm.handle if lm is not None else None, ids.data_ptr(), n.data_ptr(),
+                                          score.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                          torch.cuda.current_stream().cuda_stream))
+        return ids, n, score
+
+    def decode_batch(self, log_probs, beam_width):
+        ids, n, _ = self.decode_ids(log_probs, beam_width)
+        ids, n = ids.cpu().numpy(), n.cpu().numpy()
+        return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]

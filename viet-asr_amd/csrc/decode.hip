@@ -14,7 +14,6 @@ namespace vasr {
 
 namespace {
 
-constexpr int kMaxClasses = 128;
 
 // grid (ceil(T/64), B), block 64
 __global__ __launch_bounds__(64) void logsoftmax_argmax_kernel(const float* __restrict__ logits, int64_t row_ld,

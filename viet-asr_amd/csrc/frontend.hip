@@ -18,7 +18,6 @@ namespace {
 constexpr int kFramesPerBlock = 32;
 constexpr int kFramesPerWave = 8;
 constexpr int kNfft = 512;
-constexpr int kSeg = (kFramesPerBlock - 1) * 160 + kNfft;  // only used with hop 160; general hop below
 
 struct cf { float re, im; };
 __device__ __forceinline__ cf cadd(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }

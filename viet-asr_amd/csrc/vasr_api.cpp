@@ -88,6 +88,11 @@ struct vasr_handle {
   std::vector<hipEvent_t> ev_pool;
 };
 
+struct vasr_lm {
+  BeamLm view{};
+  std::vector<void*> allocs;
+};
+
 namespace {
 
 template <class T>
@@ -630,6 +635,63 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
   }
   return check_launch("transcribe");
 }
+
+size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
+  return batch > 0 && frames > 0 ? (size_t)batch * frames * kBeamMax * sizeof(unsigned int) : 0;
+}
+
+int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
+                         int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
+                         int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_ws, size_t ws_bytes,
+                         vasr_stream stream) {
+  if (!d_logp || !d_ids || !d_id_len || !d_score || !d_ws || batch <= 0 || frames <= 0)
+    return fail(VASR_ERR_INVALID, "bad argument");
+  if (num_classes < 2 || num_classes > 128 || beam_width < 1 || beam_width > kBeamMax)
+    return fail(VASR_ERR_UNSUPPORTED, "beam search supports 2..128 classes and beam_width 1..%d", kBeamMax);
+  if (space_id < -1 || space_id >= num_classes - 1) return fail(VASR_ERR_INVALID, "space_id out of range");
+  const size_t need_bytes = vasr_beam_workspace_bytes(batch, frames);
+  if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
+  launch_beam_search(d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width,
+                     token_min_logp, beam_prune_logp, lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws),
+                     d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream));
+  return check_launch("beam_search");
+}
+
+int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
+                   const float* h_nval, int ncap, int order, int bos_id, int eos_id, int unk_id, float alpha,
+                   float beta, float unk_offset, vasr_lm** out) {
+  if (!h_vkey || !h_vid || !h_nkey || !h_nval || !out || vcap <= 0 || ncap <= 0) return fail(VASR_ERR_INVALID, "bad argument");
+  if (order < 1 || order > 5) return fail(VASR_ERR_UNSUPPORTED, "n-gram order %d (supported: 1..5)", order);
+  auto* lm = new vasr_lm();
+  void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+  hipError_t e = hipMalloc(&p0, (size_t)vcap * 8);
+  if (e == hipSuccess) e = hipMalloc(&p1, (size_t)vcap * 4);
+  if (e == hipSuccess) e = hipMalloc(&p2, (size_t)ncap * 8);
+  if (e == hipSuccess) e = hipMalloc(&p3, (size_t)ncap * 8);
+  if (e == hipSuccess) e = hipMemcpy(p0, h_vkey, (size_t)vcap * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p1, h_vid, (size_t)vcap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p2, h_nkey, (size_t)ncap * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p3, h_nval, (size_t)ncap * 8, hipMemcpyHostToDevice);
+  lm->allocs = {p0, p1, p2, p3};
+  if (e != hipSuccess) {
+    vasr_lm_destroy(lm);
+    return fail(VASR_ERR_HIP, "uploading the n-gram tables: %s", hipGetErrorString(e));
+  }
+  lm->view = BeamLm{static_cast<unsigned long long*>(p0), static_cast<int32_t*>(p1), vcap,
+                    static_cast<unsigned long long*>(p2), static_cast<float*>(p3), ncap, order, bos_id, eos_id,
+                    unk_id, alpha, beta, unk_offset};
+  *out = lm;
+  return 0;
+}
+
+void vasr_lm_destroy(vasr_lm* lm) {
+  if (!lm) return;
+  for (void* p : lm->allocs) if (p) (void)hipFree(p);
+  delete lm;
+}
+
+uint64_t vasr_beam_hash_init(void) { return beam_hash_init(); }
+uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v) { return beam_hash_step(h, v); }
 
 int vasr_profile_begin(vasr_handle* h) {
   if (!h) return fail(VASR_ERR_INVALID, "null handle");

@@ -71,4 +71,18 @@ void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes
 void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids,
                          int32_t* id_len, hipStream_t st);
 
+// ---- beam search (beam.hip) ----
+struct BeamLm {  // device-resident hashed back-off n-gram model
+  const unsigned long long* vkey; const int32_t* vid; int vcap;   // word hash -> word id
+  const unsigned long long* nkey; const float* nval; int ncap;    // n-gram hash -> (log10 p, log10 backoff)
+  int order, bos, eos, unk;
+  float alpha, beta, unk_offset;
+};
+constexpr int kBeamMax = 128;  // beams kept per utterance at most
+void launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+                        float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
+                        int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st);
+unsigned long long beam_hash_step(unsigned long long h, unsigned long long v);
+unsigned long long beam_hash_init();
+
 }  // namespace vasr
