@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Time the device beam search on BASELINE config-4 shaped input (dev tool)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import viet_asr_amd
+from viet_asr_amd import configs, synth
+from viet_asr_amd.beam import BeamSearchDecoder
+from viet_asr_amd.engine import QuartzNetCTC
+cfg = configs.builtin("quartznet15x5"); jas = cfg["JasperEncoder"]["jasper"]
+eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 3), synth.decoder_state_dict(1024, 29, 3))
+sig, lens = synth.audio_batch(64, 160000, 3)
+r = eng.forward(torch.from_numpy(sig).cuda(), torch.from_numpy(lens).cuda(), want_logp=True)
+logp = r["logp"]
+for bw in (16, 128):
+    dec = BeamSearchDecoder(cfg["labels"])
+    dec.decode_ids(logp, bw); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): ids, n, sc = dec.decode_ids(logp, bw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f"beam_width {bw}: {dt*1e3:.1f} ms per batch of 64 x 501 frames; greedy-equal rows: "
+          f"{sum(dec.decode_batch(logp[:4], bw)[i] == eng.texts(r['ids'][:4], r['id_len'][:4])[i] for i in range(4))}/4")

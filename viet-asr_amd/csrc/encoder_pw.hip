@@ -46,7 +46,10 @@ struct PwGeom {
   static constexpr int PASSES = BKC / ROWS_PER_PASS;  // == 4 dwordx4 per thread per chunk
 };
 
-template <int WM, bool MASK, bool RES>
+// DUAL: the reduction runs over two activation tensors back to back -- rows [0, K1) from a.x, rows [K1, K)
+// from a.x2 (masked with a.lens2).  Used to fold a JasperBlock's residual 1x1 conv into its last sub-block's GEMM
+// (weights [s1*W1 | s2*W2] concatenated along K, shift h1 + h2), which removes the residual tensor round trip.
+template <int WM, bool MASK, bool RES, bool DUAL>
 __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
   using G = PwGeom<WM>;
   __shared__ v4f Bs4[2][kChunkFloats / 4];
@@ -68,11 +71,14 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
   const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64;
   const int kh = lane >> 5, l31 = lane & 31;
   const int len = MASK ? a.lens[b] : 0;
+  const int len2 = DUAL ? a.lens2[b] : 0;
 
   // B staging: thread -> (row, 4 consecutive columns) of the [BKC][BN] chunk
   constexpr int C4 = G::BN / 4;
   const int ld_row = tid / C4, ld_c4 = tid % C4;
-  const float* __restrict__ xb = a.x + (int64_t)b * a.K * a.ldx + t0 + ld_c4 * 4;
+  const int K1 = DUAL ? a.K1 : a.K;
+  const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0 + ld_c4 * 4;
+  const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 + ld_c4 * 4 : nullptr;
   // A fragments: packed [M/32][K/8][64 lanes] float4, this wave's two m-tiles
   const int kgroups = a.K / 8;
   const v4f* __restrict__ ap0 = reinterpret_cast<const v4f*>(a.wt) + ((int64_t)((m0 + wm) / 32) * kgroups) * 64 + lane;
@@ -88,16 +94,21 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
 
   v4f rb[G::PASSES];
   auto gload = [&](int k0) {
+    const bool second = DUAL && k0 >= K1;      // chunk-uniform: K1 is a multiple of the chunk depth
+    const float* __restrict__ src = second ? xb2 + (int64_t)(k0 - K1) * a.ldx2 : xb + (int64_t)k0 * a.ldx;
+    const int64_t ld = second ? a.ldx2 : a.ldx;
+    const bool mask = second || MASK;
+    const int ml = second ? len2 : len;
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
-      const int kr = k0 + ld_row + G::ROWS_PER_PASS * p;
-      v4f v = *reinterpret_cast<const v4f*>(xb + (int64_t)kr * a.ldx);
-      if (MASK) {  // MaskedConv1d: x.masked_fill(t >= lens, 0)  (jasper.py:113-118)
+      const int kr = ld_row + G::ROWS_PER_PASS * p;
+      v4f v = *reinterpret_cast<const v4f*>(src + (int64_t)kr * ld);
+      if (mask) {  // MaskedConv1d: x.masked_fill(t >= lens, 0)  (jasper.py:113-118)
         const int t = t0 + ld_c4 * 4;
-        if (t + 0 >= len) v.x = 0.f;
-        if (t + 1 >= len) v.y = 0.f;
-        if (t + 2 >= len) v.z = 0.f;
-        if (t + 3 >= len) v.w = 0.f;
+        if (t + 0 >= ml) v.x = 0.f;
+        if (t + 1 >= ml) v.y = 0.f;
+        if (t + 2 >= ml) v.z = 0.f;
+        if (t + 3 >= ml) v.w = 0.f;
       }
       rb[p] = v;
     }
@@ -175,19 +186,21 @@ void launch_t(const PwArgs& a, hipStream_t st) {
   const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
   dim3 grid(n_blocks), block(512);
-  const bool mask = a.lens != nullptr, res = a.res != nullptr;
-  if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
+  if (dual) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
 }
 
 }  // namespace
 
 void launch_pointwise(const PwArgs& a, hipStream_t st) {
   // M % 128 == 0, K % 32 == 0 and ldx % 256 == 0 are guaranteed by vasr_finalize()/pad_frames()
-  if (a.M % 512 == 0 && a.K % 128 == 0) launch_t<8>(a, st);
-  else if (a.M % 256 == 0 && a.K % 64 == 0) launch_t<4>(a, st);
+  const int kq = a.x2 ? a.K1 : a.K;   // dual source: both parts must be whole chunks
+  if (a.M % 512 == 0 && a.K % 128 == 0 && kq % 128 == 0) launch_t<8>(a, st);
+  else if (a.M % 256 == 0 && a.K % 64 == 0 && kq % 64 == 0) launch_t<4>(a, st);
   else launch_t<2>(a, st);
 }
 

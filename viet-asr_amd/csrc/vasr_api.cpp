@@ -60,6 +60,9 @@ struct Block {
   std::vector<SubBlock> subs;
   bool has_res = false;
   ConvLayer res;
+  bool fused_res = false;   // residual 1x1 conv folded into the last sub-block's GEMM (dual-source K)
+  ConvLayer fused;          // weights [s1*W1 | s2*W2], scale 1, shift h1 + h2; cin = K1 + K2
+  int fused_k1 = 0;
   int first_step = 0;
 };
 
@@ -147,6 +150,48 @@ int fold_bn(vasr_handle* h, const std::string& prefix, int c, int c_pad, ConvLay
     sh[i] = b->data[i] - m->data[i] * alpha;
   }
   if ((rc = upload(h, sc, &L->d_scale))) return rc;
+  return upload(h, sh, &L->d_shift);
+}
+
+int bn_affine(vasr_handle* h, const std::string& prefix, int c, std::vector<float>* alpha, std::vector<float>* beta) {
+  const HostTensor *g, *b, *m, *v;
+  int rc;
+  if ((rc = need(h, prefix + ".weight", c, &g)) || (rc = need(h, prefix + ".bias", c, &b)) ||
+      (rc = need(h, prefix + ".running_mean", c, &m)) || (rc = need(h, prefix + ".running_var", c, &v)))
+    return rc;
+  alpha->resize(c);
+  beta->resize(c);
+  for (int i = 0; i < c; ++i) {
+    const float invstd = 1.0f / std::sqrt(v->data[i] + 1e-3f);
+    (*alpha)[i] = g->data[i] * invstd;
+    (*beta)[i] = b->data[i] - m->data[i] * (*alpha)[i];
+  }
+  return 0;
+}
+
+// Last sub-block GEMM and residual GEMM of one JasperBlock as ONE reduction over K1 + K2:
+//   BN1(W1 d) + BN2(W2 x) = [a1*W1 | a2*W2] [d ; x] + (b1 + b2)        (parts/jasper.py:428-439)
+int pack_fused_residual(vasr_handle* h, const std::string& w1_key, const std::string& bn1, const std::string& w2_key,
+                        const std::string& bn2, int cout, int k1, int k2, ConvLayer* L) {
+  const HostTensor *w1, *w2;
+  std::vector<float> a1, b1, a2, b2;
+  int rc;
+  if ((rc = need(h, w1_key, (size_t)cout * k1, &w1)) || (rc = need(h, w2_key, (size_t)cout * k2, &w2)) ||
+      (rc = bn_affine(h, bn1, cout, &a1, &b1)) || (rc = bn_affine(h, bn2, cout, &a2, &b2)))
+    return rc;
+  const int K = k1 + k2;
+  std::vector<float> w((size_t)cout * K);
+  for (int m = 0; m < cout; ++m) {
+    for (int k = 0; k < k1; ++k) w[(size_t)m * K + k] = a1[m] * w1->data[(size_t)m * k1 + k];
+    for (int k = 0; k < k2; ++k) w[(size_t)m * K + k1 + k] = a2[m] * w2->data[(size_t)m * k2 + k];
+  }
+  L->cin = K;
+  L->cout = cout;
+  L->m_pad = (int)align_up(cout, 128);
+  std::vector<float> wt((size_t)K * L->m_pad, 0.f), sc(L->m_pad, 1.f), sh(L->m_pad, 0.f);
+  pack_pointwise_weights(w.data(), cout, K, L->m_pad, wt.data());
+  for (int m = 0; m < cout; ++m) sh[m] = b1[m] + b2[m];
+  if ((rc = upload(h, wt, &L->d_w)) || (rc = upload(h, sc, &L->d_scale))) return rc;
   return upload(h, sh, &L->d_shift);
 }
 
@@ -256,6 +301,21 @@ int build_encoder(vasr_handle* h) {
       if ((rc = pack_pointwise(h, key, d.filters, cin, &B.res))) return rc;
       snprintf(key, sizeof key, "encoder.%zu.res.0.1", i);
       if ((rc = fold_bn(h, key, d.filters, B.res.m_pad, &B.res))) return rc;
+      // fold the residual branch into the last sub-block's GEMM when both reductions tile evenly
+      const SubBlock& last = B.subs.back();
+      const int k1 = last.pw.cin, k2 = cin;
+      const int chunk = d.filters % 512 == 0 ? 128 : (d.filters % 256 == 0 ? 64 : 32);
+      if (d.stride == 1 && k1 % chunk == 0 && k2 % chunk == 0 && !getenv("VASR_NO_FUSED_RESIDUAL")) {
+        char w1[160], bn1[160], w2[160], bn2[160];
+        const int jl = j - (last.separable ? 3 : 2);
+        snprintf(w1, sizeof w1, "encoder.%zu.mconv.%d.conv.weight", i, jl + (last.separable ? 1 : 0));
+        snprintf(bn1, sizeof bn1, "encoder.%zu.mconv.%d", i, jl + (last.separable ? 2 : 1));
+        snprintf(w2, sizeof w2, "encoder.%zu.res.0.0.conv.weight", i);
+        snprintf(bn2, sizeof bn2, "encoder.%zu.res.0.1", i);
+        if ((rc = pack_fused_residual(h, w1, bn1, w2, bn2, d.filters, k1, k2, &B.fused))) return rc;
+        B.fused_res = true;
+        B.fused_k1 = k1;
+      }
     }
     if (d.filters % 128)
       return fail(VASR_ERR_UNSUPPORTED, "block %zu: filters %d is not a multiple of 128", i, d.filters);
@@ -280,7 +340,7 @@ int build_decoder(vasr_handle* h) {
 
 // ---------------- workspace plan ----------------
 struct WsPlan {
-  size_t lens_tab, seq, melp, bufP, bufQ, bufD, bufR, encp, logits, pred, total;
+  size_t lens_tab, seq, melp, bufP, bufQ, bufD, bufR, bufS, encp, logits, pred, total;
   int64_t T, Tp0, T1, Tp1;
 };
 
@@ -312,6 +372,7 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
   p.bufQ = take(h->has_encoder ? mid : 0);
   p.bufD = take(h->has_encoder ? mid : 0);
   p.bufR = take(h->has_encoder ? mid : 0);
+  p.bufS = take(h->has_encoder ? mid : 0);
   const int c_enc = h->has_encoder ? h->c_last : h->dec_feat_in;
   p.encp = take((size_t)batch * c_enc * p.Tp1 * 4);
   p.logits = take(h->has_decoder ? (size_t)batch * h->num_classes * p.Tp1 * 4 : 0);
@@ -354,16 +415,23 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
   int32_t* lens_tab = reinterpret_cast<int32_t*>(ws + p.lens_tab);
   auto lens = [&](int step) { return lens_tab + (size_t)step * batch; };
   launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st);
-  float* P = reinterpret_cast<float*>(ws + p.bufP);
-  float* Q = reinterpret_cast<float*>(ws + p.bufQ);
+  float* bufs[4] = {reinterpret_cast<float*>(ws + p.bufP), reinterpret_cast<float*>(ws + p.bufQ),
+                    reinterpret_cast<float*>(ws + p.bufR), reinterpret_cast<float*>(ws + p.bufS)};
   float* D = reinterpret_cast<float*>(ws + p.bufD);
-  float* R = reinterpret_cast<float*>(ws + p.bufR);
   const float* cur = x;
   int64_t cur_ld = x_ld, cur_T = T;
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     Block& B = h->blocks[i];
     const bool last_block = i + 1 == h->blocks.size();
-    if (B.has_res) {
+    const float* blk_in = cur;
+    const int64_t blk_ld = cur_ld;
+    // scratch buffers that are not the block input (the fused residual reads it until the block's last GEMM):
+    // sub-block outputs ping-pong between the first two, an unfused residual result takes the third
+    float* free3[3];
+    int nf = 0;
+    for (float* q : bufs) if (q != blk_in && nf < 3) free3[nf++] = q;
+    float* R = free3[2];
+    if (B.has_res && !B.fused_res) {
       // res branch: MaskedConv1d(1x1)(block input, lens_orig) -> BN   (parts/jasper.py:428-436)
       PwArgs a{};
       a.wt = B.res.d_w; a.x = cur; a.lens = lens(B.first_step); a.scale = B.res.d_scale; a.shift = B.res.d_shift;
@@ -373,7 +441,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       ProfScope ps(h, kProfPointwise, st);
       launch_pointwise(a, st);
     }
-    const int64_t res_ld = cur_ld;
+    int flip = 0;
     for (size_t r = 0; r < B.subs.size(); ++r) {
       SubBlock& S = B.subs[r];
       const bool last_sub = r + 1 == B.subs.size();
@@ -390,16 +458,20 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       } else {
         g_lens = lens(S.pw.step);  // block input is unmasked: predicate inside the GEMM
       }
-      float* dst = (cur == P) ? Q : P;
+      float* dst = free3[flip];
+      flip ^= 1;
       int64_t dst_ld = gx_ld;
       if (last_block && last_sub) { dst = out; dst_ld = out_ld; }
+      const bool fuse = last_sub && B.fused_res;
+      const ConvLayer& W = fuse ? B.fused : S.pw;
       PwArgs a{};
-      a.wt = S.pw.d_w; a.x = gx; a.lens = g_lens; a.scale = S.pw.d_scale; a.shift = S.pw.d_shift;
-      a.res = (last_sub && B.has_res) ? R : nullptr;
-      a.y = dst; a.M = S.pw.m_pad; a.K = S.pw.cin; a.batch = batch;
-      a.ldx = gx_ld; a.ldy = dst_ld; a.ldr = res_ld; a.frames = (int)g_T; a.m_store = S.pw.m_pad; a.relu = 1;
+      a.wt = W.d_w; a.x = gx; a.lens = g_lens; a.scale = W.d_scale; a.shift = W.d_shift;
+      a.res = (last_sub && B.has_res && !B.fused_res) ? R : nullptr;
+      a.y = dst; a.M = W.m_pad; a.K = W.cin; a.batch = batch;
+      a.ldx = gx_ld; a.ldy = dst_ld; a.ldr = blk_ld; a.frames = (int)g_T; a.m_store = W.m_pad; a.relu = 1;
       a.store_cols = (dst_ld % kTimeTile == 0) ? (int)dst_ld : (int)g_T;  // port tensors are not padded
-      if (a.res && res_ld != gx_ld)
+      if (fuse) { a.x2 = blk_in; a.lens2 = lens(B.first_step); a.K1 = B.fused_k1; a.ldx2 = blk_ld; }
+      if ((a.res || fuse) && blk_ld != gx_ld)
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
       {
         ProfScope ps(h, kProfPointwise, st);

@@ -46,8 +46,12 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
 
 struct PwArgs {
   const float* wt;        // weights in MFMA fragment order (pack_pointwise_weights), M % 128 == 0, K % 32 == 0
-  const float* x;         // [B][K][ldx]
+  const float* x;         // [B][K][ldx]  (dual source: [B][K1][ldx])
   const int32_t* lens;    // [B] input mask (nullptr = unmasked)
+  const float* x2;        // dual source: [B][K-K1][ldx2], always masked with lens2 (nullptr = single source)
+  const int32_t* lens2;
+  int32_t K1;
+  int64_t ldx2;
   const float* scale;     // [M]
   const float* shift;     // [M]
   const float* res;       // [B][M][ldr] added before the ReLU (nullptr = none)
