@@ -141,6 +141,12 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
 
+/* The fused call can cut the batch into `slices` contiguous parts (1..4; default 1 = off, because on MI355X it
+ * measured slower: 11.7 -> 13.5 ms at 2 slices) and run each on its own
+ * internal HIP stream, forked from / joined to `stream` with events: one part's HBM-bound kernels (depthwise,
+ * GEMM epilogue stores) then overlap another part's MFMA-bound GEMM main loops.  Results do not depend on it. */
+int vasr_set_slices(vasr_handle* h, int slices);
+
 /* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */
 /* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,
  * algorithm restated in oracle/beam_oracle.py).  Unlike the reference any batch size is accepted.

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vasr_ctc_collapse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "vasr_transcribe_greedy_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
                                              C.c_size_t, _P]),
+    "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
                                        _P, _P, _P, _P, C.c_size_t, _P]),
@@ -170,6 +171,9 @@ class Handle:
         check(lib().vasr_algorithmic_work(self.h, int(batch), int(samples), out))
         return dict(pointwise_flops=out[0], depthwise_flops=out[1], depthwise_bytes=out[2],
                     decoder_flops=out[3], frontend_flops=out[4])
+
+    def set_slices(self, n):
+        check(lib().vasr_set_slices(self.h, int(n)))
 
     def profile_begin(self):
         check(lib().vasr_profile_begin(self.h))

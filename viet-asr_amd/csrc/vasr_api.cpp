@@ -67,6 +67,7 @@ struct Block {
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int kMaxSlices = 4;
 
 }  // namespace
 
@@ -85,6 +86,13 @@ struct vasr_handle {
   ConvLayer dec;
   int c_mid_max = 0, c_last = 0;
   // optional per-kernel-class HIP-event timing (vasr_profile_begin/end)
+  // batch slicing across internal streams (vasr_set_slices)
+  // measured on MI355X (QuartzNet15x5, B=64): 1 slice 11.7 ms, 2 slices 13.5 ms, 4 slices 19.4 ms -- half-batch
+  // GEMMs leave one workgroup per CU and the co-running kernels thrash L2, so slicing is OFF by default
+  int slices = getenv("VASR_SLICES") ? atoi(getenv("VASR_SLICES")) : 1;
+  bool slice_ready = false;
+  hipStream_t slice_stream[kMaxSlices] = {};
+  hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
   bool profiling = false;
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;
@@ -562,6 +570,10 @@ void vasr_destroy(vasr_handle* h) {
   for (void* p : h->dev_allocs) (void)hipFree(p);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->slice_ready) {
+    for (int i = 0; i < kMaxSlices; ++i) { (void)hipStreamDestroy(h->slice_stream[i]); (void)hipEventDestroy(h->slice_done[i]); }
+    (void)hipEventDestroy(h->slice_fork);
+  }
   delete h;
 }
 
@@ -605,10 +617,15 @@ int64_t vasr_encoded_frames(const vasr_handle* h, int64_t mel_frames) {
   return enc_frames(h, mel_frames);
 }
 
+static size_t sliced_workspace_bytes(const vasr_handle* h, int batch, int64_t T);
+
 size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, int64_t mel_frames) {
   if (!h || !h->finalized || batch <= 0) return 0;
   const int64_t T = samples > 0 ? vasr_mel_frames(h, samples) : mel_frames;
-  return plan_ws(h, batch, T).total;
+  const size_t whole = plan_ws(h, batch, T).total;
+  if (samples > 0 && h->has_frontend && h->has_encoder && h->has_decoder)
+    return std::max(whole, sliced_workspace_bytes(h, batch, T));
+  return whole;
 }
 
 int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
@@ -672,20 +689,12 @@ int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blan
   return check_launch("ctc_collapse");
 }
 
-int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
-                               int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
-                               void* d_ws, size_t ws_bytes, vasr_stream stream) {
-  if (!h || !h->finalized || !h->has_frontend || !h->has_encoder || !h->has_decoder)
-    return fail(VASR_ERR_STATE, "handle needs a finalized front end, encoder and decoder");
-  if (batch <= 0 || !d_wav || !d_len || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
-  if (samples <= h->fe.n_fft / 2)
-    return fail(VASR_ERR_INVALID, "reflect padding needs more than n_fft/2 = %d samples (got %lld)",
-                h->fe.n_fft / 2, (long long)samples);
+// One contiguous slice of the batch through the whole path on one stream.
+static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                           int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                           char* ws, hipStream_t st) {
   const int64_t T = vasr_mel_frames(h, samples);
   const WsPlan p = plan_ws(h, batch, T);
-  if (ws_bytes < p.total) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, p.total);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  char* ws = static_cast<char*>(d_ws);
   int64_t* seq = reinterpret_cast<int64_t*>(ws + p.seq);
   float* melp = reinterpret_cast<float*>(ws + p.melp);
   float* encp = reinterpret_cast<float*>(ws + p.encp);
@@ -705,7 +714,80 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
     ProfScope ps(h, kProfHead, st);
     launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
   }
+  return 0;
+}
+
+// How many slices the batch is cut into; slice i runs on its own internal stream so that one slice's
+// HBM-bound kernels (depthwise, epilogue stores) overlap another slice's MFMA-bound GEMM main loops.
+static int n_slices(const vasr_handle* h, int batch) {
+  int n = h->slices;
+  if (n < 1) n = 1;
+  if (n > kMaxSlices) n = kMaxSlices;
+  while (n > 1 && batch / n < 8) --n;   // tiny batches: one slice (the kernels would not fill the chip anyway)
+  return n;
+}
+
+static size_t sliced_workspace_bytes(const vasr_handle* h, int batch, int64_t T) {
+  const int n = n_slices(h, batch);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int lo = (int)((int64_t)batch * i / n), hi = (int)((int64_t)batch * (i + 1) / n);
+    total += align_up(plan_ws(h, hi - lo, T).total, 256);
+  }
+  return total;
+}
+
+int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                               int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                               void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  if (!h || !h->finalized || !h->has_frontend || !h->has_encoder || !h->has_decoder)
+    return fail(VASR_ERR_STATE, "handle needs a finalized front end, encoder and decoder");
+  if (batch <= 0 || !d_wav || !d_len || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
+  if (samples <= h->fe.n_fft / 2)
+    return fail(VASR_ERR_INVALID, "reflect padding needs more than n_fft/2 = %d samples (got %lld)",
+                h->fe.n_fft / 2, (long long)samples);
+  const int64_t T = vasr_mel_frames(h, samples);
+  const size_t need_bytes = sliced_workspace_bytes(h, batch, T);
+  if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
+  hipStream_t user = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(d_ws);
+  const int n = n_slices(h, batch);
+  const int64_t T1 = vasr_encoded_frames(h, T);
+  if (n == 1) {
+    int rc = transcribe_part(h, d_wav, d_len, batch, samples, d_pred, d_ids, d_id_len, d_logp, d_enc_len, ws, user);
+    return rc ? rc : check_launch("transcribe");
+  }
+  if (!h->slice_ready) {
+    for (int i = 0; i < kMaxSlices; ++i) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->slice_stream[i], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->slice_done[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->slice_fork, hipEventDisableTiming));
+    h->slice_ready = true;
+  }
+  HIP_TRY(hipEventRecord(h->slice_fork, user));
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const int lo = (int)((int64_t)batch * i / n), hi = (int)((int64_t)batch * (i + 1) / n);
+    hipStream_t st = h->slice_stream[i];
+    HIP_TRY(hipStreamWaitEvent(st, h->slice_fork, 0));
+    int rc = transcribe_part(h, d_wav + (int64_t)lo * samples, d_len + lo, hi - lo, samples,
+                             d_pred ? d_pred + (int64_t)lo * T1 : nullptr, d_ids ? d_ids + (int64_t)lo * T1 : nullptr,
+                             d_id_len ? d_id_len + lo : nullptr,
+                             d_logp ? d_logp + (int64_t)lo * T1 * h->num_classes : nullptr,
+                             d_enc_len ? d_enc_len + lo : nullptr, ws + off, st);
+    if (rc) return rc;
+    off += align_up(plan_ws(h, hi - lo, T).total, 256);
+    HIP_TRY(hipEventRecord(h->slice_done[i], st));
+    HIP_TRY(hipStreamWaitEvent(user, h->slice_done[i], 0));
+  }
   return check_launch("transcribe");
+}
+
+int vasr_set_slices(vasr_handle* h, int slices) {
+  if (!h || slices < 1 || slices > kMaxSlices) return fail(VASR_ERR_INVALID, "slices must be 1..%d", kMaxSlices);
+  h->slices = slices;
+  return 0;
 }
 
 size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
