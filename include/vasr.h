@@ -141,6 +141,18 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
 
+/* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */
+/* int16 PCM -> float32 scaled by 2^-15 (AudioSegment._convert_samples_to_float32). n = total samples. */
+int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream);
+/* Band-limited sample-rate conversion of a zero-padded batch (interpolated windowed-sinc, the scheme of resampy's
+ * kaiser_best that librosa.load uses by default; third-party => parity unpinned).  d_table = [nwin][2] floats
+ * (window value, delta to the next entry) with num_table entries per zero crossing, built on the host
+ * (viet-asr_amd/audio.py::sinc_table); ratio = sr_out / sr_in; d_len_out[b] = int(d_len_in[b] * ratio);
+ * rows of d_out are zero past that length.  ld_out >= max output length. */
+int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in, int batch, const float* d_table,
+                      int nwin, int num_table, double ratio, float* d_out, int64_t ld_out, int64_t* d_len_out,
+                      vasr_stream stream);
+
 /* The fused call can cut the batch into `slices` contiguous parts (1..4; default 1 = off, because on MI355X it
  * measured slower: 11.7 -> 13.5 ms at 2 slices) and run each on its own
  * internal HIP stream, forked from / joined to `stream` with events: one part's HBM-bound kernels (depthwise,

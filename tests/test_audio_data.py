@@ -1,0 +1,90 @@
+"""Audio ingest + manifest data layer: CPU tests of the host logic, -m gpu tests of the device kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from viet_asr_amd import audio
+from viet_asr_amd.core import DeviceType, NeuralModuleFactory
+from viet_asr_amd.data_layer import AudioToTextDataLayer, word_error_rate
+
+LABELS = list(" abcdefghijklmnopqrstuvwxyz'")
+
+
+def _tone(n, sr, f=440.0, amp=0.3):
+    return (amp * np.sin(2 * np.pi * f * np.arange(n) / sr)).astype(np.float32)
+
+
+def test_wav_round_trip_and_int_scaling(tmp_path):
+    x = _tone(1600, 16000)
+    p = str(tmp_path / "a.wav")
+    audio.write_wav(p, x, 16000)
+    y, sr = audio.read_wav(p)
+    assert sr == 16000 and y.dtype == np.float32 and len(y) == 1600
+    assert np.abs(y - x).max() <= 1.0 / 32768 + 1e-7                     # int16 quantisation, scaled by 2^-15
+    assert np.all(np.round(y * 32768) == np.round(y * 32768).astype(np.int16))
+
+
+def test_manifest_layer_batches_and_collate(tmp_path):
+    NeuralModuleFactory(placement=DeviceType.CPU)
+    man = str(tmp_path / "m.json")
+    durs = [0.30, 0.10, 0.20, 0.25, 5.0]
+    with open(man, "w", encoding="utf-8") as f:
+        for i, d in enumerate(durs):
+            p = str(tmp_path / f"u{i}.wav")
+            audio.write_wav(p, _tone(int(d * 16000), 16000, 200 + 50 * i), 16000)
+            f.write(json.dumps({"audio_filepath": p, "duration": d, "text": f"ab c{'de'[i % 2]} Zq"}) + "\n")
+    dl = AudioToTextDataLayer(man, LABELS, batch_size=2, max_duration=1.0)
+    assert list(dl.output_ports) == ["audio_signal", "a_sig_length", "transcripts", "transcript_length"]
+    assert len(dl) == 2 and dl.utterance_order() == [1, 2, 3, 0]          # 5 s clip filtered, bucketed by duration
+    batches = list(dl.data_iterator)
+    a, al, t, tl = batches[0]
+    assert a.shape == (2, 3200) and al.tolist() == [1600, 3200] and not a[0, 1600:].any()   # zero-pad to max
+    assert tl.tolist() == [7, 7] and t[0].tolist() == [1, 2, 0, 3, 5, 0, 17]                 # 'Z' dropped, 'q' kept
+    assert word_error_rate(["a b c", "x"], ["a b d", "x"]) == pytest.approx(0.25)
+    assert word_error_rate(["abc"], ["abd"], use_cer=True) == pytest.approx(1 / 3)
+    with pytest.raises(ValueError):
+        word_error_rate(["a"], ["a", "b"])
+
+
+def test_sinc_table_matches_oracle():
+    from oracle import audio_oracle as AO
+    tab, nt = audio.sinc_table()
+    win, nt2 = AO.sinc_window()
+    assert nt == nt2 == 512 and tab.shape == (64 * 512 + 1, 2)
+    assert np.abs(tab[:, 0] - win).max() < 1e-7 and abs(tab[0, 0] - 0.9475937167399596) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr_in,sr_out", [(8000, 16000), (16000, 8000), (11025, 16000)])
+def test_device_resampler_matches_oracle(gpu, sr_in, sr_out):
+    from oracle import audio_oracle as AO
+    r = np.random.RandomState(0)
+    lens = np.array([3000, 1777], dtype=np.int64)
+    x = np.zeros((2, 3000), dtype=np.float32)
+    for b in range(2):
+        x[b, : lens[b]] = (0.2 * r.randn(lens[b]) + _tone(lens[b], sr_in, 300.0)).astype(np.float32)
+    y, ln = audio.resample(torch.from_numpy(x).to(gpu), torch.from_numpy(lens).to(gpu), sr_in, sr_out)
+    y, ln = y.cpu().numpy(), ln.cpu().numpy()
+    for b in range(2):
+        ref = AO.resample(x[b, : lens[b]], sr_in, sr_out)
+        assert ln[b] == len(ref)
+        assert np.abs(y[b, : ln[b]] - ref).max() < 2e-6
+        assert not y[b, ln[b]:].any()
+    # a band-limited tone survives 8k -> 16k: compare with the analytic signal away from the edges
+    n = 4000
+    tone = _tone(n, 8000, 440.0)
+    up, _ = audio.resample(torch.from_numpy(tone[None]).to(gpu), torch.tensor([n], device=gpu), 8000, 16000)
+    want = _tone(2 * n, 16000, 440.0)
+    assert np.abs(up.cpu().numpy()[0, 600:-600] - want[600:-600]).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_pcm16_to_float_on_device(gpu):
+    pcm = torch.from_numpy(np.array([[0, 1, -1, 32767, -32768, 1234, -4321]], dtype=np.int16)).to(gpu)
+    out = audio.pcm16_to_float(pcm).cpu().numpy()
+    assert out.dtype == np.float32 and np.array_equal(out, pcm.cpu().numpy().astype(np.float32) / 32768.0)
+    big = torch.randint(-32768, 32767, (3, 4001), dtype=torch.int16, device=gpu)
+    assert torch.equal(audio.pcm16_to_float(big), big.float() / 32768.0)

@@ -160,3 +160,55 @@ def test_full_size_properties(gpu):
     expanded = torch.stack([row, torch.full_like(row, 90)], 1).reshape(1, -1)
     ids2, n2 = stages.ctc_collapse(expanded, 90)
     assert ids2[0, : n2[0]].tolist() == row.tolist()
+
+
+def test_vietasr_class_end_to_end(gpu, tmp_path):
+    """infer.py's VietASR on synthetic checkpoints written in the reference's state_dict format: DAG path (greedy and
+    beam wiring), fused batch path, 8 kHz input resampled on the device."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.infer import VietASR
+    from oracle import audio_oracle as AO
+    from oracle import quartznet_oracle as O
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 8), synth.decoder_state_dict(1024, 91, 8)
+    enc_p, dec_p = str(tmp_path / "JasperEncoder-STEP-1.pt"), str(tmp_path / "JasperDecoderForCTC-STEP-1.pt")
+    torch.save({k: torch.as_tensor(v) for k, v in enc_sd.items()}, enc_p)
+    torch.save({k: torch.as_tensor(v) for k, v in dec_sd.items()}, dec_p)
+    asr = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="greedy")
+    sig, lens = synth.audio_batch(3, 24000, 8, ragged=True)
+    utts = [sig[b, : lens[b]] for b in range(3)]
+    for b in range(3):                     # one utterance at a time, like infer.py
+        ref = O.forward_all(utts[b][None], np.array([len(utts[b])]), enc_sd, dec_sd, jas)
+        assert asr.transcribe(utts[b]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])[0]
+    ref = O.forward_all(sig, lens, enc_sd, dec_sd, jas)            # padded batch (quirks Q4/Q5 apply)
+    assert asr.transcribe_batch(utts) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
+    # 8 kHz int16 input: scaled + resampled on the device, then the same path
+    x8 = (synth.audio_batch(1, 12000, 9)[0][0] * 32767).astype(np.int16)
+    up = AO.resample(x8.astype(np.float32) / 32768.0, 8000, 16000)
+    ref8 = O.forward_all(up[None], np.array([len(up)]), enc_sd, dec_sd, jas)
+    assert asr.transcribe(x8, sample_rate=8000) == O.ctc_decode_strings(ref8["pred"], cfg["labels"])[0]
+    beam = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="beam", beam_width=8, lm_path=None)
+    out = beam.transcribe(utts[0])
+    assert isinstance(out, str)
+    with pytest.raises(AssertionError):
+        VietASR("quartznet12x1_vi", str(tmp_path / "missing.pt"), dec_p)
+
+
+def test_long_clips_config5_shape(gpu):
+    """BASELINE config 5 geometry (30 s clips -> L=480000, T=3001, T'=1501) at a small batch, against the oracle."""
+    from viet_asr_amd import configs, synth
+    cfg = configs.builtin("quartznet15x5")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 6), synth.decoder_state_dict(1024, 29, 6)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    sig, lens = synth.audio_batch(2, 480000, 6, ragged=True)
+    r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
+    ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
+    assert r["logp"].shape == (2, 1501, 29)
+    # log-probs reach -140 on this model (very peaky posteriors): absolute + relative tolerance
+    assert ((r["logp"].cpu() - ref["logp"]).abs() <= LOGP_TOL + 5e-5 * ref["logp"].abs()).all()
+    top2 = torch.topk(ref["logp"], 2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3               # frames whose margin is far above fp32 round-off
+    assert (r["pred"].cpu()[safe] == ref["pred"][safe]).all()
+    assert (r["pred"].cpu() != ref["pred"]).sum() <= 2

@@ -54,6 +54,8 @@ SIGNATURES = {
     "vasr_ctc_collapse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "vasr_transcribe_greedy_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
                                              C.c_size_t, _P]),
+    "vasr_pcm16_to_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,

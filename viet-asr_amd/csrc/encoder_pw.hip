@@ -24,6 +24,8 @@
 //     k-steps with one coalesced 16-byte load straight from L2, one k-group ahead of use.
 //   * Work-group ids are remapped so that neighbours in (m-block, time-tile) order share an XCD
 //     (private L2 per XCD; block b lands on XCD b % 8).
+#include <cstdlib>
+
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -35,10 +37,11 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kChunkFloats = 8192;  // 32 KB of activations per LDS buffer
 
-template <int WM>
+// WM x WN wave grid, each wave TM (1 or 2) m-tiles of 32 rows by 2 n-tiles of 32 columns
+template <int WM, int TM>
 struct PwGeom {
   static constexpr int WN = 8 / WM;
-  static constexpr int BM = 64 * WM;
+  static constexpr int BM = 32 * TM * WM;
   static constexpr int BN = 64 * WN;
   static constexpr int BKC = kChunkFloats / BN;  // 128 / 64 / 32 rows of K per chunk
   static constexpr int GROUPS = BKC / 8;         // k-groups (8 k = 4 MFMA k-steps) per chunk
@@ -49,9 +52,9 @@ struct PwGeom {
 // DUAL: the reduction runs over two activation tensors back to back -- rows [0, K1) from a.x, rows [K1, K)
 // from a.x2 (masked with a.lens2).  Used to fold a JasperBlock's residual 1x1 conv into its last sub-block's GEMM
 // (weights [s1*W1 | s2*W2] concatenated along K, shift h1 + h2), which removes the residual tensor round trip.
-template <int WM, bool MASK, bool RES, bool DUAL>
+template <int WM, int TM, bool MASK, bool RES, bool DUAL>
 __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
-  using G = PwGeom<WM>;
+  using G = PwGeom<WM, TM>;
   __shared__ v4f Bs4[2][kChunkFloats / 4];
 
   // ---- XCD-aware remap: consecutive logical ids -> same XCD ----
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64;
+  const int wm = (wave / G::WN) * 32 * TM, wn = (wave % G::WN) * 64;
   const int kh = lane >> 5, l31 = lane & 31;
   const int len = MASK ? a.lens[b] : 0;
   const int len2 = DUAL ? a.lens2[b] : 0;
@@ -79,14 +82,14 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
   const int K1 = DUAL ? a.K1 : a.K;
   const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0 + ld_c4 * 4;
   const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 + ld_c4 * 4 : nullptr;
-  // A fragments: packed [M/32][K/8][64 lanes] float4, this wave's two m-tiles
+  // A fragments: packed [M/32][K/8][64 lanes] float4, this wave's TM m-tiles
   const int kgroups = a.K / 8;
   const v4f* __restrict__ ap0 = reinterpret_cast<const v4f*>(a.wt) + ((int64_t)((m0 + wm) / 32) * kgroups) * 64 + lane;
-  const v4f* __restrict__ ap1 = ap0 + (int64_t)kgroups * 64;
+  const v4f* __restrict__ ap1 = ap0 + (TM > 1 ? (int64_t)kgroups * 64 : 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -140,8 +143,10 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
         const float b1 = Bs[kk * G::BN + 32];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1, acc[1][1], 0, 0, 0);
+        if constexpr (TM > 1) {
+          acc[TM - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0, acc[TM - 1][0], 0, 0, 0);
+          acc[TM - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1, acc[TM - 1][1], 0, 0, 0);
+        }
       }
       a0 = n0;
       a1 = n1;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/bench_layers.py ablation)
   const bool full = (t0 + G::BN <= a.store_cols) && (m0 + G::BM <= a.m_store);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int mq = m0 + wm + i * 32 + 8 * q + 4 * kh;
@@ -179,29 +184,35 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_kernel(PwArgs a, int blocks_m,
   }
 }
 
-template <int WM>
+template <int WM, int TM>
 void launch_t(const PwArgs& a, hipStream_t st) {
-  using G = PwGeom<WM>;
+  using G = PwGeom<WM, TM>;
   const int blocks_m = a.M / G::BM;
   const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
   dim3 grid(n_blocks), block(512);
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else hipLaunchKernelGGL((pw_gemm_kernel<WM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  if (dual) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
 }
 
 }  // namespace
 
 void launch_pointwise(const PwArgs& a, hipStream_t st) {
-  // M % 128 == 0, K % 32 == 0 and ldx % 256 == 0 are guaranteed by vasr_finalize()/pad_frames()
-  const int kq = a.x2 ? a.K1 : a.K;   // dual source: both parts must be whole chunks
-  if (a.M % 512 == 0 && a.K % 128 == 0 && kq % 128 == 0) launch_t<8>(a, st);
-  else if (a.M % 256 == 0 && a.K % 64 == 0 && kq % 64 == 0) launch_t<4>(a, st);
-  else launch_t<2>(a, st);
+  // M % 128 == 0, K % 32 == 0 and ldx % 256 == 0 are guaranteed by vasr_finalize()/pad_frames().
+  // Tile choice: cover all of M with one workgroup where possible (each activation fetched once), and keep
+  // >= 2 workgroups per CU in flight: 512 ch -> 512x64 tiles, 256 ch -> 256x64 (one m-tile per wave), else 128x128.
+  static const int force = getenv("VASR_PW_TILE") ? atoi(getenv("VASR_PW_TILE")) : 0;
+  const int kq = a.x2 ? a.K1 : a.K;   // dual source: both parts must be whole chunks of the K depth per LDS buffer
+  const bool k128 = a.K % 128 == 0 && kq % 128 == 0, k64 = a.K % 64 == 0 && kq % 64 == 0;
+  if (a.M % 512 == 0 && k128 && force != 42) launch_t<8, 2>(a, st);
+  else if (a.M % 256 == 0 && k128 && force != 42) launch_t<8, 1>(a, st);
+  else if (a.M % 256 == 0 && k64) launch_t<4, 2>(a, st);
+  else if (k64) launch_t<4, 1>(a, st);
+  else launch_t<2, 2>(a, st);
 }
 
 // [cout][cin] row-major -> MFMA A-fragment order [m_pad/32][cin/8][64 lanes][4]:

@@ -784,6 +784,27 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
   return check_launch("transcribe");
 }
 
+int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream) {
+  if (!d_pcm || !d_out || n < 0) return fail(VASR_ERR_INVALID, "bad argument");
+  if (n == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(d_pcm) & 7) || (reinterpret_cast<uintptr_t>(d_out) & 15))
+    return fail(VASR_ERR_INVALID, "pcm / float buffers must be 8 / 16-byte aligned");
+  launch_pcm16_to_f32(d_pcm, n, d_out, static_cast<hipStream_t>(stream));
+  return check_launch("pcm16_to_f32");
+}
+
+int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in, int batch, const float* d_table,
+                      int nwin, int num_table, double ratio, float* d_out, int64_t ld_out, int64_t* d_len_out,
+                      vasr_stream stream) {
+  if (!d_in || !d_len_in || !d_table || !d_out || !d_len_out || batch <= 0 || ld_in <= 0 || ld_out <= 0)
+    return fail(VASR_ERR_INVALID, "bad argument");
+  if (!(ratio > 0.0) || nwin < 2 || num_table < 1 || (int)((ratio < 1.0 ? ratio : 1.0) * num_table) < 1)
+    return fail(VASR_ERR_INVALID, "invalid ratio / table for resampling");
+  launch_resample(d_in, ld_in, d_len_in, batch, d_table, nwin, num_table, ratio, d_out, ld_out, d_len_out,
+                  static_cast<hipStream_t>(stream));
+  return check_launch("resample");
+}
+
 int vasr_set_slices(vasr_handle* h, int slices) {
   if (!h || slices < 1 || slices > kMaxSlices) return fail(VASR_ERR_INVALID, "slices must be 1..%d", kMaxSlices);
   h->slices = slices;

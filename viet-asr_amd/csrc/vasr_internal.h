@@ -75,6 +75,11 @@ void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes
 void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids,
                          int32_t* id_len, hipStream_t st);
 
+// ---- audio ingest (audio.hip) ----
+void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st);
+void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int batch, const float* table, int nwin,
+                     int num_table, double ratio, float* y, int64_t ld_out, int64_t* len_out, hipStream_t st);
+
 // ---- beam search (beam.hip) ----
 struct BeamLm {  // device-resident hashed back-off n-gram model
   const unsigned long long* vkey; const int32_t* vid; int vcap;   // word hash -> word id

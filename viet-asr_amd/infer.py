@@ -64,15 +64,30 @@ class VietASR:
             raise ValueError(f"decoder must be 'greedy' or 'beam', got {decoder!r}")
         self._fused = None
 
-    def transcribe(self, audio_signal):
+    def _to_model_rate(self, audio_signal, sample_rate):
+        """The reference CLI resamples with librosa.load(sr=16000) (infer.py:200); here on the device."""
+        rate = self.model_definition["AudioToMelSpectrogramPreprocessor"]["sample_rate"]
+        x = np.asarray(audio_signal)
+        if x.dtype.kind == "i":                     # integer PCM: AudioSegment scaling (segment.py:61-74)
+            x = x.astype(np.float32) * (1.0 / 2 ** (8 * x.dtype.itemsize - 1))
+        x = x.astype(np.float32)
+        if sample_rate is None or int(sample_rate) == int(rate):
+            return x
+        from . import audio
+        y, n = audio.resample(torch.from_numpy(x)[None].cuda(), torch.tensor([len(x)], device="cuda"), sample_rate, rate)
+        return y[0, : int(n[0])].cpu().numpy()
+
+    def transcribe(self, audio_signal, sample_rate=None):
+        audio_signal = self._to_model_rate(audio_signal, sample_rate)
         self.data_layer.set_signal(audio_signal)
         evaluated = self.neural_factory.infer(tensors=self.infer_tensors, verbose=False)
         if self.mode == "greedy":
             return post_process_predictions(evaluated[0], self.labels)[0]
         return evaluated[0][0]
 
-    def transcribe_batch(self, signals):
+    def transcribe_batch(self, signals, sample_rate=None):
         """Greedy transcripts of a list of 1-D signals through the fused one-call path."""
+        signals = [self._to_model_rate(s, sample_rate) for s in signals]
         if self._fused is None:
             self._fused = QuartzNetCTC(self.model_definition, self.encoder.state_dict(), self.decoder.state_dict())
         return self._fused.transcribe([np.asarray(s, dtype=np.float32) for s in signals])
