@@ -141,6 +141,13 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
 
+/* GEMM arithmetic of the 1x1 convolutions of the encoder:
+ *   0 (default)  v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;
+ *   1            every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
+ *                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error < one fp32 rounding; 2.67x less
+ *                matrix time).  Layers whose shape the split kernel does not cover keep mode 0. */
+int vasr_set_gemm_mode(vasr_handle* h, int mode);
+
 /* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */
 /* int16 PCM -> float32 scaled by 2^-15 (AudioSegment._convert_samples_to_float32). n = total samples. */
 int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream);

@@ -56,6 +56,7 @@ SIGNATURES = {
                                              C.c_size_t, _P]),
     "vasr_pcm16_to_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
     "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
+    "vasr_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
@@ -173,6 +174,10 @@ class Handle:
         check(lib().vasr_algorithmic_work(self.h, int(batch), int(samples), out))
         return dict(pointwise_flops=out[0], depthwise_flops=out[1], depthwise_bytes=out[2],
                     decoder_flops=out[3], frontend_flops=out[4])
+
+    def set_gemm_mode(self, mode):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (3 x bf16 split operands, fp32-equivalent accuracy)."""
+        check(lib().vasr_set_gemm_mode(self.h, {"fp32": 0, "bf16x3": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_slices(self, n):
         check(lib().vasr_set_slices(self.h, int(n)))

@@ -1,0 +1,250 @@
+// Pointwise (1x1) convolution GEMM on the bf16 matrix pipe with fp32-equivalent accuracy ("3 x bf16" operands).
+//
+// Same operation, tiling, epilogue and dual-source K reduction as encoder_pw.hip (reference
+// nemo/collections/asr/parts/jasper.py:113-132, :374-392, :428-448), but every fp32 operand is split exactly into
+// three bf16 terms  x = x_hi + x_mid + x_lo  (round-to-nearest each: 8 + 8 + 8 significant bits = the 24 of fp32)
+// and the product is evaluated with the six largest cross terms
+//     a*b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms are < 2^-25 |a b| (measured: max relative
+// product error 2.7e-8, below the 4e-8 of one fp32 rounding), so the result is as accurate as the fp32-MFMA path
+// -- 6 bf16 MFMAs (6 x 32 cycles per 32x32x16 block) replace 8 fp32 ones (8 x 64 cycles): 2.67x less matrix time.
+//
+//   * weights are split and packed at vasr_finalize() in A-fragment order [M/32][K/16][3 planes][64 lanes][8 bf16]:
+//     one 16-byte load per lane, plane and 16-deep k-step, straight from L2, one step ahead of use;
+//   * activations are split ONCE per workgroup while they are staged into LDS (v_cvt_pk_bf16_f32), laid out
+//     [plane][k-step][k-half][column][8 bf16] so that every B fragment is one conflict-free ds_read_b128.
+#include <cstdlib>
+#include <cstring>
+
+#include "vasr_internal.h"
+
+namespace vasr {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+using v2f = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+constexpr int BN = 64;    // time columns per workgroup
+constexpr int BKC = 64;   // K rows per LDS buffer (3 planes x 64 x 64 x 2 B = 24 KB)
+constexpr int STEPS = BKC / 16;
+
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+  const v2f v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32, RNE
+}
+
+// 8 consecutive-k values of one column -> three 16-byte bf16 fragments
+__device__ __forceinline__ void split3(const float (&x)[8], uint4& hi, uint4& mid, uint4& lo) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    h[p] = cvt2(a, b);
+    const float ra = a - __uint_as_float(h[p] << 16), rb = b - __uint_as_float(h[p] & 0xffff0000u);   // exact
+    m[p] = cvt2(ra, rb);
+    const float sa = ra - __uint_as_float(m[p] << 16), sb = rb - __uint_as_float(m[p] & 0xffff0000u); // exact
+    l[p] = cvt2(sa, sb);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  mid = make_uint4(m[0], m[1], m[2], m[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// 8 waves stacked along M, each TM m-tiles (32 rows) x 2 n-tiles (32 columns): workgroup tile (256*TM) x 64
+template <int TM, bool MASK, bool RES, bool DUAL>
+__global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+  constexpr int BM = 256 * TM;
+  __shared__ uint4 Bs[2][3][STEPS][2][BN];
+
+  int bid = blockIdx.x;
+  {
+    const int q = n_blocks / 8, r = n_blocks % 8, xcd = bid % 8, slot = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int mb = bid % blocks_m;
+  const int nt = bid / blocks_m;
+  const int b = nt / tiles_t;
+  const int t0 = (nt % tiles_t) * BN;
+  const int m0 = mb * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave * 32 * TM;
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int len = MASK ? a.lens[b] : 0;
+  const int len2 = DUAL ? a.lens2[b] : 0;
+
+  // staging: thread -> (8 consecutive k rows, one column)
+  const int st_n = tid % BN, st_g = tid / BN;   // st_g in [0, 8): k rows 8*st_g .. 8*st_g+7 of the chunk
+  const int K1 = DUAL ? a.K1 : a.K;
+  const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0 + st_n;
+  const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 + st_n : nullptr;
+  // A fragments [M/32][K/16][3][64] uint4
+  const int ksteps = a.K / 16;
+  const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * ksteps) * 3 * 64 + lane;
+  const int64_t a_tile = (int64_t)ksteps * 3 * 64;   // uint4 stride between m-tiles
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float rb[8];
+  auto gload = [&](int k0) {
+    const bool second = DUAL && k0 >= K1;
+    const float* __restrict__ src = second ? xb2 + (int64_t)(k0 - K1 + 8 * st_g) * a.ldx2 : xb + (int64_t)(k0 + 8 * st_g) * a.ldx;
+    const int64_t ld = second ? a.ldx2 : a.ldx;
+    const bool keep = !(second || MASK) || (t0 + st_n < (second ? len2 : len));   // MaskedConv1d (jasper.py:113-118)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = src[(int64_t)e * ld];
+      rb[e] = keep ? v : 0.f;
+    }
+  };
+  auto sstore = [&](int buf) {
+    uint4 hi, mid, lo;
+    split3(rb, hi, mid, lo);
+    Bs[buf][0][st_g >> 1][st_g & 1][st_n] = hi;
+    Bs[buf][1][st_g >> 1][st_g & 1][st_n] = mid;
+    Bs[buf][2][st_g >> 1][st_g & 1][st_n] = lo;
+  };
+
+  uint4 af[TM][3], an[TM][3];
+  auto aload = [&](int s, uint4 (&dst)[TM][3]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)s * 3 + p) * 64];
+  };
+
+  const int nchunks = a.K / BKC;
+  gload(0);
+  aload(0, af);
+  sstore(0);
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) gload((c + 1) * BKC);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int gs = c * STEPS + s;
+      aload(gs + 1 < ksteps ? gs + 1 : gs, an);   // next k-step's weights (harmless re-read at the very end)
+      uint4 bf[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[j][p] = Bs[c & 1][p][s][kh][j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 t = acc[i][j];
+          t = mma(af[i][2], bf[j][0], t);   // lo  * hi
+          t = mma(af[i][0], bf[j][2], t);   // hi  * lo
+          t = mma(af[i][1], bf[j][1], t);   // mid * mid
+          t = mma(af[i][1], bf[j][0], t);   // mid * hi
+          t = mma(af[i][0], bf[j][1], t);   // hi  * mid
+          t = mma(af[i][0], bf[j][0], t);   // hi  * hi
+          acc[i][j] = t;
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
+    }
+    if (c + 1 < nchunks) {
+      sstore((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
+  const bool full = (t0 + BN <= a.store_cols) && (m0 + BM <= a.m_store);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mq = m0 + wm + i * 32 + 8 * q + 4 * kh;
+      const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq);
+      const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = mq + rr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = t0 + j * 32 + l31;
+          float v = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
+          if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
+          if (a.relu & 1) v = fmaxf(v, 0.f);
+          if (full || (t < a.store_cols && m < a.m_store)) a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TM>
+void launch_t(const PwArgs& a, hipStream_t st) {
+  const int blocks_m = a.M / (256 * TM);
+  const int tiles_t = (int)((a.ldx + BN - 1) / BN);
+  const int n_blocks = blocks_m * tiles_t * a.batch;
+  dim3 grid(n_blocks), block(512);
+  const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
+  if (dual) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask && res) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (res) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+}
+
+inline unsigned short bf16_rne(float x, float* back) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  *back = __builtin_bit_cast(float, u);
+  return (unsigned short)(u >> 16);
+}
+
+}  // namespace
+
+bool pointwise_bf16x3_supported(int M, int K, int K1) {
+  return M % 256 == 0 && K % BKC == 0 && (K1 == 0 || K1 % BKC == 0);
+}
+
+void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st) {
+  if (a.M % 512 == 0) launch_t<2>(a, st);
+  else launch_t<1>(a, st);
+}
+
+// [cout][cin] row-major fp32 -> [m_pad/32][cin/16][3 planes][64 lanes][8] bf16 bit patterns:
+//   lane (l31, kh), element e  <-  plane_p( W[mt*32 + l31][s*16 + 8*kh + e] )
+void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out) {
+  const int ksteps = cin / 16;
+  for (int mt = 0; mt < m_pad / 32; ++mt)
+    for (int s = 0; s < ksteps; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int m = mt * 32 + (lane & 31), k = s * 16 + 8 * (lane >> 5) + e;
+          const float x = m < cout ? w[(size_t)m * cin + k] : 0.f;
+          float hf, mf, lf;
+          const unsigned short h = bf16_rne(x, &hf);
+          const unsigned short mi = bf16_rne(x - hf, &mf);
+          const unsigned short lo = bf16_rne((x - hf) - mf, &lf);
+          const size_t base = (((size_t)mt * ksteps + s) * 3) * 64 * 8 + (size_t)lane * 8 + e;
+          out[base] = h;
+          out[base + 64 * 8] = mi;
+          out[base + 2 * 64 * 8] = lo;
+        }
+}
+
+}  // namespace vasr

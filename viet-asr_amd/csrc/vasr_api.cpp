@@ -44,7 +44,8 @@ struct HostTensor {
 struct ConvLayer {
   int cin = 0, cout = 0, kernel = 1, stride = 1, dilation = 1, pad = 0;
   int m_pad = 0;             // pointwise: rows of the packed weight (multiple of 128)
-  float* d_w = nullptr;      // depthwise [C][K]; pointwise K-major [cin][m_pad]
+  float* d_w = nullptr;      // depthwise [C][K]; pointwise: MFMA A-fragment order (fp32)
+  unsigned short* d_w3 = nullptr;  // pointwise: 3 x bf16 split fragments (encoder_pw_bf16x3.hip), when the shape allows
   float* d_scale = nullptr;  // [m_pad]
   float* d_shift = nullptr;  // [m_pad]
   int step = -1;             // index in the MaskedConv1d length chain
@@ -93,6 +94,8 @@ struct vasr_handle {
   bool slice_ready = false;
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
+  // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16
+  int gemm_mode = getenv("VASR_GEMM") && !strcmp(getenv("VASR_GEMM"), "bf16x3") ? 1 : 0;
   bool profiling = false;
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;
@@ -199,6 +202,11 @@ int pack_fused_residual(vasr_handle* h, const std::string& w1_key, const std::st
   std::vector<float> wt((size_t)K * L->m_pad, 0.f), sc(L->m_pad, 1.f), sh(L->m_pad, 0.f);
   pack_pointwise_weights(w.data(), cout, K, L->m_pad, wt.data());
   for (int m = 0; m < cout; ++m) sh[m] = b1[m] + b2[m];
+  if (pointwise_bf16x3_supported(L->m_pad, K, k1)) {
+    std::vector<unsigned short> w3((size_t)K * L->m_pad * 3);
+    pack_pointwise_weights_bf16x3(w.data(), cout, K, L->m_pad, w3.data());
+    if ((rc = upload(h, w3, &L->d_w3))) return rc;
+  }
   if ((rc = upload(h, wt, &L->d_w)) || (rc = upload(h, sc, &L->d_scale))) return rc;
   return upload(h, sh, &L->d_shift);
 }
@@ -214,6 +222,11 @@ int pack_pointwise(vasr_handle* h, const std::string& key, int cout, int cin, Co
   L->m_pad = (int)align_up(cout, 128);
   std::vector<float> wt((size_t)cin * L->m_pad, 0.f);
   pack_pointwise_weights(w->data.data(), cout, cin, L->m_pad, wt.data());
+  if (pointwise_bf16x3_supported(L->m_pad, cin, 0)) {
+    std::vector<unsigned short> w3((size_t)cin * L->m_pad * 3);
+    pack_pointwise_weights_bf16x3(w->data.data(), cout, cin, L->m_pad, w3.data());
+    if ((rc = upload(h, w3, &L->d_w3))) return rc;
+  }
   return upload(h, wt, &L->d_w);
 }
 
@@ -417,6 +430,17 @@ int check_launch(const char* what) {
   return 0;
 }
 
+// GEMM dispatch: exact-fp32 MFMA kernel, or the 3 x bf16 split kernel when selected and the layer has that pack.
+static void run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStream_t st) {
+  if (h->gemm_mode == 1 && W.d_w3) {
+    a.wt = reinterpret_cast<const float*>(W.d_w3);
+    launch_pointwise_bf16x3(a, st);
+  } else {
+    a.wt = W.d_w;
+    launch_pointwise(a, st);
+  }
+}
+
 // Encoder over an input [B][feat_in][x_ld]; writes [B][c_last][out_ld] (T1 valid frames).
 int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const int64_t* seq, int batch,
                 float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st) {
@@ -447,7 +471,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
       a.m_store = B.res.m_pad; a.relu = 0;
       ProfScope ps(h, kProfPointwise, st);
-      launch_pointwise(a, st);
+      run_pointwise(h, a, B.res, st);
     }
     int flip = 0;
     for (size_t r = 0; r < B.subs.size(); ++r) {
@@ -483,7 +507,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
       {
         ProfScope ps(h, kProfPointwise, st);
-        launch_pointwise(a, st);
+        run_pointwise(h, a, W, st);
       }
       cur = dst; cur_ld = dst_ld; cur_T = g_T;
     }
@@ -803,6 +827,12 @@ int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in,
   launch_resample(d_in, ld_in, d_len_in, batch, d_table, nwin, num_table, ratio, d_out, ld_out, d_len_out,
                   static_cast<hipStream_t>(stream));
   return check_launch("resample");
+}
+
+int vasr_set_gemm_mode(vasr_handle* h, int mode) {
+  if (!h || mode < 0 || mode > 1) return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA) or 1 (3 x bf16 split)");
+  h->gemm_mode = mode;
+  return 0;
 }
 
 int vasr_set_slices(vasr_handle* h, int slices) {

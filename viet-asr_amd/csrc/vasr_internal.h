@@ -67,6 +67,11 @@ void launch_pointwise(const PwArgs& a, hipStream_t st);
 // host: [cout][cin] row-major -> fragment order [m_pad/32][cin/8][64][4] (zero rows past cout)
 void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float* out);
 
+// 3 x bf16 split variant (encoder_pw_bf16x3.hip): same PwArgs, a.wt points at the bf16 fragment pack
+bool pointwise_bf16x3_supported(int M, int K, int K1);
+void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st);
+void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out);
+
 // ---- CTC head / decode (decode.hip) ----
 // logits [B][ldm rows][ld] (row v, column t) -> logp [B][T][V] (optional), pred [B][T] (optional)
 void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
