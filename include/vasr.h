@@ -217,6 +217,11 @@ int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h
 int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
                          int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 
+/* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
+int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);
+int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
+                                int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

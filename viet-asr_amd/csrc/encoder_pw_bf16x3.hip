@@ -12,7 +12,10 @@
 //   * weights are split and packed at vasr_finalize() in A-fragment order [M/32][K/16][3 planes][64 lanes][8 bf16]:
 //     one 16-byte load per lane, plane and 16-deep k-step, straight from L2, one step ahead of use;
 //   * activations are split ONCE per workgroup while they are staged into LDS (v_cvt_pk_bf16_f32), laid out
-//     [plane][k-step][k-half][column][8 bf16] so that every B fragment is one conflict-free ds_read_b128.
+//     [plane][k-step][k-half][column][8 bf16] so that every B fragment is one conflict-free ds_read_b128;
+//   * tile 512 x 128 (8 wavefronts, two 32-row m-tiles each, every wave owning all 128 columns, 128 accumulator
+//     registers): a weight fragment is reused for 24 MFMAs, which keeps the weight stream from L2 at 8 TB/s instead
+//     of 17 TB/s at full MFMA rate; one workgroup per CU, up to 256 VGPRs per lane.
 #include <cstdlib>
 #include <cstring>
 
@@ -28,9 +31,10 @@ using v2f = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
-constexpr int BN = 64;    // time columns per workgroup
-constexpr int BKC = 64;   // K rows per LDS buffer (3 planes x 64 x 64 x 2 B = 24 KB)
+constexpr int BN = 128;   // time columns per workgroup (4 MFMA n-tiles, all owned by every wave)
+constexpr int BKC = 64;   // K rows per LDS buffer (3 planes x 64 x 128 x 2 B = 48 KB; two buffers)
 constexpr int STEPS = BKC / 16;
+constexpr int TN = BN / 32;
 
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
   const v2f v = {a, b};
@@ -58,11 +62,20 @@ __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// 8 waves stacked along M, each TM m-tiles (32 rows) x 2 n-tiles (32 columns): workgroup tile (256*TM) x 64
+// 8 wavefronts stacked along M, each TM m-tiles (32 rows) x all 4 n-tiles (128 columns): workgroup tile (256*TM) x 128,
+// one workgroup per CU with the whole 512-entry register file split between its 2 waves per SIMD (accumulators 64*TM,
+// two weight-fragment sets in flight, double-buffered activation fragments).  A weight fragment (3 planes, 48 B per
+// lane) is fetched once per k-step and reused for 24 MFMAs; activations are split once per workgroup into LDS.
 template <int TM, bool MASK, bool RES, bool DUAL>
-__global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+__global__ __launch_bounds__(512, 2) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
   constexpr int BM = 256 * TM;
-  __shared__ uint4 Bs[2][3][STEPS][2][BN];
+  constexpr int NT = 512;                     // threads
+  constexpr int PATCHES = BKC / 8 * BN;       // 1024 staging patches (8 k-rows x 1 column) per chunk
+  constexpr int PPT = PATCHES / NT;           // 2 patches per thread
+  extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][3][STEPS][2][BN]
+  auto bs = [&](int buf, int plane, int s, int kb, int n) -> uint4& {
+    return Bs[(((buf * 3 + plane) * STEPS + s) * 2 + kb) * BN + n];
+  };
 
   int bid = blockIdx.x;
   {
@@ -82,50 +95,63 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
   const int len = MASK ? a.lens[b] : 0;
   const int len2 = DUAL ? a.lens2[b] : 0;
 
-  // staging: thread -> (8 consecutive k rows, one column)
-  const int st_n = tid % BN, st_g = tid / BN;   // st_g in [0, 8): k rows 8*st_g .. 8*st_g+7 of the chunk
   const int K1 = DUAL ? a.K1 : a.K;
-  const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0 + st_n;
-  const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 + st_n : nullptr;
+  const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0;
+  const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 : nullptr;
   // A fragments [M/32][K/16][3][64] uint4
   const int ksteps = a.K / 16;
   const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * ksteps) * 3 * 64 + lane;
   const int64_t a_tile = (int64_t)ksteps * 3 * 64;   // uint4 stride between m-tiles
 
-  f32x16 acc[TM][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float rb[8];
+  // staging: patch p of this thread -> (8 consecutive k rows, one column)
+  float rb[PPT][8];
   auto gload = [&](int k0) {
     const bool second = DUAL && k0 >= K1;
-    const float* __restrict__ src = second ? xb2 + (int64_t)(k0 - K1 + 8 * st_g) * a.ldx2 : xb + (int64_t)(k0 + 8 * st_g) * a.ldx;
+    const float* __restrict__ base = second ? xb2 + (int64_t)(k0 - K1) * a.ldx2 : xb + (int64_t)k0 * a.ldx;
     const int64_t ld = second ? a.ldx2 : a.ldx;
-    const bool keep = !(second || MASK) || (t0 + st_n < (second ? len2 : len));   // MaskedConv1d (jasper.py:113-118)
+    const int ml = second ? len2 : len;
+    const bool masked = second || MASK;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = src[(int64_t)e * ld];
-      rb[e] = keep ? v : 0.f;
+    for (int p = 0; p < PPT; ++p) {
+      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
+      const bool keep = !masked || (t0 + n < ml);   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118)
+      const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = src[(int64_t)e * ld];
+        rb[p][e] = keep ? v : 0.f;
+      }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore_patch = [&](int buf, int p) {
+    const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
     uint4 hi, mid, lo;
-    split3(rb, hi, mid, lo);
-    Bs[buf][0][st_g >> 1][st_g & 1][st_n] = hi;
-    Bs[buf][1][st_g >> 1][st_g & 1][st_n] = mid;
-    Bs[buf][2][st_g >> 1][st_g & 1][st_n] = lo;
+    split3(rb[p], hi, mid, lo);
+    bs(buf, 0, g >> 1, g & 1, n) = hi;
+    bs(buf, 1, g >> 1, g & 1, n) = mid;
+    bs(buf, 2, g >> 1, g & 1, n) = lo;
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) sstore_patch(buf, p);
   };
 
+  // weights: the next k-step's fragments are in flight while the current ones are multiplied
   uint4 af[TM][3], an[TM][3];
   auto aload = [&](int s, uint4 (&dst)[TM][3]) {
+    const int sc = s < ksteps ? s : ksteps - 1;   // harmless re-read past the end
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)s * 3 + p) * 64];
+      for (int p = 0; p < 3; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * 3 + p) * 64];
   };
 
   const int nchunks = a.K / BKC;
@@ -138,33 +164,36 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
     if (c + 1 < nchunks) gload((c + 1) * BKC);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      const int gs = c * STEPS + s;
-      aload(gs + 1 < ksteps ? gs + 1 : gs, an);   // next k-step's weights (harmless re-read at the very end)
-      uint4 bf[2][3];
+      aload(c * STEPS + s + 1, an);
+      uint4 bf[2][3];   // activation fragments of n-tile j (current) and j+1 (being read)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, s, kh, l31);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[j][p] = Bs[c & 1][p][s][kh][j * 32 + l31];
+      for (int j = 0; j < TN; ++j) {
+        if (j + 1 < TN) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+        }
+        const uint4 bh = bf[j & 1][0], bm = bf[j & 1][1], bl = bf[j & 1][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int i = 0; i < TM; ++i) {
           f32x16 t = acc[i][j];
-          t = mma(af[i][2], bf[j][0], t);   // lo  * hi
-          t = mma(af[i][0], bf[j][2], t);   // hi  * lo
-          t = mma(af[i][1], bf[j][1], t);   // mid * mid
-          t = mma(af[i][1], bf[j][0], t);   // mid * hi
-          t = mma(af[i][0], bf[j][1], t);   // hi  * mid
-          t = mma(af[i][0], bf[j][0], t);   // hi  * hi
+          t = mma(af[i][2], bh, t);   // lo  * hi
+          t = mma(af[i][0], bl, t);   // hi  * lo
+          t = mma(af[i][1], bm, t);   // mid * mid
+          t = mma(af[i][1], bh, t);   // mid * hi
+          t = mma(af[i][0], bm, t);   // hi  * mid
+          t = mma(af[i][0], bh, t);   // hi  * hi
           acc[i][j] = t;
         }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
     }
     if (c + 1 < nchunks) {
-      sstore((c + 1) & 1);
+      sstore((c + 1) & 1);   // (interleaving this with the MFMAs above measured no gain)
       __syncthreads();
     }
   }
@@ -182,7 +211,7 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
       for (int rr = 0; rr < 4; ++rr) {
         const int m = mq + rr;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
           const int t = t0 + j * 32 + l31;
           float v = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
           if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
@@ -194,18 +223,30 @@ __global__ __launch_bounds__(512, 4) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
   }
 }
 
-template <int TM>
-void launch_t(const PwArgs& a, hipStream_t st) {
+constexpr size_t kLdsBytes = (size_t)2 * 3 * STEPS * 2 * BN * sizeof(uint4);   // 96 KB
+
+template <int TM, bool MASK, bool RES, bool DUAL>
+void launch_k(const PwArgs& a, hipStream_t st) {
   const int blocks_m = a.M / (256 * TM);
   const int tiles_t = (int)((a.ldx + BN - 1) / BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
-  dim3 grid(n_blocks), block(512);
+  auto kern = pw_gemm_bf16x3_kernel<TM, MASK, RES, DUAL>;
+  static bool once = [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), kLdsBytes, st, a, blocks_m, tiles_t, n_blocks);
+}
+
+template <int TM>
+void launch_t(const PwArgs& a, hipStream_t st) {
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask && res) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (res) hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else hipLaunchKernelGGL((pw_gemm_bf16x3_kernel<TM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  if (dual) launch_k<TM, false, false, true>(a, st);
+  else if (mask && res) launch_k<TM, true, true, false>(a, st);
+  else if (mask) launch_k<TM, true, false, false>(a, st);
+  else if (res) launch_k<TM, false, true, false>(a, st);
+  else launch_k<TM, false, false, false>(a, st);
 }
 
 inline unsigned short bf16_rne(float x, float* back) {
@@ -222,8 +263,8 @@ bool pointwise_bf16x3_supported(int M, int K, int K1) {
 }
 
 void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st) {
-  if (a.M % 512 == 0) launch_t<2>(a, st);
-  else launch_t<1>(a, st);
+  if (a.M % 512 == 0) launch_t<2>(a, st);   // 512 x 128 tile
+  else launch_t<1>(a, st);                  // 256 x 128 tile
 }
 
 // [cout][cin] row-major fp32 -> [m_pad/32][cin/16][3 planes][64 lanes][8] bf16 bit patterns:

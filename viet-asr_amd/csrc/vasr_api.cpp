@@ -977,4 +977,23 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   return check_launch("bench_pointwise");
 }
 
+int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out) {
+  if (!h_w || !h_out || cout <= 0 || cin % 16 || m_pad % 32 || m_pad < cout) return fail(VASR_ERR_INVALID, "bad argument");
+  pack_pointwise_weights_bf16x3(h_w, cout, cin, m_pad, h_out);
+  return 0;
+}
+
+int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
+                                int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
+  if (!d_x || !d_w3 || !d_scale || !d_shift || !d_y || !pointwise_bf16x3_supported(cout, cin, 0))
+    return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(frames);
+  PwArgs a{};
+  a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
+  a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
+  launch_pointwise_bf16x3(a, static_cast<hipStream_t>(stream));
+  return check_launch("bench_pointwise_bf16x3");
+}
+
 }  // extern "C"
