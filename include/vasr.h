@@ -142,10 +142,12 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
                                vasr_stream stream);
 
 /* GEMM arithmetic of the 1x1 convolutions of the encoder:
- *   0 (default)  v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;
- *   1            every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
- *                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error < one fp32 rounding; 2.67x less
- *                matrix time).  Layers whose shape the split kernel does not cover keep mode 0. */
+ *   0            v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;
+ *   1 (default)  every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
+ *                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error < one fp32 rounding, measured
+ *                error against fp64 not larger than mode 0's; 2.67x less matrix time).  Layers whose shape the
+ *                split kernel does not cover (the CTC head) keep mode 0.
+ * The environment variable VASR_GEMM=fp32 / bf16x3 sets the initial mode of new handles. */
 int vasr_set_gemm_mode(vasr_handle* h, int mode);
 
 /* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */

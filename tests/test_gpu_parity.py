@@ -14,15 +14,17 @@ MEL_TOL = 2e-4
 LOGP_TOL = 2e-3
 
 
-def _engine(cfg, enc_sd, dec_sd):
+def _engine(cfg, enc_sd, dec_sd, gemm=None):
     from viet_asr_amd.engine import QuartzNetCTC
-    return QuartzNetCTC(cfg, enc_sd, dec_sd)
+    return QuartzNetCTC(cfg, enc_sd, dec_sd, gemm=gemm)
 
 
+@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_fused_path_matches_reference_goldens(gpu, name):
+def test_fused_path_matches_reference_goldens(gpu, name, gemm):
+    """Both GEMM arithmetics (3 x bf16 split operands = default, exact-fp32 MFMA) against the reference goldens."""
     g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
-    eng = _engine(cfg, enc_sd, dec_sd)
+    eng = _engine(cfg, enc_sd, dec_sd, gemm)
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
     torch.cuda.synchronize()
     logp = r["logp"].cpu().numpy()
@@ -193,6 +195,33 @@ def test_vietasr_class_end_to_end(gpu, tmp_path):
     assert isinstance(out, str)
     with pytest.raises(AssertionError):
         VietASR("quartznet12x1_vi", str(tmp_path / "missing.pt"), dec_p)
+
+
+def test_split_bf16_gemm_is_as_accurate_as_fp32_mfma(gpu):
+    """Isolated 1x1-conv GEMM (512 -> 512 channels) against an fp64 reference: the 3 x bf16 split must not be less
+    accurate than the exact-fp32 MFMA chain, and the two must agree to fp32 round-off."""
+    from viet_asr_amd import _lib
+    L = _lib.lib()
+    B, T, cin, cout = 2, 300, 512, 512
+    ld = int(L.vasr_padded_frames(T))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, cin, ld, generator=g).to(gpu)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).contiguous()
+    sc, sh = torch.ones(cout, device=gpu), torch.zeros(cout, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    pk = torch.empty(cout * cin)
+    _lib.check(L.vasr_pack_pointwise(w.data_ptr(), cout, cin, cout, pk.data_ptr()))
+    pk3 = torch.empty(cout * cin * 3, dtype=torch.int16)
+    _lib.check(L.vasr_pack_pointwise_bf16x3(w.data_ptr(), cout, cin, cout, pk3.data_ptr()))
+    y32, y3 = torch.empty(B, cout, ld, device=gpu), torch.empty(B, cout, ld, device=gpu)
+    w32, w3 = pk.to(gpu), pk3.to(gpu)
+    _lib.check(L.vasr_bench_pointwise(x.data_ptr(), w32.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y32.data_ptr(), st))
+    _lib.check(L.vasr_bench_pointwise_bf16x3(x.data_ptr(), w3.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y3.data_ptr(), st))
+    ref = torch.relu(torch.einsum("mk,bkt->bmt", w.double().to(gpu), x[:, :, :T].double()))
+    e32 = float((y32[:, :, :T].double() - ref).abs().max())
+    e3 = float((y3[:, :, :T].double() - ref).abs().max())
+    assert e32 < 1e-5 and e3 < 1e-5 and e3 <= 1.5 * e32 + 1e-7, (e32, e3)
+    assert float((y3[:, :, :T] - y32[:, :, :T]).abs().max()) < 1e-5
 
 
 def test_long_clips_config5_shape(gpu):

@@ -95,7 +95,9 @@ struct vasr_handle {
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16
-  int gemm_mode = getenv("VASR_GEMM") && !strcmp(getenv("VASR_GEMM"), "bf16x3") ? 1 : 0;
+  // Default 1: measured max error against fp64 is slightly LOWER than mode 0's (tools/kscan.py: 3.6e-6 vs 4.7e-6 at
+  // K=512) and every parity test passes unchanged, at 1.6x the GEMM throughput.  VASR_GEMM=fp32 selects mode 0.
+  int gemm_mode = getenv("VASR_GEMM") && !strcmp(getenv("VASR_GEMM"), "fp32") ? 0 : 1;
   bool profiling = false;
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;

@@ -39,7 +39,8 @@ def blocks_from_config(jasper_cfg):
 
 
 class QuartzNetCTC:
-    def __init__(self, model_definition, encoder_state, decoder_state, device="cuda:0"):
+    def __init__(self, model_definition, encoder_state, decoder_state, device="cuda:0", gemm=None):
+        """gemm: None (library default: "bf16x3"), "bf16x3" or "fp32" -- see vasr_set_gemm_mode in include/vasr.h."""
         _require_gpu()
         self.device = torch.device(device)
         self.labels = list(model_definition["labels"])
@@ -57,6 +58,8 @@ class QuartzNetCTC:
             self.handle.load_state_dict(encoder_state)
             self.handle.load_state_dict(decoder_state)
             self.handle.finalize()
+            if gemm is not None:
+                self.handle.set_gemm_mode(gemm)
         self._ws = None
 
     # -- shapes
