@@ -175,17 +175,19 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
           for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
         }
         const uint4 bh = bf[j & 1][0], bm = bf[j & 1][1], bl = bf[j & 1][2];
+        // six cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          f32x16 t = acc[i][j];
-          t = mma(af[i][2], bh, t);   // lo  * hi
-          t = mma(af[i][0], bl, t);   // hi  * lo
-          t = mma(af[i][1], bm, t);   // mid * mid
-          t = mma(af[i][1], bh, t);   // mid * hi
-          t = mma(af[i][0], bm, t);   // hi  * mid
-          t = mma(af[i][0], bh, t);   // hi  * hi
-          acc[i][j] = t;
-        }
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][2], bh, acc[i][j]);   // lo  * hi
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bl, acc[i][j]);   // hi  * lo
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bm, acc[i][j]);   // mid * mid
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bh, acc[i][j]);   // mid * hi
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bm, acc[i][j]);   // hi  * mid
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bh, acc[i][j]);   // hi  * hi
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
