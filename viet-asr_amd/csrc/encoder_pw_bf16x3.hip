@@ -1,6 +1,6 @@
 // Pointwise (1x1) convolution GEMM on the bf16 matrix pipe with fp32-equivalent accuracy ("3 x bf16" operands).
 //
-// Same operation, tiling, epilogue and dual-source K reduction as encoder_pw.hip (reference
+// Same operation, epilogue and dual-source K reduction as encoder_pw.hip (reference
 // nemo/collections/asr/parts/jasper.py:113-132, :374-392, :428-448), but every fp32 operand is split exactly into
 // three bf16 terms  x = x_hi + x_mid + x_lo  (round-to-nearest each: 8 + 8 + 8 significant bits = the 24 of fp32)
 // and the product is evaluated with the six largest cross terms
@@ -13,9 +13,11 @@
 //     one 16-byte load per lane, plane and 16-deep k-step, straight from L2, one step ahead of use;
 //   * activations are split ONCE per workgroup while they are staged into LDS (v_cvt_pk_bf16_f32), laid out
 //     [plane][k-step][k-half][column][8 bf16] so that every B fragment is one conflict-free ds_read_b128;
-//   * tile 512 x 128 (8 wavefronts, two 32-row m-tiles each, every wave owning all 128 columns, 128 accumulator
-//     registers): a weight fragment is reused for 24 MFMAs, which keeps the weight stream from L2 at 8 TB/s instead
-//     of 17 TB/s at full MFMA rate; one workgroup per CU, up to 256 VGPRs per lane.
+//   * throughput tile 512 x 128 (8 wavefronts, two 32-row m-tiles each, every wave owning all 128 columns, 128
+//     accumulator registers, one workgroup per CU): a weight fragment is reused for 24 MFMAs, which keeps the weight
+//     stream from L2 at 8 TB/s instead of 17 TB/s at full MFMA rate;
+//   * latency tile 64 x 32 (2 wavefronts) for small batches, where the throughput tile would leave most of the
+//     256 CUs idle (B = 1: 4 workgroups per layer instead of 128).
 #include <cstdlib>
 #include <cstring>
 
@@ -31,10 +33,8 @@ using v2f = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
-constexpr int BN = 128;   // time columns per workgroup (4 MFMA n-tiles, all owned by every wave)
-constexpr int BKC = 64;   // K rows per LDS buffer (3 planes x 64 x 128 x 2 B = 48 KB; two buffers)
+constexpr int BKC = 64;   // K rows per LDS buffer
 constexpr int STEPS = BKC / 16;
-constexpr int TN = BN / 32;
 
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
   const v2f v = {a, b};
@@ -62,16 +62,23 @@ __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// 8 wavefronts stacked along M, each TM m-tiles (32 rows) x all 4 n-tiles (128 columns): workgroup tile (256*TM) x 128,
-// one workgroup per CU with the whole 512-entry register file split between its 2 waves per SIMD (accumulators 64*TM,
-// two weight-fragment sets in flight, double-buffered activation fragments).  A weight fragment (3 planes, 48 B per
-// lane) is fetched once per k-step and reused for 24 MFMAs; activations are split once per workgroup into LDS.
-template <int TM, bool MASK, bool RES, bool DUAL>
-__global__ __launch_bounds__(512, 2) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
-  constexpr int BM = 256 * TM;
-  constexpr int NT = 512;                     // threads
-  constexpr int PATCHES = BKC / 8 * BN;       // 1024 staging patches (8 k-rows x 1 column) per chunk
-  constexpr int PPT = PATCHES / NT;           // 2 patches per thread
+// NW wavefronts stacked along M, each TM m-tiles (32 rows) x all TN n-tiles (32 columns each):
+// workgroup tile (32*TM*NW) x (32*TN).
+template <int NW, int TM, int TN>
+struct Geom {
+  static constexpr int BM = 32 * TM * NW;
+  static constexpr int BN = 32 * TN;
+  static constexpr int NT = 64 * NW;                   // threads
+  static constexpr int PATCHES = BKC / 8 * BN;         // staging patches (8 k-rows x 1 column) per chunk
+  static constexpr int PPT = PATCHES / NT;             // patches per thread (2 for every instantiated shape)
+  static constexpr size_t LDS = (size_t)2 * 3 * STEPS * 2 * BN * sizeof(uint4);
+  static_assert(PATCHES % NT == 0 && PPT >= 1, "staging patches must divide evenly over the threads");
+};
+
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL>
+__global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+  using G = Geom<NW, TM, TN>;
+  constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT;
   extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][3][STEPS][2][BN]
   auto bs = [&](int buf, int plane, int s, int kb, int n) -> uint4& {
     return Bs[(((buf * 3 + plane) * STEPS + s) * 2 + kb) * BN + n];
@@ -131,17 +138,16 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
       }
     }
   };
-  auto sstore_patch = [&](int buf, int p) {
-    const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
-    uint4 hi, mid, lo;
-    split3(rb[p], hi, mid, lo);
-    bs(buf, 0, g >> 1, g & 1, n) = hi;
-    bs(buf, 1, g >> 1, g & 1, n) = mid;
-    bs(buf, 2, g >> 1, g & 1, n) = lo;
-  };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) sstore_patch(buf, p);
+    for (int p = 0; p < PPT; ++p) {
+      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
+      uint4 hi, mid, lo;
+      split3(rb[p], hi, mid, lo);
+      bs(buf, 0, g >> 1, g & 1, n) = hi;
+      bs(buf, 1, g >> 1, g & 1, n) = mid;
+      bs(buf, 2, g >> 1, g & 1, n) = lo;
+    }
   };
 
   // weights: the next k-step's fragments are in flight while the current ones are multiplied
@@ -225,30 +231,29 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_bf16x3_kernel(PwArgs a, int bl
   }
 }
 
-constexpr size_t kLdsBytes = (size_t)2 * 3 * STEPS * 2 * BN * sizeof(uint4);   // 96 KB
-
-template <int TM, bool MASK, bool RES, bool DUAL>
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL>
 void launch_k(const PwArgs& a, hipStream_t st) {
-  const int blocks_m = a.M / (256 * TM);
-  const int tiles_t = (int)((a.ldx + BN - 1) / BN);
+  using G = Geom<NW, TM, TN>;
+  const int blocks_m = a.M / G::BM;
+  const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
-  auto kern = pw_gemm_bf16x3_kernel<TM, MASK, RES, DUAL>;
+  auto kern = pw_gemm_bf16x3_kernel<NW, TM, TN, MASK, RES, DUAL>;
   static bool once = [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), kLdsBytes, st, a, blocks_m, tiles_t, n_blocks);
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
 }
 
-template <int TM>
+template <int NW, int TM, int TN>
 void launch_t(const PwArgs& a, hipStream_t st) {
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) launch_k<TM, false, false, true>(a, st);
-  else if (mask && res) launch_k<TM, true, true, false>(a, st);
-  else if (mask) launch_k<TM, true, false, false>(a, st);
-  else if (res) launch_k<TM, false, true, false>(a, st);
-  else launch_k<TM, false, false, false>(a, st);
+  if (dual) launch_k<NW, TM, TN, false, false, true>(a, st);
+  else if (mask && res) launch_k<NW, TM, TN, true, true, false>(a, st);
+  else if (mask) launch_k<NW, TM, TN, true, false, false>(a, st);
+  else if (res) launch_k<NW, TM, TN, false, true, false>(a, st);
+  else launch_k<NW, TM, TN, false, false, false>(a, st);
 }
 
 inline unsigned short bf16_rne(float x, float* back) {
@@ -265,8 +270,20 @@ bool pointwise_bf16x3_supported(int M, int K, int K1) {
 }
 
 void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st) {
-  if (a.M % 512 == 0) launch_t<2>(a, st);   // 512 x 128 tile
-  else launch_t<1>(a, st);                  // 256 x 128 tile
+  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..4 pins a tile shape
+  // the largest tile that still gives (almost) every one of the 256 CUs a workgroup: 512x128, 256x128, 128x64, 64x32
+  auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
+  int tile = 4;
+  if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
+  else if (blocks(256, 128) >= 192) tile = 2;
+  else if (blocks(128, 64) >= 192) tile = 3;
+  if (force >= 1 && force <= 4 && !(force == 1 && a.M % 512)) tile = force;
+  switch (tile) {
+    case 1: return launch_t<8, 2, 4>(a, st);
+    case 2: return launch_t<8, 1, 4>(a, st);
+    case 3: return launch_t<4, 1, 2>(a, st);
+    default: return launch_t<2, 1, 1>(a, st);
+  }
 }
 
 // [cout][cin] row-major fp32 -> [m_pad/32][cin/16][3 planes][64 lanes][8] bf16 bit patterns:
