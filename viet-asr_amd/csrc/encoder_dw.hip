@@ -165,6 +165,179 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
   }
 }
 
+// ---- utterance-pair variant ---------------------------------------------------------------------------------------
+// The kernel above is VALU-issue bound from K = 51 up (2.5 packed FMAs per tap and 4 outputs, because time-adjacent
+// output pairs only line up with even-aligned register pairs for every other tap).  Here the two halves of every
+// packed-fp32 operation are the SAME (channel, frame) of two different utterances b0 = 2*blockIdx.y and b0 + 1:
+//   * the LDS window holds pairs (x[b0][c][t], x[b0+1][c][t]); a pair is an aligned register pair for every tap, so
+//     a tap costs exactly one v_pk_fma_f32 per output pair -- 2.0 per tap and 4 outputs, nothing discarded;
+//   * both utterances share the channel's taps: K wave-uniform scalars, broadcast to both halves by op_sel;
+//   * every lane slides over 8 consecutive frames (K + 7 window pairs from LDS instead of 2 x (K + 3) samples), which
+//     also halves the LDS read traffic per output;
+//   * a lane's window starts 64 bytes after its neighbour's, which would be a 4-way bank conflict for ds_read_b128;
+//     the window is therefore stored with one pad quad after every 16 (quad L at L + L/16).  The pad position seen
+//     by a lane depends only on (lane & 3), so four pre-skewed base pointers keep every read an immediate offset.
+// Odd batch tail: the last utterance is paired with itself and stored once.
+template <int K, int DIL = 1>
+struct PairGeom {
+  static constexpr int PAD = DIL > 1 ? (DIL * K) / 2 - 1 : K / 2;   // get_same_padding (jasper.py:60-65)
+  static constexpr int PADL = (PAD + 3) & ~3;
+  static constexpr int OFF = PADL - PAD;
+  static constexpr int NP = OFF + DIL * (K - 1) + 8;                // pairs in one lane's register window
+  static constexpr int NQ = (NP + 1) / 2;                           // quads = 2 pairs = one ds_read_b128
+  static constexpr int NLD = (4 * 63 + NQ + 127) / 128;             // staging float4 per lane and utterance
+  static constexpr int QUADS = 128 * NLD;                           // logical quads staged per wavefront
+  static constexpr int PHYS = QUADS + QUADS / 16;                   // + one pad quad per 16
+  static constexpr int TB = 16;                                     // taps per software-pipeline block
+  static constexpr int NB = (K + TB - 1) / TB;
+  // one past the last quad that taps [0, min(K, TB*(blk+1))) touch
+  static constexpr int qend(int blk) {
+    const int klast = (K < TB * (blk + 1) ? K : TB * (blk + 1)) - 1;
+    return (OFF + DIL * klast + 7) / 2 + 1;
+  }
+};
+
+template <int K, int DIL = 1>
+__global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ w,
+                                                      const int32_t* __restrict__ lens_in,
+                                                      const int32_t* __restrict__ lens_out, int channels, int batch,
+                                                      float* __restrict__ y, int64_t ldy) {
+  using G = PairGeom<K, DIL>;
+  constexpr int NLD = G::NLD;
+  __shared__ v4f lds4[4 * G::PHYS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = blockIdx.x * 4 + wave;
+  const int b0 = 2 * blockIdx.y;
+  const bool twin = b0 + 1 < batch;
+  const int b1 = twin ? b0 + 1 : b0;
+  const int t_start = blockIdx.z * kTile;
+  v4f* win = lds4 + wave * G::PHYS;
+
+  // ---- staging: both rows, branch-free (clamped address + selects), all loads in flight together ----
+  const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
+  const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
+  v4f s0[NLD], s1[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+    int tc = t < 0 ? 0 : t;
+    tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
+    s0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
+    s1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+  }
+  const float* wg = w + (int64_t)c * K;
+  constexpr bool PIN = K <= 44;   // all taps resident in SGPRs; longer kernels stream them block by block
+  float wc[PIN ? K : 1];
+  if constexpr (PIN) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) wc[k] = wg[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" : "+s"(wc[k]));
+  }
+  const int len_in0 = lens_in[b0], len_in1 = lens_in[b1];
+  // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding.  t and PADL are
+  // multiples of 4, so a float4 is either entirely left of frame 0 or not at all.
+  auto masked = [&](v4f v, int t, int len) {
+    const int n = t < 0 ? 0 : len - t;
+    v.x = n > 0 ? v.x : 0.f;
+    v.y = n > 1 ? v.y : 0.f;
+    v.z = n > 2 ? v.z : 0.f;
+    v.w = n > 3 ? v.w : 0.f;
+    return v;
+  };
+  v4f* wr = win + 2 * lane + (lane >> 3);   // logical quad 2*(lane + 64 j) -> physical + 136 j
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+    const v4f a = masked(s0[j], t, len_in0), bq = masked(s1[j], t, len_in1);
+    const v4f q0 = {a.x, bq.x, a.y, bq.y}, q1 = {a.z, bq.z, a.w, bq.w};
+    wr[136 * j] = q0;
+    wr[136 * j + 1] = q1;
+  }
+  wave_sync();
+
+  // ---- sliding window: logical quad 4*lane + q lives at 4*lane + q + ((4*lane + q) >> 4) ----
+  const v4f* rb = win + 4 * lane + (lane >> 2);
+  const int u = lane & 3;
+  const v4f* pm[4] = {rb, rb + (u >= 3 ? 1 : 0), rb + (u >= 2 ? 1 : 0), rb + (u >= 1 ? 1 : 0)};
+  v2f xw[2 * G::NQ];
+  auto load_quads = [&](int qa, int qb) {
+#pragma unroll
+    for (int q = qa; q < qb; ++q) {
+      const v4f v = pm[(q & 15) >> 2][q + (q >> 4)];
+      xw[2 * q] = v.xy;
+      xw[2 * q + 1] = v.zw;
+    }
+  };
+  v2f acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = v2f{0.f, 0.f};
+
+  load_quads(0, G::qend(0));
+  float wn[PIN ? 1 : G::TB];
+  if constexpr (!PIN) {
+#pragma unroll
+    for (int k = 0; k < G::TB; ++k) wn[k] = wg[k < K ? k : K - 1];
+  }
+#pragma unroll
+  for (int blk = 0; blk < G::NB; ++blk) {
+    float wb[PIN ? 1 : G::TB];
+    if constexpr (!PIN) {
+#pragma unroll
+      for (int k = 0; k < G::TB; ++k) wb[k] = wn[k];
+      if (blk + 1 < G::NB) {
+        int off = G::TB * (blk + 1);
+        asm volatile("" : "+s"(off));   // opaque: keeps the compiler from hoisting every block's taps to the top
+#pragma unroll
+        for (int k = 0; k < G::TB; ++k) wn[k] = wg[off + (G::TB * (blk + 1) + k < K ? k : K - 1 - G::TB * (blk + 1))];
+      }
+    }
+    if (blk + 1 < G::NB) load_quads(G::qend(blk), G::qend(blk + 1));
+#pragma unroll
+    for (int k = G::TB * blk; k < G::TB * (blk + 1) && k < K; ++k) {
+      float wk;
+      if constexpr (PIN) wk = wc[k];
+      else wk = wb[k - G::TB * blk];
+      const v2f w2 = {wk, wk};
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = __builtin_elementwise_fma(w2, xw[G::OFF + DIL * k + r], acc[r]);
+    }
+    // anchor: without it LLVM sinks the whole FMA chain into the conditional store block below, which serialises
+    // "load the entire window" -> "all FMAs" and keeps every window register live
+#pragma unroll
+    for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(acc[r]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- store: the following 1x1 MaskedConv1d masks with lens_out, so frames past it are written as zeros ----
+  const int t = t_start + 8 * lane;
+  const int n0 = lens_out[b0] - t, n1 = lens_out[b1] - t;
+  float* y0 = y + ((int64_t)b0 * channels + c) * ldy + t;
+  float* y1 = y + ((int64_t)b1 * channels + c) * ldy + t;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (t + 4 * h < ldy) {
+      v4f o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = n0 > 4 * h + e ? acc[4 * h + e].x : 0.f;
+        o1[e] = n1 > 4 * h + e ? acc[4 * h + e].y : 0.f;
+      }
+      *reinterpret_cast<v4f*>(y0 + 4 * h) = o0;
+      if (twin) *reinterpret_cast<v4f*>(y1 + 4 * h) = o1;
+    }
+  }
+}
+
+template <int K, int DIL>
+void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
+                    int channels, float* y, int64_t ldy, hipStream_t st) {
+  dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
+  hipLaunchKernelGGL((dw_pair_kernel<K, DIL>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy);
+}
+
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
 // Used for the stride-2 prologue block (64 channels) and the dilated K=87 block.
 __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __restrict__ x, int64_t ldx,
@@ -245,6 +418,21 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
                       int pad, float* y, int64_t ldy, hipStream_t st) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  static const bool pair = !(getenv("VASR_DW_PAIR") && atoi(getenv("VASR_DW_PAIR")) == 0);
+  if (pair && aligned && stride == 1) {
+    if (dilation == 2 && kernel == 87 && pad == 86)
+      return launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+    if (dilation == 1 && pad == kernel / 2) {
+      switch (kernel) {
+        case 33: return launch_dw_pair<33, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        case 39: return launch_dw_pair<39, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        case 51: return launch_dw_pair<51, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        case 63: return launch_dw_pair<63, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        case 75: return launch_dw_pair<75, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        default: break;
+      }
+    }
+  }
   if (aligned && stride == 1 && dilation == 2 && kernel == 87 && pad == 86) {
     dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
     hipLaunchKernelGGL((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
