@@ -174,9 +174,11 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 //   * both utterances share the channel's taps: K wave-uniform scalars, broadcast to both halves by op_sel;
 //   * every lane slides over 8 consecutive frames (K + 7 window pairs from LDS instead of 2 x (K + 3) samples), which
 //     also halves the LDS read traffic per output;
-//   * a lane's window starts 64 bytes after its neighbour's, which would be a 4-way bank conflict for ds_read_b128;
-//     the window is therefore stored with one pad quad after every 16 (quad L at L + L/16).  The pad position seen
-//     by a lane depends only on (lane & 3), so four pre-skewed base pointers keep every read an immediate offset.
+//   * a lane's window starts 64 bytes (4 quads of 16 B) after its neighbour's, a 4-way bank conflict for
+//     ds_read_b128 (16 slots of 16 B, serviced in four 16-lane groups whose lane numbers cover every residue mod 16).
+//     The window is therefore stored with one pad quad after every 4 (quad L at L + L/4): lane l starts at slot 5 l,
+//     an odd stride, so the 16 lanes of a group always hit 16 different slots, and because 4 l is a multiple of 4
+//     the pad seen at window offset q is q/4 for every lane -- all reads stay immediate offsets from one base.
 // Odd batch tail: the last utterance is paired with itself and stored once.
 template <int K, int DIL = 1>
 struct PairGeom {
@@ -185,10 +187,12 @@ struct PairGeom {
   static constexpr int OFF = PADL - PAD;
   static constexpr int NP = OFF + DIL * (K - 1) + 8;                // pairs in one lane's register window
   static constexpr int NQ = (NP + 1) / 2;                           // quads = 2 pairs = one ds_read_b128
-  static constexpr int NLD = (4 * 63 + NQ + 127) / 128;             // staging float4 per lane and utterance
-  static constexpr int QUADS = 128 * NLD;                           // logical quads staged per wavefront
-  static constexpr int PHYS = QUADS + QUADS / 16;                   // + one pad quad per 16
-  static constexpr int TB = 16;                                     // taps per software-pipeline block
+  static constexpr int QNEED = 4 * 63 + NQ;                         // logical quads lane 63's window reaches
+  static constexpr int NLD = (QNEED + 127) / 128;                   // staging float4 per lane and utterance
+  static constexpr int LAST = (QNEED - 128 * (NLD - 1) + 1) / 2;    // lanes that take part in the last staging slab
+  static constexpr int QUADS = 128 * (NLD - 1) + 2 * (LAST < 64 ? LAST : 64);   // logical quads staged
+  static constexpr int PHYS = QUADS + QUADS / 4 + 1;                // + one pad quad per 4
+  static constexpr int TB = 8;                                      // taps per software-pipeline block
   static constexpr int NB = (K + TB - 1) / TB;
   // one past the last quad that taps [0, min(K, TB*(blk+1))) touch
   static constexpr int qend(int blk) {
@@ -197,7 +201,10 @@ struct PairGeom {
   }
 };
 
-template <int K, int DIL = 1>
+// grid (C/4, ceil(B/2), ceil(ldy/512)), block 256 = 4 wavefronts, one (channel, utterance pair, 512-frame tile) each.
+// (Walking several pairs per wavefront with the next pair's rows prefetched measured 5-15% slower than simply keeping
+// 6-7 short-lived wavefronts per SIMD resident, so there is no row loop.)
+template <int K, int DIL>
 __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
@@ -216,19 +223,26 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
   v4f* win = lds4 + wave * G::PHYS;
 
   // ---- staging: both rows, branch-free (clamped address + selects), all loads in flight together ----
-  const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
-  const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
+  // The last slab only reaches as far as lane 63's window: lanes past it neither load nor store.
   v4f s0[NLD], s1[NLD];
+  const bool in_last = G::LAST >= 64 || lane < G::LAST;
+  {
+    const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
+    const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
 #pragma unroll
-  for (int j = 0; j < NLD; ++j) {
-    const int t = t_start - G::PADL + 4 * (lane + 64 * j);
-    int tc = t < 0 ? 0 : t;
-    tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
-    s0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
-    s1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+    for (int j = 0; j < NLD; ++j) {
+      const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+      int tc = t < 0 ? 0 : t;
+      tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
+      if (j + 1 < NLD || in_last) {
+        s0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
+        s1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+      }
+    }
   }
   const float* wg = w + (int64_t)c * K;
-  constexpr bool PIN = K <= 44;   // all taps resident in SGPRs; longer kernels stream them block by block
+  // all taps resident in SGPRs; longer kernels stream them block by block
+  constexpr bool PIN = K <= 44;
   float wc[PIN ? K : 1];
   if constexpr (PIN) {
 #pragma unroll
@@ -236,7 +250,6 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < K; ++k) asm volatile("" : "+s"(wc[k]));
   }
-  const int len_in0 = lens_in[b0], len_in1 = lens_in[b1];
   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding.  t and PADL are
   // multiples of 4, so a float4 is either entirely left of frame 0 or not at all.
   auto masked = [&](v4f v, int t, int len) {
@@ -247,26 +260,28 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     v.w = n > 3 ? v.w : 0.f;
     return v;
   };
-  v4f* wr = win + 2 * lane + (lane >> 3);   // logical quad 2*(lane + 64 j) -> physical + 136 j
+  v4f* wr = win + 2 * lane + (lane >> 1);   // logical quads 2*(lane + 64 j), +1 -> physical (+ 160 j), +1
+  // sliding window: logical quad 4*lane + q lives at 4*lane + q + ((4*lane + q) >> 2) = 5*lane + q + (q >> 2)
+  const v4f* rb = win + 5 * lane;
+
+  const int len_in0 = lens_in[b0], len_in1 = lens_in[b1];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
     const int t = t_start - G::PADL + 4 * (lane + 64 * j);
     const v4f a = masked(s0[j], t, len_in0), bq = masked(s1[j], t, len_in1);
     const v4f q0 = {a.x, bq.x, a.y, bq.y}, q1 = {a.z, bq.z, a.w, bq.w};
-    wr[136 * j] = q0;
-    wr[136 * j + 1] = q1;
+    if (j + 1 < NLD || in_last) {
+      wr[160 * j] = q0;
+      wr[160 * j + 1] = q1;
+    }
   }
   wave_sync();
 
-  // ---- sliding window: logical quad 4*lane + q lives at 4*lane + q + ((4*lane + q) >> 4) ----
-  const v4f* rb = win + 4 * lane + (lane >> 2);
-  const int u = lane & 3;
-  const v4f* pm[4] = {rb, rb + (u >= 3 ? 1 : 0), rb + (u >= 2 ? 1 : 0), rb + (u >= 1 ? 1 : 0)};
   v2f xw[2 * G::NQ];
   auto load_quads = [&](int qa, int qb) {
 #pragma unroll
     for (int q = qa; q < qb; ++q) {
-      const v4f v = pm[(q & 15) >> 2][q + (q >> 4)];
+      const v4f v = rb[q + (q >> 2)];
       xw[2 * q] = v.xy;
       xw[2 * q + 1] = v.zw;
     }
@@ -335,7 +350,8 @@ template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
                     int channels, float* y, int64_t ldy, hipStream_t st) {
   dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
-  hipLaunchKernelGGL((dw_pair_kernel<K, DIL>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy);
+  static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
+  hipLaunchKernelGGL((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
