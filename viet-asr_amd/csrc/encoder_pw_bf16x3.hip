@@ -62,6 +62,13 @@ __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// orders a wavefront's own LDS writes and reads for the compiler (the LDS pipeline itself keeps them in issue order)
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // NW wavefronts stacked along M, each TM m-tiles (32 rows) x all TN n-tiles (32 columns each):
 // workgroup tile (32*TM*NW) x (32*TN).
 template <int NW, int TM, int TN>
@@ -119,29 +126,33 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging: patch p of this thread -> (8 consecutive k rows, one column)
+  // gload only issues the loads (no use of the values, so nothing waits on HBM there); the MaskedConv1d mask is
+  // applied when the chunk is converted, in sstore(buf, k0) with the same k0.
   float rb[PPT][8];
   auto gload = [&](int k0) {
     const bool second = DUAL && k0 >= K1;
     const float* __restrict__ base = second ? xb2 + (int64_t)(k0 - K1) * a.ldx2 : xb + (int64_t)k0 * a.ldx;
     const int64_t ld = second ? a.ldx2 : a.ldx;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
+      const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[p][e] = src[(int64_t)e * ld];
+    }
+  };
+  auto sstore = [&](int buf, int k0) {
+    const bool second = DUAL && k0 >= K1;
     const int ml = second ? len2 : len;
     const bool masked = second || MASK;
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
       const bool keep = !masked || (t0 + n < ml);   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118)
-      const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
+      if (masked) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = src[(int64_t)e * ld];
-        rb[p][e] = keep ? v : 0.f;
+        for (int e = 0; e < 8; ++e) rb[p][e] = keep ? rb[p][e] : 0.f;
       }
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
       uint4 hi, mid, lo;
       split3(rb[p], hi, mid, lo);
       bs(buf, 0, g >> 1, g & 1, n) = hi;
@@ -163,14 +174,24 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
   const int nchunks = a.K / BKC;
   gload(0);
   aload(0, af);
-  sstore(0);
+  sstore(0, 0);
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) gload((c + 1) * BKC);
+    // The next chunk's activations are requested unconditionally (the last chunk re-reads itself): a branch here
+    // would make the compiler merge the two paths' load counters and wait for these HBM loads (vmcnt(0)) before the
+    // first MFMA of every chunk.  They are issued behind the step-1 weight prefetch, because vmcnt retires in order
+    // and every later weight wait therefore also waits for them.
+    const int cn = c + 1 < nchunks ? c + 1 : c;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       aload(c * STEPS + s + 1, an);
+      if (s == 0) gload(cn * BKC);
+      // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
+      // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step, and the activation loads land
+      // next to sstore.  It also keeps sstore's conversion (which may overlap the last step's MFMAs) from moving
+      // further up, where its first instruction would wait for the HBM loads.
+      __builtin_amdgcn_sched_barrier(0);
       uint4 bf[2][3];   // activation fragments of n-tile j (current) and j+1 (being read)
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, s, kh, l31);
@@ -200,14 +221,50 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
     }
-    if (c + 1 < nchunks) {
-      sstore((c + 1) & 1);   // (interleaving this with the MFMAs above measured no gain)
-      __syncthreads();
-    }
+    // also unconditional (after the last chunk it refills the idle buffer): inside a branch LLVM sinks the global
+    // loads above down to this, their only use, and their whole HBM latency is exposed
+    sstore((c + 1) & 1, cn * BKC);
+    __syncthreads();
   }
 
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
+  if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
   const bool full = (t0 + BN <= a.store_cols) && (m0 + BM <= a.m_store);
+  const bool vec = full && ((a.ldy | a.ldr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
+  if (vec) {
+    // Interior tiles: the accumulators (one column, 16 scattered rows per lane) go through LDS, 8 rows x BN columns
+    // per pass in a wavefront-private buffer, and come back as float4 row pieces, so that a store instruction writes
+    // whole row segments (2 x 512 B for BN = 128) instead of 2 x 128 B dwords and the residual is read the same way.
+    // The 67 MB output of a 512-channel layer is otherwise store-issue bound (4.8 TB/s against ~7.5 TB/s for a fill).
+    float* stage = reinterpret_cast<float*>(Bs) + wave * (2 * 8 * BN);
+    constexpr int F4 = 8 * BN / 4 / 64;   // float4 pieces per lane and pass
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* buf = stage + ((i * 4 + q) & 1) * (8 * BN);
+        const int mq = m0 + wm + i * 32 + 8 * q;
+        const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq + 4 * kh);
+        const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq + 4 * kh);
+        wave_fence();   // LDS executes one wavefront's accesses in order: pass p+2's writes follow pass p's reads
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) buf[(4 * kh + rr) * BN + 32 * j + l31] = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < F4; ++k) {
+          const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
+          v4f v = *reinterpret_cast<const v4f*>(buf + row * BN + 4 * c4);
+          const int m = mq + row, t = t0 + 4 * c4;
+          if (RES) v += *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m) * a.ldr + t);
+          if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
+          *reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

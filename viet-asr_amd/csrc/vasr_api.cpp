@@ -993,7 +993,7 @@ int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const fl
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
   launch_pointwise_bf16x3(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise_bf16x3");
 }
