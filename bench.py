@@ -204,7 +204,7 @@ def main():
         dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
         default_workload = a.model == "quartznet15x5" and a.batch == 64 and a.seconds == 10.0 and not a.ragged
         pw_traffic, traffic_src = pmc_traffic("pw_gemm_bf16x3" if split else "pw_gemm_kernel") if default_workload else (None, None)
-        dw_traffic, _ = pmc_traffic("dw_conv_kernel") if default_workload else (None, None)
+        dw_traffic, _ = pmc_traffic("dw_pair_kernel") if default_workload else (None, None)
         out = {
             "metric": "real_time_factor", "value": round(audio_all * a.steps / elapsed, 1),
             "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -224,7 +224,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps},
-            "depthwise": {"kernel": "dw_conv_kernel<K>", "bound": "hbm", "achieved": round(dw_gbs, 1),
+            "depthwise": {"kernel": "dw_pair_kernel<K, DIL> (utterance-pair packed-FMA depthwise)", "bound": "hbm", "achieved": round(dw_gbs, 1),
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": dw_traffic,
                           "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
                           "launches_per_step": prof["depthwise"]["launches"] // a.steps},

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the .so: torch ships its 
 #                runtimes in the process and hipMalloc then reports "no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvasr_hip.so")
+LIB_PATH = os.environ.get("VASR_LIB_PATH") or os.path.join(_HERE, "lib", "libvasr_hip.so")   # override: dev builds
 
 
 class VasrError(RuntimeError):

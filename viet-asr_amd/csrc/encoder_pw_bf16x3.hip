@@ -34,6 +34,9 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
 constexpr int BKC = 64;   // K rows per LDS buffer
+#ifndef VASR_ABLATE
+#define VASR_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no weight reloads, 2 no LDS fragment reads,
+#endif                  // 4 no activation staging, 8 no per-chunk barrier
 constexpr int STEPS = BKC / 16;
 
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
     const int cn = c + 1 < nchunks ? c + 1 : c;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      aload(c * STEPS + s + 1, an);
-      if (s == 0) gload(cn * BKC);
+      if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
+      if (s == 0 && !(VASR_ABLATE & 4)) gload(cn * BKC);
       // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
       // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step, and the activation loads land
       // next to sstore.  It also keeps sstore's conversion (which may overlap the last step's MFMAs) from moving
@@ -194,12 +197,13 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
       __builtin_amdgcn_sched_barrier(0);
       uint4 bf[2][3];   // activation fragments of n-tile j (current) and j+1 (being read)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, s, kh, l31);
+      for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, (VASR_ABLATE & 2) ? 0 : s, kh, l31);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (j + 1 < TN) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+          for (int p = 0; p < 3; ++p)
+            bf[(j + 1) & 1][p] = (VASR_ABLATE & 2) ? bf[0][p] : bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
         }
         const uint4 bh = bf[j & 1][0], bm = bf[j & 1][1], bl = bf[j & 1][2];
         // six cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
     }
     // also unconditional (after the last chunk it refills the idle buffer): inside a branch LLVM sinks the global
     // loads above down to this, their only use, and their whole HBM latency is exposed
-    sstore((c + 1) & 1, cn * BKC);
-    __syncthreads();
+    if (!(VASR_ABLATE & 4)) sstore((c + 1) & 1, cn * BKC);
+    if (!(VASR_ABLATE & 8)) __syncthreads();
   }
 
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
