@@ -21,3 +21,25 @@ for bw in (16, 128):
     dt = (time.perf_counter() - t0) / 3
     print(f"beam_width {bw}: {dt*1e3:.1f} ms per batch of 64 x 501 frames; greedy-equal rows: "
           f"{sum(dec.decode_batch(logp[:4], bw)[i] == eng.texts(r['ids'][:4], r['id_len'][:4])[i] for i in range(4))}/4")
+
+# with an n-gram LM (BASELINE config 4 shape): synthetic vocabulary, unigrams + bigrams, written as ARPA text
+import tempfile
+from oracle import beam_oracle as BO
+rng = np.random.default_rng(4)
+letters = [c for c in cfg["labels"] if c.strip() and c != "'"]
+words = sorted({"".join(rng.choice(letters, rng.integers(2, 7))) for _ in range(3000)})
+ng = {("<s>",): (-99.0, -0.3), ("</s>",): (-1.5, 0.0), ("<unk>",): (-3.0, 0.0)}
+for w in words:
+    ng[(w,)] = (float(-2.0 - 2.0 * rng.random()), float(-0.4 * rng.random()))
+for _ in range(12000):
+    a, b2 = rng.choice(words, 2)
+    ng[(a, b2)] = (float(-0.5 - 2.0 * rng.random()), 0.0)
+path = os.path.join(tempfile.mkdtemp(), "synthetic.arpa")
+BO.write_arpa(path, 2, ng)
+dec = BeamSearchDecoder(cfg["labels"], lm_path=path, alpha=0.5, beta=1.5)
+for bw in (16, 128):
+    dec.decode_ids(logp, bw); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): dec.decode_ids(logp, bw)
+    torch.cuda.synchronize()
+    print(f"beam_width {bw} + 2-gram LM ({len(words)} words): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per batch of 64 x 501 frames")

@@ -4,21 +4,34 @@
 // hands exp(log_probs[0]) to pyctcdecode on the host, one utterance at a time.  pyctcdecode / kenlm are third-party
 // and absent (parity unpinned); the algorithm restated here is oracle/beam_oracle.py (file header there).
 //
-// One workgroup (256 threads) per utterance walks the frames; per frame
-//   1. candidate characters {c : logp >= token_min_logp} U {argmax}, capped so the merge table stays < 70 % full;
+// One workgroup (512 threads) per utterance walks the frames; per frame
+//   1. candidate characters {c : logp >= token_min_logp} U {argmax}, capped so the merge table stays < 70 % full:
+//      one wavefront, ballots only (bitwise threshold search when the cap bites);
 //   2. every (beam, character) pair is hashed -- key = hash(prefix string incl. committed spaces, last character) --
 //      into an LDS open-addressing table: identical prefixes MERGE by log-sum-exp (fp64 max via ordered-int
 //      atomicMax, then a 2^-44 fixed-point atomicAdd of exp(score - max): associative, hence deterministic);
-//   3. a word committed by ' ' is scored with the n-gram LM (hashed tables in HBM, back-off walk), partial words get
-//      pyctcdecode's OOV penalty; beams below max-10 are dropped; the top `beam_width` are kept by a 4-pass radix
-//      select on the ordered bits of the combined score (no sort);
-//   4. survivors are compacted (ballot/prefix scan) and a back-pointer row is written for the final trace-back.
+//   3. every thread pulls its own 4 table slots into registers; a word committed by ' ' is scored with the n-gram LM
+//      (hashed tables in HBM, back-off walk), partial words get pyctcdecode's OOV penalty; beams below max-10 are
+//      dropped; the top `beam_width` are kept by a radix select on the ordered bits of the combined score (8-bit
+//      digits, parallel bucket search, stops as soon as a bucket is taken whole; no sort);
+//   4. survivors publish (slot, merged logit) at their rank, the new beams are built one per thread and a
+//      back-pointer row is written for the final trace-back.
+// What the frame loop is bound by, and what the structure answers (measured with VASR_BEAM_PROF cycle counters):
+// dependent LDS round trips and barriers, not arithmetic.  Hence DPP scans instead of ds_bpermute shuffles, LDS-only
+// barriers (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() also waits for the back-pointer stores and the
+// log-prob prefetch), per-thread slots in registers between phases, and a loop body kept at 32 KB of code -- fully
+// unrolled it was 68 KB, more than the instruction cache two CUs share.  B = 64 x 501 frames, beam 128: 10.7 -> 4.0 ms.
 #include "vasr_internal.h"
 
 namespace vasr {
 
 namespace {
 
+#ifndef VASR_BEAM_THREADS
+#define VASR_BEAM_THREADS 512
+#endif
+constexpr int kThreads = VASR_BEAM_THREADS;   // workgroup size: 256, 512 or 1024
+constexpr int kWaves = kThreads / 64;
 constexpr int kMaxBeams = 128;
 constexpr int kSlots = 2048;
 constexpr int kMaxFill = 1434;  // 70 % of kSlots
@@ -49,15 +62,15 @@ struct Beam {
   int ctx[kMaxCtx];          // LM history, most recent last, -1 = empty
 };
 
-struct Slot {
-  unsigned long long key;    // 0 = empty
-  long long mx;              // ordered bits of the max score
-  unsigned long long sum;    // fixed-point sum of exp(score - max)
-  int src;                   // (beam << 8) | class
-  float lm_delta;            // LM score of the word this candidate commits
-  int wid;                   // id of that word (-2: nothing committed)
-  int pad;
+// Merge table, structure-of-arrays in LDS (consecutive threads touch consecutive words: no bank conflicts):
+//   key   0 = empty                                  mx   ordered bits of the max score, later of the combined score
+//   sum   fixed-point sum of exp(score - max), later the bits of the merged logit
+//   src   (beam << 8) | class
+// After the expand phase every thread keeps its 8 slots (i = tid + 256 j) in registers for scoring and selection.
+struct Slots {
+  unsigned long long* key; long long* mx; unsigned long long* sum; int* src;
 };
+constexpr size_t kSlotBytes = kSlots * (8 + 8 + 8 + 4);
 
 struct LmView {
   const unsigned long long* vkey; const int* vid; int vcap;
@@ -135,37 +148,106 @@ __device__ inline float partial_penalty(float unk_offset, int wlen) {
   return u;
 }
 
+// log(r) for r in [1, 2^20): exponent split + atanh series (10 odd terms at |s| <= 0.1716: < 1e-16 relative).
+// The library log costs ~2400 cycles per wavefront here, every merged prefix needs one per frame.
+__device__ inline double log_ge1(double r) {
+  long long bits = __double_as_longlong(r);
+  int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);   // [1, 2)
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }                                         // [0.7071, 1.4142]
+  const double s = (m - 1.0) / (m + 1.0), z = s * s;
+  double p = 1.0 / 21.0;
+  p = fma(p, z, 1.0 / 19.0); p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0); p = fma(p, z, 1.0);
+  return fma((double)e, 0.6931471805599453, 2.0 * s * p);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it
+// waits for the back-pointer stores of the previous frame to be acknowledged and for the prefetched log-prob row
+// to arrive -- a full HBM round trip per frame that nothing in the workgroup depends on.
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Wavefront-wide inclusive scan / max on the DPP data path (row shifts + row broadcasts, ~20 VALU instructions).
+// The __shfl_up / __shfl_xor forms go through ds_bpermute: six dependent LDS round trips, ~700 cycles per scan, and
+// the frame loop runs five or more of them.
+template <int CTRL>
+__device__ inline int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+
+__device__ inline int wave_scan_incl(int v) {
+  const int lane = threadIdx.x & 63, rl = lane & 15;
+  int x = v, t;
+  t = dpp_mov<0x111>(x); if (rl >= 1) x += t;              // row_shr:1
+  t = dpp_mov<0x112>(x); if (rl >= 2) x += t;              // row_shr:2
+  t = dpp_mov<0x114>(x); if (rl >= 4) x += t;              // row_shr:4
+  t = dpp_mov<0x118>(x); if (rl >= 8) x += t;              // row_shr:8
+  t = dpp_mov<0x142>(x); if ((lane & 31) >= 16) x += t;    // row_bcast:15
+  t = dpp_mov<0x143>(x); if (lane >= 32) x += t;           // row_bcast:31
+  return x;
+}
+
+__device__ inline unsigned wave_max_u32(unsigned v) {
+  const int lane = threadIdx.x & 63, rl = lane & 15;
+  unsigned x = v, t;
+  t = (unsigned)dpp_mov<0x111>((int)x); if (rl >= 1) x = max(x, t);
+  t = (unsigned)dpp_mov<0x112>((int)x); if (rl >= 2) x = max(x, t);
+  t = (unsigned)dpp_mov<0x114>((int)x); if (rl >= 4) x = max(x, t);
+  t = (unsigned)dpp_mov<0x118>((int)x); if (rl >= 8) x = max(x, t);
+  t = (unsigned)dpp_mov<0x142>((int)x); if ((lane & 31) >= 16) x = max(x, t);
+  t = (unsigned)dpp_mov<0x143>((int)x); if (lane >= 32) x = max(x, t);
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// max of a signed 64-bit value over the wavefront: high words first, then the low words of the lanes that tie
+__device__ inline long long wave_max_i64(long long v) {
+  const unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ull;
+  const unsigned hi = (unsigned)(u >> 32), lo = (unsigned)u;
+  const unsigned hmax = wave_max_u32(hi);
+  const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
+  return (long long)((((unsigned long long)hmax << 32) | lmax) ^ 0x8000000000000000ull);
+}
+
 __device__ inline int block_scan_excl(int v, int* scratch, int* total) {
-  // 256 threads, 4 wavefronts
+  // kWaves wavefronts; scratch holds kWaves ints
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  const int x = wave_scan_incl(v);
   if (lane == 63) scratch[wave] = x;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += scratch[w];
-  *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-  __syncthreads();
+  lds_barrier();
+  int base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) { const int c = scratch[w]; all += c; if (w < wave) base += c; }
+  *total = all;
+  lds_barrier();
   return base + x - v;
 }
 
-// grid (B), block 256
-__global__ __launch_bounds__(256) void beam_search_kernel(const float* __restrict__ logp, int frames, int V1,
+// grid (B), block kThreads
+__global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __restrict__ logp, int frames, int V1,
                                                           int space_id, int beam_width, float token_min_logp,
                                                           float beam_prune_logp, LmView lm, int use_lm,
                                                           unsigned int* __restrict__ bp_all,
                                                           int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
                                                           float* __restrict__ out_score) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Slot* slots = reinterpret_cast<Slot*>(smem);
-  Beam* beams = reinterpret_cast<Beam*>(slots + kSlots);
-  Beam* nbeams = beams + kMaxBeams;
+  Slots sl;
+  sl.key = reinterpret_cast<unsigned long long*>(smem);
+  sl.mx = reinterpret_cast<long long*>(sl.key + kSlots);
+  sl.sum = reinterpret_cast<unsigned long long*>(sl.mx + kSlots);
+  sl.src = reinterpret_cast<int*>(sl.sum + kSlots);
+  Beam* beams = reinterpret_cast<Beam*>(smem + kSlotBytes);
+  Beam* nbeams = beams + kMaxBeams;   // the two buffers swap roles every frame
   double* lp = reinterpret_cast<double*>(nbeams + kMaxBeams);  // [kMaxClasses]
   int* cand = reinterpret_cast<int*>(lp + kMaxClasses);        // [kMaxClasses]
   int* hist = cand + kMaxClasses;                              // [256]
-  int* misc = hist + 256;                                      // [16]
-  long long* best = reinterpret_cast<long long*>(misc + 16);   // [1]
+  int* misc = hist + 256;                                      // [16] + [16] block-scan scratch
+  long long* best = reinterpret_cast<long long*>(misc + 32);   // [1] (+1 pad)
+  long long* sel_lgt = best + 2;                                // [kMaxBeams] merged logit of the survivor at each rank
+  float* sl_lmd = reinterpret_cast<float*>(sel_lgt + kMaxBeams);   // [kSlots] LM score of the word a slot commits
+  int* sl_wid = reinterpret_cast<int*>(sl_lmd + kSlots);            // [kSlots] its word id
+  unsigned short* pair_slot = reinterpret_cast<unsigned short*>(sl_wid + kSlots);   // [kMaxFill + 2] slot of a pair
+  unsigned short* sel_slot = pair_slot + kMaxFill + 2;              // [kMaxBeams] slot of the survivor at each rank
 
   const int tid = threadIdx.x, b = blockIdx.x, V = V1 - 1;
   const float* lrow = logp + (int64_t)b * frames * V1;
@@ -179,164 +261,271 @@ __global__ __launch_bounds__(256) void beam_search_kernel(const float* __restric
     beams[0] = s;
     misc[0] = 1;  // live beams
   }
-  __syncthreads();
+  lds_barrier();
 
+#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals of workgroup 0 (tools/bench_beam.py with VASR_LIB_PATH)
+  long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = clock64();
+#define BEAM_TICK(k) { const long long now = clock64(); prof[k] += now - pt; pt = now; }
+#else
+#define BEAM_TICK(k)
+#endif
+  constexpr int kSpt = kSlots / kThreads;       // table slots owned by a thread: i = tid + kThreads j
+  float lrow_next = tid < V1 ? lrow[tid] : 0.f;   // next frame's log-prob, requested one frame ahead
   for (int t = 0; t < frames; ++t) {
     const int nb = misc[0];
+    BEAM_TICK(5)
     // ---- 1. log-probs (pyctcdecode: log(clip(p, 1e-15, 1))) and candidate characters ----
-    if (tid < V1) lp[tid] = log(fmin(fmax(exp((double)lrow[(int64_t)t * V1 + tid]), 1e-15), 1.0));
-    if (tid == 0) { misc[1] = 0; *best = ord64(-1e300); }
-    for (int i = tid; i < kSlots; i += 256) { slots[i].key = 0; slots[i].mx = ord64(-1e300); slots[i].sum = 0; }
-    __syncthreads();
-    if (tid < V1) {
-      const double v = lp[tid];
-      int rank = 0;            // number of classes strictly better (ties: lower index first) -> argmax has rank 0
-      for (int j = 0; j < V1; ++j) rank += (lp[j] > v) || (lp[j] == v && j < tid);
+    // log(clip(exp(x), 1e-15, 1)) = clip(x, log 1e-15, 0): the same value without two fp64 transcendentals
+    if (tid < V1) lp[tid] = fmin(fmax((double)lrow_next, -34.538776394910684), 0.0);
+    if (tid < V1 && t + 1 < frames) lrow_next = lrow[(int64_t)(t + 1) * V1 + tid];
+    if (tid == 0) *best = ord64(-1e300);
+#pragma unroll
+    for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.mx[i] = ord64(-1e300); sl.sum[i] = 0; }
+    BEAM_TICK(8)
+    lds_barrier();
+    BEAM_TICK(9)
+    if (tid < 64) {
+      // Wavefront 0 picks the candidates, two classes per lane (V1 <= 128), with ballots only -- no LDS, no atomics,
+      // fixed (class) order: wanted = {v >= token_min_logp} U {arg-max}; if more than `cap` are wanted, the cap largest
+      // (ties: lower class first) are found by a bitwise threshold search on the order-preserving integer image of v.
+      const int c0 = tid, c1 = tid + 64;
+      const float v0 = c0 < V1 ? (float)lp[c0] : 0.f, v1 = c1 < V1 ? (float)lp[c1] : 0.f;
+      auto okey = [](float v) { const unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+      const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+      const unsigned kmax = wave_max_u32(max(key0, key1));
+      const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+      const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;
+      bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
+      bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
+      const unsigned long long lt = (1ull << tid) - 1ull;
       const int cap = max(1, kMaxFill / nb);
-      if ((v >= (double)token_min_logp || rank == 0) && rank < cap) cand[atomicAdd(&misc[1], 1)] = tid;
+      if (__popcll(__ballot(k0)) + __popcll(__ballot(k1)) > cap) {
+        unsigned thr = 0;   // the cap-th largest wanted key
+        for (int bit = 31; bit >= 0; --bit) {
+          const unsigned trial = thr | (1u << bit);
+          if (__popcll(__ballot(k0 && key0 >= trial)) + __popcll(__ballot(k1 && key1 >= trial)) >= cap) thr = trial;
+        }
+        const int room = cap - (__popcll(__ballot(k0 && key0 > thr)) + __popcll(__ballot(k1 && key1 > thr)));
+        const unsigned long long e0 = __ballot(k0 && key0 == thr), e1 = __ballot(k1 && key1 == thr);
+        k0 = k0 && (key0 > thr || (key0 == thr && __popcll(e0 & lt) < room));
+        k1 = k1 && (key1 > thr || (key1 == thr && __popcll(e0) + __popcll(e1 & lt) < room));
+      }
+      const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+      if (k0) cand[__popcll(m0 & lt)] = c0;
+      if (k1) cand[__popcll(m0) + __popcll(m1 & lt)] = c1;
+      if (tid == 0) misc[1] = __popcll(m0) + __popcll(m1);
     }
-    __syncthreads();
+    BEAM_TICK(10)
+    lds_barrier();
     const int nc = misc[1];
-    // ---- 2. expand: phase 1 claims a slot and raises its max, phase 2 adds exp(score - max) ----
-    for (int phase = 0; phase < 2; ++phase) {
-      for (int p = tid; p < nb * nc; p += 256) {
-        const int bi = p / nc, c = cand[p % nc];
-        const Beam& s = beams[bi];
-        unsigned long long key = s.key;
-        if (!(c == V || c == s.last)) {
-          if (c == space_id) { if (s.wlen > 0) key = hmix(key, (unsigned long long)c); }
-          else key = hmix(key, (unsigned long long)c);
-        }
-        unsigned long long k = hmix(key, (unsigned long long)(c + 7)) | 1ull;   // (prefix, last char)
-        const double score = s.logit + lp[c];
-        int i = (int)(k & (kSlots - 1));
-        while (true) {
-          const unsigned long long e = slots[i].key;
-          if (e == k) break;
-          if (e == 0) {
-            const unsigned long long old = atomicCAS(&slots[i].key, 0ull, k);
-            if (old == 0ull) { slots[i].src = (bi << 8) | c; break; }
-            if (old == k) break;
-          }
-          i = (i + 1) & (kSlots - 1);
-        }
-        if (phase == 0) atomicMax(&slots[i].mx, ord64(score));
-        else atomicAdd(&slots[i].sum, (unsigned long long)(exp(score - unord64(slots[i].mx)) * kFix));
-      }
-      __syncthreads();
-    }
-    // ---- 3. LM scoring of committed words, combined score, running max ----
-    for (int i = tid; i < kSlots; i += 256) {
-      Slot& sl = slots[i];
-      if (sl.key == 0) continue;
-      const int bi = sl.src >> 8, c = sl.src & 255;
+    BEAM_TICK(0)
+    // ---- 2. expand: every (beam, character) pair claims / finds its slot and raises the slot's max, then (after a
+    //         barrier) adds exp(score - max).  Deliberately NOT unrolled: the kernel must stay inside the 64 KB
+    //         instruction cache it shares with the neighbouring CU (68 KB unrolled: every section fetch-bound). ----
+#pragma unroll 1
+    for (int p = tid; p < nb * nc; p += kThreads) {
+      const int bi = p / nc, c = cand[p % nc];
       const Beam& s = beams[bi];
-      const double logit = unord64(sl.mx) + log((double)sl.sum / kFix);
-      const bool stay = (c == V || c == s.last);
-      const bool commit = !stay && c == space_id && s.wlen > 0;
-      int wlen_new = stay ? s.wlen : (c == space_id ? 0 : s.wlen + 1);
-      float lm_total = 0.f;
-      sl.wid = -2; sl.lm_delta = 0.f;
-      if (use_lm) {
-        if (commit) sl.lm_delta = lm_word_score(lm, s.ctx, s.whash, false, &sl.wid);
-        lm_total = s.lm_text + sl.lm_delta + partial_penalty(lm.unk_offset, wlen_new);
+      unsigned long long key = s.key;
+      if (!(c == V || c == s.last)) {
+        if (c == space_id) { if (s.wlen > 0) key = hmix(key, (unsigned long long)c); }
+        else key = hmix(key, (unsigned long long)c);
       }
-      const double total = logit + (double)lm_total;
-      sl.mx = ord64(total);                 // reuse: ordered combined score
-      sl.sum = (unsigned long long)__double_as_longlong(logit);
-      atomicMax(best, ord64(total));
+      unsigned long long k = hmix(key, (unsigned long long)(c + 7)) | 1ull;   // (prefix, last char)
+      int i = (int)(k & (kSlots - 1));
+      while (true) {
+        const unsigned long long e = sl.key[i];
+        if (e == k) break;
+        if (e == 0) {
+          const unsigned long long old = atomicCAS(&sl.key[i], 0ull, k);
+          if (old == 0ull) { sl.src[i] = (bi << 8) | c; break; }
+          if (old == k) break;
+        }
+        i = (i + 1) & (kSlots - 1);
+      }
+      atomicMax(&sl.mx[i], ord64(s.logit + lp[c]));
+      pair_slot[p] = (unsigned short)i;
     }
-    __syncthreads();
+    lds_barrier();
+#pragma unroll 1
+    for (int p = tid; p < nb * nc; p += kThreads) {
+      const int i = pair_slot[p];
+      const double score = beams[p / nc].logit + lp[cand[p % nc]];
+      atomicAdd(&sl.sum[i], (unsigned long long)(exp(score - unord64(sl.mx[i])) * kFix));
+    }
+    lds_barrier();
+    BEAM_TICK(1)
+    // ---- 3. the thread's own slots move into registers; LM scoring of committed words, combined score ----
+    long long tot[kSpt];      // ordered bits of the combined score
+    long long lgt[kSpt];      // bits of the merged logit
+    unsigned live = 0;        // bit j: slot j is occupied (later: and survives the prune)
+    {
+      unsigned long long k8[kSpt], s8[kSpt];
+      long long m8[kSpt];
+      int src[kSpt];
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) {
+        const int i = tid + kThreads * j;
+        k8[j] = sl.key[i]; m8[j] = sl.mx[i]; s8[j] = sl.sum[i]; src[j] = sl.src[i];
+      }
+      unsigned need = 0;      // slots whose candidate commits a word: LM score wanted
+      float lmt[kSpt];        // LM part of the combined score
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) {
+        lmt[j] = 0.f;
+        if (k8[j] == 0) continue;
+        live |= 1u << j;
+        if (use_lm) {
+          const int bi = src[j] >> 8, c = src[j] & 255;
+          const Beam& s = beams[bi];
+          const bool stay = (c == V || c == s.last);
+          if (!stay && c == space_id && s.wlen > 0) need |= 1u << j;
+          const int wlen_new = stay ? s.wlen : (c == space_id ? 0 : s.wlen + 1);
+          lmt[j] = s.lm_text + partial_penalty(lm.unk_offset, wlen_new);
+        }
+      }
+      // one copy of the n-gram walk for all slots of the thread
+      for (unsigned nm = need; nm; nm &= nm - 1) {
+        const int i = tid + kThreads * (__ffs(nm) - 1);
+        const Beam& s = beams[sl.src[i] >> 8];
+        int w;
+        sl_lmd[i] = lm_word_score(lm, s.ctx, s.whash, false, &w);
+        sl_wid[i] = w;
+      }
+      long long my_best = ord64(-1e300);
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) {
+        tot[j] = ord64(-1e300); lgt[j] = 0;
+        if (!(live >> j & 1)) continue;
+        if (need >> j & 1) lmt[j] += sl_lmd[tid + kThreads * j];   // written by this thread just above
+        // a slot with a single contributor holds exactly exp(0) * 2^44: no logarithm needed
+        const double logit = unord64(m8[j]) + (s8[j] == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8[j] * (1.0 / kFix)));
+        tot[j] = ord64(logit + (double)lmt[j]);
+        lgt[j] = __double_as_longlong(logit);
+        my_best = max(my_best, tot[j]);
+      }
+      // one LDS atomic per wavefront instead of one per candidate (they all hit the same address)
+      my_best = wave_max_i64(my_best);
+      if ((tid & 63) == 0) atomicMax(best, my_best);
+    }
+    lds_barrier();
+    BEAM_TICK(2)
     // ---- 4. prune (max + beam_prune_logp) and radix-select the top beam_width by combined score ----
     const long long thr_prune = ord64(unord64(*best) + (double)beam_prune_logp);
+    unsigned long long u8[kSpt];   // keys as unsigned radix digits
+#pragma unroll
+    for (int j = 0; j < kSpt; ++j) {
+      if (tot[j] < thr_prune) live &= ~(1u << j);
+      u8[j] = (unsigned long long)tot[j] ^ 0x8000000000000000ull;
+    }
     unsigned long long prefix = 0, mask = 0;
     int want = beam_width;   // how many still to take among keys matching the prefix
     {
-      int cnt = 0;
-      for (int i = tid; i < kSlots; i += 256) cnt += (slots[i].key != 0 && slots[i].mx >= thr_prune);
-      int tot;
-      block_scan_excl(cnt, misc + 4, &tot);
-      if (tot > beam_width) {
+      int tot_live;
+      block_scan_excl(__popc(live), misc + 16, &tot_live);
+      if (tot_live > beam_width) {
+#pragma unroll 1
         for (int shift = 56; shift >= 0; shift -= 8) {
-          hist[tid] = 0;
-          __syncthreads();
-          for (int i = tid; i < kSlots; i += 256) {
-            if (slots[i].key == 0 || slots[i].mx < thr_prune) continue;
-            const unsigned long long u = (unsigned long long)slots[i].mx ^ 0x8000000000000000ull;
-            if ((u & mask) == prefix) atomicAdd(&hist[(int)((u >> shift) & 255)], 1);
+          if (tid < 256) hist[tid] = 0;
+          lds_barrier();
+#pragma unroll
+          for (int j = 0; j < kSpt; ++j)
+            if ((live >> j & 1) && (u8[j] & mask) == prefix) atomicAdd(&hist[(int)((u8[j] >> shift) & 255)], 1);
+          lds_barrier();
+          // the bucket holding the want-th largest key, searched from the top by all threads at once: thread tid owns
+          // bin 255 - tid and a block scan gives it the number of keys in the bins above
+          const int mine = tid < 256 ? hist[255 - tid] : 0;
+          int all;
+          const int above = block_scan_excl(mine, misc + 16, &all);
+          if (above < want && want <= above + mine) {
+            misc[2] = 255 - tid; misc[3] = want - above;
+            misc[8] = (mine == want - above);   // the whole bucket is taken: no need to refine further
           }
-          __syncthreads();
-          if (tid == 0) {
-            int acc = 0, d = 255;
-            for (; d >= 0; --d) { if (acc + hist[d] >= want) break; acc += hist[d]; }
-            misc[2] = d; misc[3] = want - acc;
-          }
-          __syncthreads();
+          lds_barrier();
           prefix |= (unsigned long long)misc[2] << shift;
           mask |= 0xFFull << shift;
           want = misc[3];
-          __syncthreads();
+          const int done = misc[8];
+          lds_barrier();
+          if (done) break;
         }
-      } else { prefix = 0; mask = 0; want = beam_width; }
-    }
-    // selected: score > threshold key, plus the first `want` (in slot order) equal to it
-    int sel_gt = 0, sel_eq = 0;
-    for (int i = tid; i < kSlots; i += 256) {
-      if (slots[i].key == 0 || slots[i].mx < thr_prune) continue;
-      const unsigned long long u = (unsigned long long)slots[i].mx ^ 0x8000000000000000ull;
-      if (mask == 0 || u > prefix) ++sel_gt; else if (u == prefix) ++sel_eq;
-    }
-    int tot_gt, tot_eq;
-    const int off_gt = block_scan_excl(sel_gt, misc + 4, &tot_gt);
-    const int off_eq = block_scan_excl(sel_eq, misc + 4, &tot_eq);
-    const int take_eq = mask == 0 ? 0 : min(want, tot_eq);
-    {
-      int ig = off_gt, ie = off_eq;
-      for (int i = tid; i < kSlots; i += 256) {
-        if (slots[i].key == 0 || slots[i].mx < thr_prune) continue;
-        const unsigned long long u = (unsigned long long)slots[i].mx ^ 0x8000000000000000ull;
-        int dst = -1;
-        if (mask == 0 || u > prefix) dst = ig++;
-        else if (u == prefix) { if (ie < take_eq) dst = tot_gt + ie; ++ie; }
-        if (dst < 0 || dst >= kMaxBeams) continue;
-        const Slot& sl = slots[i];
-        const int bi = sl.src >> 8, c = sl.src & 255;
-        const Beam& s = beams[bi];
-        Beam n = s;
-        const bool stay = (c == V || c == s.last);
-        unsigned int appended = 0;
-        if (!stay) {
-          if (c == space_id) {
-            if (s.wlen > 0) {
-              n.key = hmix(s.key, (unsigned long long)c);
-              appended = c + 1;
-              n.lm_text = s.lm_text + sl.lm_delta;
-              if (use_lm) { for (int q = 0; q < kMaxCtx - 1; ++q) n.ctx[q] = s.ctx[q + 1]; n.ctx[kMaxCtx - 1] = sl.wid; }
-              n.wlen = 0; n.whash = kFnvOffset;
-            }
-          } else {
-            n.key = hmix(s.key, (unsigned long long)c);
-            n.whash = hmix(s.whash, (unsigned long long)c);
-            n.wlen = s.wlen + 1;
-            appended = c + 1;
-          }
-        }
-        n.last = c;
-        n.logit = __longlong_as_double((long long)sl.sum);
-        nbeams[dst] = n;
-        bp[(int64_t)t * kMaxBeams + dst] = ((unsigned)bi << 8) | appended;
       }
     }
-    __syncthreads();
-    if (tid == 0) misc[0] = min(kMaxBeams, tot_gt + take_eq);
-    for (int i = tid; i < min(kMaxBeams, tot_gt + take_eq); i += 256) beams[i] = nbeams[i];
-    __syncthreads();
+    BEAM_TICK(3)
+    // selected: key > threshold prefix, plus the first `want` (in thread-major slot order) equal to it
+    unsigned gt = 0, eq = 0;
+#pragma unroll
+    for (int j = 0; j < kSpt; ++j) {
+      if (!(live >> j & 1)) continue;
+      const unsigned long long u = u8[j] & mask;
+      if (mask == 0 || u > prefix) gt |= 1u << j; else if (u == prefix) eq |= 1u << j;
+    }
+    int tot_pk;   // both counts through one scan: < 2048 each, packed 16 + 16 bits
+    const int off_pk = block_scan_excl(__popc(gt) | (__popc(eq) << 16), misc + 16, &tot_pk);
+    const int off_gt = off_pk & 0xffff, off_eq = off_pk >> 16, tot_gt = tot_pk & 0xffff, tot_eq = tot_pk >> 16;
+    const int take_eq = mask == 0 ? 0 : min(want, tot_eq);
+    const int n_new = min(kMaxBeams, tot_gt + take_eq);
+    BEAM_TICK(6)
+    {
+      // survivors publish (slot, merged logit) at their rank; the new beams are then built one per thread
+      int ig = off_gt, ie = off_eq;
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) {
+        int dst = -1;
+        if (gt >> j & 1) dst = ig++;
+        else if (eq >> j & 1) { if (ie < take_eq) dst = tot_gt + ie; ++ie; }
+        if (dst >= 0 && dst < kMaxBeams) { sel_slot[dst] = (unsigned short)(tid + kThreads * j); sel_lgt[dst] = lgt[j]; }
+      }
+    }
+    lds_barrier();
+    if (tid < n_new) {
+      const int i = sel_slot[tid];
+      const int bi = sl.src[i] >> 8, c = sl.src[i] & 255;
+      const Beam& s = beams[bi];
+      Beam n = s;
+      const bool stay = (c == V || c == s.last);
+      unsigned int appended = 0;
+      if (!stay) {
+        if (c == space_id) {
+          if (s.wlen > 0) {
+            n.key = hmix(s.key, (unsigned long long)c);
+            appended = c + 1;
+            if (use_lm) {
+              n.lm_text = s.lm_text + sl_lmd[i];
+              for (int q = 0; q < kMaxCtx - 1; ++q) n.ctx[q] = s.ctx[q + 1];
+              n.ctx[kMaxCtx - 1] = sl_wid[i];
+            }
+            n.wlen = 0; n.whash = kFnvOffset;
+          }
+        } else {
+          n.key = hmix(s.key, (unsigned long long)c);
+          n.whash = hmix(s.whash, (unsigned long long)c);
+          n.wlen = s.wlen + 1;
+          appended = c + 1;
+        }
+      }
+      n.last = c;
+      n.logit = __longlong_as_double(sel_lgt[tid]);
+      nbeams[tid] = n;
+      bp[(int64_t)t * kMaxBeams + tid] = ((unsigned)bi << 8) | appended;
+    }
+    BEAM_TICK(7)
+    if (tid == 0) misc[0] = n_new;
+    { Beam* x = beams; beams = nbeams; nbeams = x; }
+    lds_barrier();
+    BEAM_TICK(4)
   }
+#ifdef VASR_BEAM_PROF
+  if (tid == 0 && b == 0)
+    printf("beam prof (cycles/frame): candidates %lld expand %lld lm %lld select %lld count+scan %lld compact %lld tail %lld other %lld  clear %lld bar %lld rank %lld live beams %d\n",
+           prof[0] / frames, prof[1] / frames, prof[2] / frames, prof[3] / frames, prof[6] / frames, prof[7] / frames,
+           prof[4] / frames, prof[5] / frames, prof[8] / frames, prof[9] / frames, prof[10] / frames, misc[0]);
+#endif
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best ----
   const int nb = misc[0];
   double* fin = lp;  // [kMaxBeams] combined score per beam
-  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(slots);  // [kMaxBeams]
+  unsigned long long* fkey = sl.key;  // [kMaxBeams]
   if (tid < nb) {
     const Beam& s = beams[tid];
     double total = s.logit;
@@ -385,7 +574,8 @@ __global__ __launch_bounds__(256) void beam_search_kernel(const float* __restric
 }  // namespace
 
 size_t beam_lds_bytes() {
-  return sizeof(Slot) * kSlots + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 16) + 16;
+  return kSlotBytes + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 32) + 16 +
+         8 * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2 + kMaxBeams) + 16;
 }
 
 void launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
@@ -406,7 +596,7 @@ void launch_beam_search(const float* logp, int batch, int frames, int V1, int sp
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(256), lds, st, logp, frames, V1, space_id, beam_width,
+  hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, V1, space_id, beam_width,
                      token_min_logp, beam_prune_logp, v, use_lm, bp, out_ids, out_len, out_score);
 }
 
