@@ -166,6 +166,9 @@ def main():
         eng.forward(wav, ln, want_logp=False, want_pred=False)
     torch.cuda.synchronize()
     prof = eng.handle.profile_end()
+    # depthwise / pointwise launches carry their own (start, stop) events (hipExtLaunchKernelGGL: the dispatch packet's
+    # begin / end timestamps), so these are kernel durations as rocprofv3 --kernel-trace reports them
+    # (profiles/rNN_bench_kernel_stats.csv); the 2-3 us dispatch gap between dependent launches is in ms_per_step only.
     work = eng.handle.algorithmic_work(a.batch, samples)
 
     # ---- the other GEMM arithmetic on the same workload, for reference (rank 0 of a single-GPU run only) ----

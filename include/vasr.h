@@ -207,6 +207,11 @@ int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, doub
  *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse) */
 int vasr_profile_begin(vasr_handle* h);
 int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]);
+/* What one event bracket adds to a bracketed launch: median elapsed time (microseconds) of n brackets around an empty
+ * kernel, recorded back to back on `stream` exactly like the profiled launches.  A bracket measures "previous kernel
+ * done -> this kernel done", i.e. the kernel plus its dispatch gap; bench.py reports class times both raw and with
+ * launches x this value removed (the latter is what rocprofv3 --kernel-trace reports as kernel duration). */
+int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us);
 /* Run ONE encoder layer kind in isolation for benchmarking/roofline measurement:
  * kind 0 = depthwise (K, stride 1, dilation 1), 1 = pointwise GEMM (+BN+ReLU epilogue).
  * Buffers are caller provided [B][C][Tp] with Tp = vasr_padded_frames(T). */

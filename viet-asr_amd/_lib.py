@@ -71,6 +71,7 @@ SIGNATURES = {
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "vasr_profile_begin": (C.c_int, [_P]),
     "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vasr_profile_bracket_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "vasr_padded_frames": (C.c_int64, [C.c_int64]),
     "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_pack_pointwise_bf16x3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
@@ -192,6 +193,12 @@ class Handle:
         check(lib().vasr_profile_end(self.h, ms, n))
         names = ("frontend", "depthwise", "pointwise", "head")
         return {k: dict(ms=ms[i], launches=int(n[i])) for i, k in enumerate(names)}
+
+    @staticmethod
+    def profile_bracket_overhead_us(stream, n=256):
+        out = C.c_double()
+        check(lib().vasr_profile_bracket_overhead(stream, n, C.byref(out)))
+        return out.value
 
     def close(self):
         if getattr(self, "h", None):

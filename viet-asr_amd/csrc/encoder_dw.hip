@@ -351,7 +351,7 @@ void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* 
                     int channels, float* y, int64_t ldy, hipStream_t st) {
   dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
   static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  hipLaunchKernelGGL((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy);
+  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
@@ -419,16 +419,16 @@ void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li,
   static const int rows_env = getenv("VASR_DW_ROWS") ? atoi(getenv("VASR_DW_ROWS")) : 1;
   if (channels % 32 == 0 && rows_env == 8) {
     dim3 grid(channels / 32, batch, tiles);
-    hipLaunchKernelGGL((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
   } else if (channels % 8 == 0 && rows_env == 2) {
     dim3 grid(channels / 8, batch, tiles);
-    hipLaunchKernelGGL((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
   } else if (channels % 16 == 0 && rows_env != 1) {
     dim3 grid(channels / 16, batch, tiles);
-    hipLaunchKernelGGL((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
   } else {
     dim3 grid(channels / 4, batch, tiles);
-    hipLaunchKernelGGL((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
   }
 }
 
@@ -456,7 +456,7 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
   }
   if (aligned && stride == 1 && dilation == 2 && kernel == 87 && pad == 86) {
     dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
-    hipLaunchKernelGGL((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
+    VASR_LAUNCH((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
                        y, ldy);
     return;
   }
@@ -472,7 +472,7 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
     }
   }
   dim3 grid((unsigned)((ldy + 255) / 256), channels, batch);
-  hipLaunchKernelGGL(dw_conv_generic_kernel, grid, dim3(256), 0, st, x, ldx, frames_in, w, lens_in, lens_out,
+  VASR_LAUNCH(dw_conv_generic_kernel, grid, dim3(256), 0, st, x, ldx, frames_in, w, lens_in, lens_out,
                      channels, kernel, stride, dilation, pad, y, ldy);
 }
 

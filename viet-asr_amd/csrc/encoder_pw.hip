@@ -192,11 +192,11 @@ void launch_t(const PwArgs& a, hipStream_t st) {
   const int n_blocks = blocks_m * tiles_t * a.batch;
   dim3 grid(n_blocks), block(512);
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask && res) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (mask) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else if (res) hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
-  else hipLaunchKernelGGL((pw_gemm_kernel<WM, TM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  if (dual) VASR_LAUNCH((pw_gemm_kernel<WM, TM, false, false, true>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask && res) VASR_LAUNCH((pw_gemm_kernel<WM, TM, true, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (mask) VASR_LAUNCH((pw_gemm_kernel<WM, TM, true, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else if (res) VASR_LAUNCH((pw_gemm_kernel<WM, TM, false, true, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
+  else VASR_LAUNCH((pw_gemm_kernel<WM, TM, false, false, false>), grid, block, 0, st, a, blocks_m, tiles_t, n_blocks);
 }
 
 }  // namespace

@@ -304,7 +304,7 @@ void launch_k(const PwArgs& a, hipStream_t st) {
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
+  VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
 }
 
 template <int NW, int TM, int TN>

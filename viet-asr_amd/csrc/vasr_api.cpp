@@ -9,12 +9,15 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "vasr.h"
 #include "vasr_internal.h"
 
 using namespace vasr;
+
+namespace vasr { thread_local LaunchProbe g_probe; }
 
 namespace {
 
@@ -413,14 +416,25 @@ struct ProfScope {
     (void)hipEventCreate(&e);
     return e;
   }
+  // Single-launch classes (depthwise, pointwise) hand the event pair to the launch itself (g_probe: the dispatch
+  // packet's begin / end timestamps); multi-launch groups (front end, head) are bracketed on the stream.
   ProfScope(vasr_handle* h_, int cls_, hipStream_t st_) : h(h_), st(st_), cls(cls_) {
     if (!h->profiling) return;
     a = get(h); b = get(h);
-    (void)hipEventRecord(a, st);
+    if (cls == 1 || cls == 2) g_probe = LaunchProbe{a, b};
+    else (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (!h->profiling) return;
-    (void)hipEventRecord(b, st);
+    if (cls == 1 || cls == 2) {
+      if (g_probe.start) {   // no instrumented launch happened inside the scope
+        g_probe = LaunchProbe{};
+        (void)hipEventRecord(a, st);
+        (void)hipEventRecord(b, st);
+      }
+    } else {
+      (void)hipEventRecord(b, st);
+    }
     h->prof.push_back({a, b, cls});
   }
 };
@@ -922,6 +936,27 @@ int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]) {
     h->ev_pool.push_back(r.b);
   }
   h->prof.clear();
+  return 0;
+}
+
+__global__ void vasr_noop_kernel() {}
+
+int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us) {
+  if (n < 1 || n > 4096 || !out_us) return fail(VASR_ERR_INVALID, "bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < n; ++i) {   // same shape as ProfScope: record, launch, record -- back to back on one stream
+    HIP_TRY(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(vasr_noop_kernel, dim3(1), dim3(64), 0, st);
+    HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+  }
+  HIP_TRY(hipEventSynchronize(ev.back()));
+  std::vector<float> t(n);
+  for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(t.begin(), t.end());
+  *out_us = 1e3 * (double)t[n / 2];
   return 0;
 }
 

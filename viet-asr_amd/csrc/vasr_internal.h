@@ -1,9 +1,27 @@
 // Internal launch interface between vasr_api.cpp and the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace vasr {
+
+// Kernel-duration probe for vasr_profile_begin/end.  When armed, the next VASR_LAUNCH goes out through
+// hipExtLaunchKernelGGL with (start, stop) events that take the dispatch packet's own begin / end timestamps, i.e. the
+// kernel's execution time as rocprofv3 --kernel-trace reports it.  (Events recorded around a launch span "previous
+// kernel done -> this kernel done" and so include the 2-3 us dispatch gap: 13 % on a 20 us depthwise layer.)
+struct LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchProbe g_probe;
+#define VASR_LAUNCH(kern, grid, block, lds, st, ...)                                                       \
+  do {                                                                                                     \
+    if (::vasr::g_probe.start) {                                                                           \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, ::vasr::g_probe.start, ::vasr::g_probe.stop, 0,   \
+                            __VA_ARGS__);                                                                  \
+      ::vasr::g_probe.start = nullptr;                                                                     \
+    } else {                                                                                               \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                         \
+    }                                                                                                      \
+  } while (0)
 
 // Activations live in HBM as [B][C][ld] fp32 with the time axis contiguous and
 // ld = pad_frames(T): every row starts 1-KB aligned and every (64..256)-frame GEMM tile stays
