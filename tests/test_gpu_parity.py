@@ -242,3 +242,37 @@ def test_long_clips_config5_shape(gpu):
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3               # frames whose margin is far above fp32 round-off
     assert (r["pred"].cpu()[safe] == ref["pred"][safe]).all()
     assert (r["pred"].cpu() != ref["pred"]).sum() <= 2
+
+
+_ALT_PATH_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
+from conftest import load_golden
+from viet_asr_amd.engine import QuartzNetCTC
+bad = []
+for name in ("vi12x1_b3_ragged", "en15x5_b2_ragged"):
+    g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
+    eng = QuartzNetCTC(cfg, enc_sd, dec_sd)
+    r = eng.forward(torch.from_numpy(sig).cuda(), torch.from_numpy(lens).cuda(), want_logp=True)
+    torch.cuda.synchronize()
+    err = float(np.abs(r["logp"].cpu().numpy() - g["logp"]).max())
+    same = bool((r["pred"].cpu().numpy() == g["pred"]).all()) and eng.texts(r["ids"], r["id_len"]) == [str(s) for s in g["hyp"]]
+    if err > 2e-3 or not same:
+        bad.append((name, err, same))
+print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
+"""
+
+
+@pytest.mark.parametrize("env", [{"VASR_DW_PAIR": "0"}, {"VASR_NO_FUSED_RESIDUAL": "1"}, {"VASR_PW3_TILE": "3"},
+                                 {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_alternate_kernel_paths_match_goldens(gpu, env):
+    """The kernels a default run does not pick (one-row depthwise, two-GEMM residual, latency GEMM tiles, batch slices
+    on side streams) are selected by environment variables read once per process: run each in a child process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = _ALT_PATH_SNIPPET.format(tests=here, root=os.path.dirname(here))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert "ALT_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
