@@ -327,18 +327,20 @@ inline unsigned short bf16_rne(float x, float* back) {
 }  // namespace
 
 bool pointwise_bf16x3_supported(int M, int K, int K1) {
-  return M % 256 == 0 && K % BKC == 0 && (K1 == 0 || K1 % BKC == 0);
+  return M % 64 == 0 && K % BKC == 0 && (K1 == 0 || K1 % BKC == 0);
 }
 
 void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st) {
   static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..4 pins a tile shape
-  // the largest tile that still gives (almost) every one of the 256 CUs a workgroup: 512x128, 256x128, 128x64, 64x32
+  // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
+  // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
+  const int rows[5] = {0, 512, 256, 128, 64};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
-  else if (blocks(256, 128) >= 192) tile = 2;
-  else if (blocks(128, 64) >= 192) tile = 3;
-  if (force >= 1 && force <= 4 && !(force == 1 && a.M % 512)) tile = force;
+  else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
+  else if (a.M % 128 == 0 && blocks(128, 64) >= 192) tile = 3;
+  if (force >= 1 && force <= 4 && a.M % rows[force] == 0) tile = force;
   switch (tile) {
     case 1: return launch_t<8, 2, 4>(a, st);
     case 2: return launch_t<8, 1, 4>(a, st);

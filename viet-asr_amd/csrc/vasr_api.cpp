@@ -539,7 +539,7 @@ int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int b
   a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
   a.relu = 0;
   ProfScope ps(h, kProfHead, st);
-  launch_pointwise(a, st);
+  run_pointwise(h, a, h->dec, st);   // split-bf16 GEMM unless fp32 mode is selected (the head is HBM-bound either way)
   launch_logsoftmax_argmax(logits, ld, (int64_t)h->num_classes * ld, batch, (int)T1, h->num_classes, logp, pred, st);
   return check_launch("decoder");
 }
