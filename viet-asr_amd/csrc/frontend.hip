@@ -25,6 +25,15 @@ __device__ __forceinline__ cf csub(cf a, cf b) { return {a.re - b.re, a.im - b.i
 __device__ __forceinline__ cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cf cmul_negi(cf a) { return {a.im, -a.re}; }
 
+// The FFT scratch, power spectrum and tile columns of a frame belong to ONE wavefront, and the LDS pipeline executes a
+// wavefront's accesses in issue order: a compiler-level fence is all the frame loop needs (it used six workgroup
+// barriers per frame, i.e. the four wavefronts kept waiting for each other 48 times per block).
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // grid (ceil(T/32), B), block 256
 __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
                                                           int64_t samples, int hop, float preemph,
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
       bufA[4 * lane + 2] = csub(t0, t2);
       bufA[4 * lane + 3] = csub(t1, t3);
     }
-    __syncthreads();
+    wave_fence();
     cf* in = bufA;
     cf* out = bufB;
 #pragma unroll
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
       out[j0 + Ns] = cadd(t1, t3);
       out[j0 + 2 * Ns] = csub(t0, t2);
       out[j0 + 3 * Ns] = csub(t1, t3);
-      __syncthreads();
+      wave_fence();
       cf* t = in; in = out; out = t;
     }
     // ---- real-FFT split + power spectrum (features.py:260-263 pow(2).sum(-1)) ----
@@ -125,14 +134,15 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
       cf xk = cadd(e, cmul(tw512[k], o));
       P[k] = xk.re * xk.re + xk.im * xk.im;
     }
-    __syncthreads();
+    wave_fence();
     // ---- mel projection (features.py:266) over the filter's non-zero bins, log guard "add" (:269-271) ----
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < kMelTaps; ++i) acc = fmaf(mw[i], P[mlo + i], acc);
     tile[lane * (kFramesPerBlock + 1) + fl] = logf(acc + log_guard);
-    __syncthreads();
+    wave_fence();
   }
+  __syncthreads();
   // ---- [64][32] tile -> HBM rows ----
   for (int idx = tid; idx < 64 * kFramesPerBlock; idx += 256) {
     const int f = idx / kFramesPerBlock, j = idx % kFramesPerBlock;
