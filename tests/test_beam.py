@@ -120,3 +120,24 @@ def test_beam_module_on_model_output(gpu):
         assert out[b] == BO.decode(g["logp"][b], cfg["labels"], 16, table_fill=1434)
     single = beam(force_pt=True, log_probs=logp[:1], log_probs_length=None)
     assert isinstance(single, str) and single == out[0]            # what infer.py consumes: evaluated_tensors[0][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_lm", [False, True])
+def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
+    """Flat posteriors over 150 frames: every class clears token_min_logp, so the candidate cap (1434 // n_beams = 22 of
+    29 classes at beam 64) bites on every frame -- the ballot threshold search, multi-pass radix select and heavy prefix
+    merging are all on the path."""
+    from viet_asr_amd.beam import BeamSearchDecoder
+    path, _ = toy_lm(str(tmp_path))
+    lp = np.stack([random_posteriors(150, 29, 70 + b, peaky=1.0) for b in range(2)])
+    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    ids, n, score = dec.decode_ids(torch.from_numpy(lp).to(gpu), 64)
+    texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), 64)
+    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
+    for b in range(2):
+        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, 64, lm=lm, table_fill=1434, eos_ignores_cache=True)
+        close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
+        assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (texts[b], ref[:2])
+        if texts[b] == ref[0][0]:
+            assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (float(score[b]), ref[0][2])
