@@ -91,8 +91,9 @@ struct vasr_handle {
   int c_mid_max = 0, c_last = 0;
   // optional per-kernel-class HIP-event timing (vasr_profile_begin/end)
   // batch slicing across internal streams (vasr_set_slices)
-  // measured on MI355X (QuartzNet15x5, B=64): 1 slice 11.7 ms, 2 slices 13.5 ms, 4 slices 19.4 ms -- half-batch
-  // GEMMs leave one workgroup per CU and the co-running kernels thrash L2, so slicing is OFF by default
+  // measured on MI355X (QuartzNet15x5, B=64, 512x128 GEMM tiles pinned): 1 slice 7.35 ms, 2 slices 7.41 ms, 2 slices
+  // phase-shifted by 40 / 100 / 300 us 7.39 / 7.34 / 7.68 ms -- the kernels of the two streams do not overlap in any
+  // useful way (one workgroup per CU each), so slicing is OFF by default
   int slices = getenv("VASR_SLICES") ? atoi(getenv("VASR_SLICES")) : 1;
   bool slice_ready = false;
   hipStream_t slice_stream[kMaxSlices] = {};
