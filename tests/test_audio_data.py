@@ -58,7 +58,7 @@ def test_sinc_table_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sr_in,sr_out", [(8000, 16000), (16000, 8000), (11025, 16000)])
+@pytest.mark.parametrize("sr_in,sr_out", [(8000, 16000), (16000, 8000), (11025, 16000), (16000, 24000), (48000, 16000)])
 def test_device_resampler_matches_oracle(gpu, sr_in, sr_out):
     from oracle import audio_oracle as AO
     r = np.random.RandomState(0)

