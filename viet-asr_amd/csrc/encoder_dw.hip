@@ -3,13 +3,16 @@
 // Replaces the groups == channels MaskedConv1d of every separable JasperBlock
 // (reference nemo/collections/asr/parts/jasper.py:113-132 mask + conv, :360-373 layer order).
 //
-// HBM-bound by design (2*K flops per 8 bytes): one wavefront owns (utterance, channel) row
-// segments of 512 outputs and walks 4 channels, prefetching the next row from HBM while it
-// computes the current one.  The masked input window is staged once into LDS with 16-byte
-// coalesced loads; every lane then pulls a register window of K+4 samples with ds_read_b128 and
-// produces two groups of 4 consecutive outputs on packed-fp32 FMAs, so that each input sample is
-// read from HBM exactly once and both the LDS reads and the 16-byte output stores are conflict
-// free / fully coalesced.  The K taps of the row's channel are wave-uniform and travel through SGPRs.
+// HBM-bound by design (2*K flops per 8 bytes); from K = 51 up the packed-fp32 FMA issue rate is the second bound.
+// Two kernels, same contract (masked input, output zeroed past lens_out so the following GEMM needs no mask):
+//   * dw_pair_kernel (default, further down): one wavefront = one channel x one 512-frame tile of TWO utterances;
+//     the halves of every v_pk_fma_f32 are the two utterances, 8 consecutive frames per lane.
+//   * dw_conv_kernel (VASR_DW_PAIR=0): one wavefront = one (utterance, channel) row segment of 512 outputs; the
+//     masked input window is staged once into LDS with 16-byte coalesced loads; every lane pulls a register window of
+//     K+4 samples with ds_read_b128 and produces two groups of 4 consecutive outputs, pairing time-adjacent outputs
+//     in the packed FMAs.
+// In both, each input sample is read from HBM exactly once, LDS reads are conflict free, stores are 16 bytes per
+// lane, and the K taps of the row's channel are wave-uniform and travel through SGPRs.
 #include <cstdlib>
 
 #include "vasr_internal.h"
