@@ -12,8 +12,10 @@ fixed.  Workload at any N: BASELINE.json configs[2] = QuartzNet15x5, batch 64 x 
 (the configuration the metric/target is quoted on).
 
 Prints ONE JSON line on rank 0 with the driver contract keys plus
-  roofline      -- dominant kernel (1x1-conv fp32 MFMA GEMM): algorithmic flops / HIP-event time
-  depthwise     -- depthwise-conv kernels: algorithmic HBM bytes / HIP-event time vs 8 TB/s
+  roofline      -- dominant kernel (1x1-conv GEMM, fp32 operands as 3 x bf16 on the bf16 MFMA pipe): executed flops /
+                   summed kernel durations (per-launch dispatch timestamps, hipExtLaunchKernelGGL) vs the 2.5 PFLOP/s
+                   nominal peak, plus the rate a bare MFMA stream sustains on this box (sustained_peak)
+  depthwise     -- depthwise-conv kernels: algorithmic HBM bytes / summed kernel durations vs 8 TB/s
   cpu_baseline  -- the CPU oracle (same ATen ops as the reference) on this box's host cores
 """
 import argparse
@@ -29,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import viet_asr_amd  # noqa: E402,F401
-from viet_asr_amd import configs, synth  # noqa: E402
+from viet_asr_amd import _lib, configs, synth  # noqa: E402
 from viet_asr_amd.engine import QuartzNetCTC  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
@@ -171,6 +173,23 @@ def main():
     # (profiles/rNN_bench_kernel_stats.csv); the 2-3 us dispatch gap between dependent launches is in ms_per_step only.
     work = eng.handle.algorithmic_work(a.batch, samples)
 
+    # ---- what the matrix pipe sustains on this box: the GEMM's MFMA stream alone (no loads, LDS, barriers) ----
+    sustained = None
+    if rank == 0 and a.gemm == "bf16x3":
+        import ctypes
+        sink = torch.zeros(16, device=dev)
+        fl = ctypes.c_double()
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        st = torch.cuda.current_stream().cuda_stream
+        run = lambda: _lib.check(_lib.lib().vasr_bench_mfma_bf16_sustained(n_cu, 2000, sink.data_ptr(), ctypes.byref(fl), st))
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        sustained = 3 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
     # ---- the other GEMM arithmetic on the same workload, for reference (rank 0 of a single-GPU run only) ----
     other = None
     if world == 1:
@@ -224,6 +243,10 @@ def main():
                          "bound": "mfma", "achieved": round(exec_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(exec_tflops / peak, 4),
                          "fp32_equivalent_tflops": round(pw_tflops, 2), "traffic": pw_traffic,
+                         "sustained_peak": round(sustained, 1) if sustained else None,
+                         "frac_of_sustained_peak": round(exec_tflops / sustained, 4) if sustained else None,
+                         "sustained_peak_note": "the same MFMA stream with no loads / LDS / barriers, measured in this run: "
+                                                "what the chip holds under its power limit (nominal peak assumes 2.4 GHz)",
                          "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps},

@@ -224,6 +224,12 @@ int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h
 int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
                          int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 
+/* Reference point for the GEMM roofline: launches `workgroups` x 8 wavefronts that do nothing but
+ * v_mfma_f32_32x32x16_bf16 on register operands (the pointwise kernel's MFMA stream without loads, LDS or barriers),
+ * `steps` x 48 per wavefront; *flops = bf16 flops issued.  Timed by the caller; what it sustains is the rate the chip
+ * holds under its power limit, against which bench.py also quotes the GEMM (roofline.sustained_peak). */
+int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
+
 /* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
 int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);
 int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,

@@ -371,3 +371,66 @@ void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad,
 }
 
 }  // namespace vasr
+
+// ---- sustained-MFMA reference point for the roofline (bench.py: roofline.sustained_peak) ----------------------------
+// The GEMM's instruction stream with everything but the MFMAs removed: 8 wavefronts per workgroup (2 per SIMD), one
+// workgroup per CU, per "k-step" 48 v_mfma_f32_32x32x16_bf16 on 8 independent accumulators, operands resident in
+// registers (pseudo-random bf16 patterns, so the data-dependent power draw is that of real operands, not of zeros).
+// What this sustains is the ceiling a bf16 GEMM on this chip can approach under its power limit; the nominal
+// 2.5 PFLOP/s assumes 2.4 GHz, which the part does not hold under dense MFMA load.
+namespace vasr {
+namespace {
+__global__ __launch_bounds__(512) void mfma_bf16_sustained_kernel(int steps, float* __restrict__ sink) {
+  const unsigned seed = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  auto rnd = [](unsigned& s) { s = s * 1664525u + 1013904223u; return (s & 0x7fff7fffu) | 0x3c003c00u; };   // two bf16 near 1
+  unsigned s = seed;
+  uint4 af[2][3], bf[4][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[i][p] = make_uint4(rnd(s), rnd(s), rnd(s), rnd(s));
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bf[j][p] = make_uint4(rnd(s), rnd(s), rnd(s), rnd(s));
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < steps; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][2], bf[j][0], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][2], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][1], bf[j][1], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][1], bf[j][0], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][1], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][0], acc[i][j]);
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+  if (t == 12345.678f) sink[0] = t;   // keeps the accumulators alive
+}
+}  // namespace
+
+// launches one workgroup per CU (n_cu of them); returns the bf16 flops issued
+double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_bf16_sustained_kernel, dim3(n_cu), dim3(512), 0, st, steps, sink);
+  return (double)n_cu * 8 * steps * 48 * (2.0 * 32 * 32 * 16);
+}
+}  // namespace vasr

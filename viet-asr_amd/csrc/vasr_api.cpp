@@ -1015,6 +1015,12 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   return check_launch("bench_pointwise");
 }
 
+int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream) {
+  if (workgroups < 1 || steps < 1 || !d_sink || !flops) return fail(VASR_ERR_INVALID, "bad argument");
+  *flops = launch_mfma_bf16_sustained(workgroups, steps, d_sink, static_cast<hipStream_t>(stream));
+  return check_launch("mfma_bf16_sustained");
+}
+
 int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out) {
   if (!h_w || !h_out || cout <= 0 || cin % 16 || m_pad % 32 || m_pad < cout) return fail(VASR_ERR_INVALID, "bad argument");
   pack_pointwise_weights_bf16x3(h_w, cout, cin, m_pad, h_out);

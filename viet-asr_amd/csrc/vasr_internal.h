@@ -87,6 +87,7 @@ void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float*
 
 // 3 x bf16 split variant (encoder_pw_bf16x3.hip): same PwArgs, a.wt points at the bf16 fragment pack
 bool pointwise_bf16x3_supported(int M, int K, int K1);
+double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st);
 void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st);
 void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out);
 
