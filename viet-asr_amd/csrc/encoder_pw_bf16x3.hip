@@ -186,6 +186,11 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
     // first MFMA of every chunk.  They are issued behind the step-1 weight prefetch, because vmcnt retires in order
     // and every later weight wait therefore also waits for them.
     const int cn = c + 1 < nchunks ? c + 1 : c;
+    // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
+    // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
+    uint4 bf[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
@@ -195,17 +200,22 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
       // next to sstore.  It also keeps sstore's conversion (which may overlap the last step's MFMAs) from moving
       // further up, where its first instruction would wait for the HBM loads.
       __builtin_amdgcn_sched_barrier(0);
-      uint4 bf[2][3];   // activation fragments of n-tile j (current) and j+1 (being read)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, (VASR_ABLATE & 2) ? 0 : s, kh, l31);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (j + 1 < TN) {
+        const int cur = (s * TN + j) & 1, nxt = cur ^ 1;
+        if (!(VASR_ABLATE & 2)) {
+          if (j + 1 < TN) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            bf[(j + 1) & 1][p] = (VASR_ABLATE & 2) ? bf[0][p] : bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+            for (int p = 0; p < 3; ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+          } else if (s + 1 < STEPS) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bf[nxt][p] = bf[cur][p];
         }
-        const uint4 bh = bf[j & 1][0], bm = bf[j & 1][1], bl = bf[j & 1][2];
+        const uint4 bh = bf[cur][0], bm = bf[cur][1], bl = bf[cur][2];
         // six cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][2], bh, acc[i][j]);   // lo  * hi
