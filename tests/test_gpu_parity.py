@@ -276,3 +276,19 @@ def test_alternate_kernel_paths_match_goldens(gpu, env):
     code = _ALT_PATH_SNIPPET.format(tests=here, root=os.path.dirname(here))
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert "ALT_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_results_do_not_depend_on_batch_size_or_tile_shape(gpu):
+    """An utterance gives bit-identical log-probs alone (64x32 GEMM tiles, self-paired depthwise) and inside an odd
+    batch of 67 equal-length clips (256x128 / 512x128 tiles, utterance pairs): every reduction runs in the same order
+    whatever the launch shape.  This is what lets the serving queue merge requests without changing answers."""
+    from viet_asr_amd import configs, synth
+    cfg = configs.builtin("quartznet15x5")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 9), synth.decoder_state_dict(1024, 29, 9))
+    sig, lens = synth.audio_batch(67, 24000, 9)
+    r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
+    for b in (0, 33, 66):
+        r1 = eng.forward(torch.from_numpy(sig[b:b + 1]).to(gpu), torch.from_numpy(lens[b:b + 1]).to(gpu), want_logp=True)
+        assert torch.equal(r["logp"][b], r1["logp"][0])
+        assert torch.equal(r["pred"][b], r1["pred"][0])
