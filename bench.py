@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--ragged", action="store_true", help="lengths uniform in [L/2, L] instead of full clips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-gemm", action="store_true", help="skip the comparison pass in the other GEMM arithmetic")
     ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="arithmetic of the 1x1-conv GEMMs: 3 x bf16 split operands on the bf16 MFMA pipe "
                          "(fp32-equivalent accuracy, default) or exact-fp32 MFMA")
@@ -192,7 +193,7 @@ def main():
 
     # ---- the other GEMM arithmetic on the same workload, for reference (rank 0 of a single-GPU run only) ----
     other = None
-    if world == 1:
+    if world == 1 and not a.no_other_gemm:
         other_mode = "fp32" if a.gemm == "bf16x3" else "bf16x3"
         eng.handle.set_gemm_mode(other_mode)
         for _ in range(2):
