@@ -174,10 +174,15 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
       for (int p = 0; p < 3; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * 3 + p) * 64];
   };
 
-  const int nchunks = a.K / BKC;
-  gload(0);
-  aload(0, af);
-  sstore(0, 0);
+  // A time tile on which every input is zero (past the utterance's length in a ragged batch) has nothing to reduce:
+  // its outputs are shift (+ residual) through the ReLU, which is what the epilogue makes of zero accumulators.
+  const int zf = a.zero_from ? max(a.zero_from[b], DUAL ? len2 : 0) : 0x7fffffff;
+  const int nchunks = t0 >= zf ? 0 : a.K / BKC;
+  if (nchunks) {
+    gload(0);
+    aload(0, af);
+    sstore(0, 0);
+  }
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
@@ -340,8 +345,11 @@ bool pointwise_bf16x3_supported(int M, int K, int K1) {
   return M % 64 == 0 && K % BKC == 0 && (K1 == 0 || K1 % BKC == 0);
 }
 
-void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st) {
+void launch_pointwise_bf16x3(const PwArgs& args, hipStream_t st) {
   static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..4 pins a tile shape
+  static const bool no_skip = getenv("VASR_NO_TILE_SKIP") && atoi(getenv("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
+  PwArgs a = args;
+  if (no_skip) a.zero_from = nullptr;
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };

@@ -519,6 +519,8 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.y = dst; a.M = W.m_pad; a.K = W.cin; a.batch = batch;
       a.ldx = gx_ld; a.ldy = dst_ld; a.ldr = blk_ld; a.frames = (int)g_T; a.m_store = W.m_pad; a.relu = 1;
       a.store_cols = (dst_ld % kTimeTile == 0) ? (int)dst_ld : (int)g_T;  // port tensors are not padded
+      // the depthwise output is zero past its lens_out, a masked input past its mask: tiles out there skip their K loop
+      a.zero_from = S.separable ? lens(S.dw.step + 1) : g_lens;
       if (fuse) { a.x2 = blk_in; a.lens2 = lens(B.first_step); a.K1 = B.fused_k1; a.ldx2 = blk_ld; }
       if ((a.res || fuse) && blk_ld != gx_ld)
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);

@@ -80,6 +80,10 @@ struct PwArgs {
   int32_t store_cols;     // columns < store_cols are stored: ldy for padded internal buffers, frames for ports
   int32_t m_store;        // rows < m_store are stored (decoder: V+1 of 128)
   int32_t relu;
+  // [B] (or nullptr): every input source of utterance b is zero at columns >= zero_from[b] (the depthwise kernel and
+  // the masks guarantee it), so a time tile that starts there skips its K loop: its outputs are relu(shift (+ res)).
+  // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
+  const int32_t* zero_from;
 };
 void launch_pointwise(const PwArgs& a, hipStream_t st);
 // host: [cout][cin] row-major -> fragment order [m_pad/32][cin/8][64][4] (zero rows past cout)
