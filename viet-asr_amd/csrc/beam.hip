@@ -155,7 +155,12 @@ __device__ inline double log_ge1(double r) {
   int e = (int)((bits >> 52) & 0x7ff) - 1023;
   double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);   // [1, 2)
   if (m > 1.4142135623730951) { m *= 0.5; e += 1; }                                         // [0.7071, 1.4142]
-  const double s = (m - 1.0) / (m + 1.0), z = s * s;
+  // 1/(m+1): hardware estimate + two Newton steps (full IEEE division is ~25 fp64 instructions, 8 cycles each)
+  const double d = m + 1.0;
+  double r1 = __builtin_amdgcn_rcp(d);
+  r1 = fma(fma(-d, r1, 1.0), r1, r1);
+  r1 = fma(fma(-d, r1, 1.0), r1, r1);
+  const double s = (m - 1.0) * r1, z = s * s;
   double p = 1.0 / 21.0;
   p = fma(p, z, 1.0 / 19.0); p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0);
   p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0);
@@ -209,17 +214,20 @@ __device__ inline long long wave_max_i64(long long v) {
   return (long long)((((unsigned long long)hmax << 32) | lmax) ^ 0x8000000000000000ull);
 }
 
-__device__ inline int block_scan_excl(int v, int* scratch, int* total) {
-  // kWaves wavefronts; scratch holds kWaves ints
+// Exclusive scan over the workgroup with ONE barrier: the per-wavefront totals go to one of two scratch rows that
+// alternate from call to call (`flip`), so a row is rewritten only after another barrier has passed.
+__device__ inline int block_scan_excl(int v, int* scratch, int* total, int& flip) {
+  // kWaves wavefronts; scratch holds 2 x kWaves ints
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = wave_scan_incl(v);
-  if (lane == 63) scratch[wave] = x;
+  int* row = scratch + flip * kWaves;
+  flip ^= 1;
+  if (lane == 63) row[wave] = x;
   lds_barrier();
   int base = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) { const int c = scratch[w]; all += c; if (w < wave) base += c; }
+  for (int w = 0; w < kWaves; ++w) { const int c = row[w]; all += c; if (w < wave) base += c; }
   *total = all;
-  lds_barrier();
   return base + x - v;
 }
 
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   int* cand = reinterpret_cast<int*>(lp + kMaxClasses);        // [kMaxClasses]
   int* hist = cand + kMaxClasses;                              // [256]
   int* misc = hist + 256;                                      // [16] + [16] block-scan scratch
-  long long* best = reinterpret_cast<long long*>(misc + 32);   // [1] (+1 pad)
+  long long* best = reinterpret_cast<long long*>(misc + 16 + 2 * kWaves + (kWaves & 1) * 0);   // [1] (+1 pad)
   long long* sel_lgt = best + 2;                                // [kMaxBeams] merged logit of the survivor at each rank
   float* sl_lmd = reinterpret_cast<float*>(sel_lgt + kMaxBeams);   // [kSlots] LM score of the word a slot commits
   int* sl_wid = reinterpret_cast<int*>(sl_lmd + kSlots);            // [kSlots] its word id
@@ -270,26 +278,36 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 #define BEAM_TICK(k)
 #endif
   constexpr int kSpt = kSlots / kThreads;       // table slots owned by a thread: i = tid + kThreads j
-  float lrow_next = tid < V1 ? lrow[tid] : 0.f;   // next frame's log-prob, requested one frame ahead
+  // next frame's log-probs of classes tid and tid + 64 (wavefront 0 only), requested one frame ahead
+  float lrow_next = tid < 64 && tid < V1 ? lrow[tid] : 0.f, lrow_next1 = tid < 64 && tid + 64 < V1 ? lrow[tid + 64] : 0.f;
+  int flip = 0;   // block_scan_excl scratch row
   for (int t = 0; t < frames; ++t) {
     const int nb = misc[0];
     BEAM_TICK(5)
     // ---- 1. log-probs (pyctcdecode: log(clip(p, 1e-15, 1))) and candidate characters ----
     // log(clip(exp(x), 1e-15, 1)) = clip(x, log 1e-15, 0): the same value without two fp64 transcendentals
-    if (tid < V1) lp[tid] = fmin(fmax((double)lrow_next, -34.538776394910684), 0.0);
-    if (tid < V1 && t + 1 < frames) lrow_next = lrow[(int64_t)(t + 1) * V1 + tid];
+    // Wavefront 0 owns the log-probs (two classes per lane) and picks the candidates while the others clear the merge
+    // table: one barrier for both.
     if (tid == 0) *best = ord64(-1e300);
+    if (tid < 256) hist[tid] = 0;
 #pragma unroll
     for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.mx[i] = ord64(-1e300); sl.sum[i] = 0; }
     BEAM_TICK(8)
-    lds_barrier();
     BEAM_TICK(9)
     if (tid < 64) {
-      // Wavefront 0 picks the candidates, two classes per lane (V1 <= 128), with ballots only -- no LDS, no atomics,
+      // Candidates with ballots only (V1 <= 128) -- no LDS, no atomics,
       // fixed (class) order: wanted = {v >= token_min_logp} U {arg-max}; if more than `cap` are wanted, the cap largest
       // (ties: lower class first) are found by a bitwise threshold search on the order-preserving integer image of v.
       const int c0 = tid, c1 = tid + 64;
-      const float v0 = c0 < V1 ? (float)lp[c0] : 0.f, v1 = c1 < V1 ? (float)lp[c1] : 0.f;
+      const double d0 = fmin(fmax((double)lrow_next, -34.538776394910684), 0.0);
+      const double d1 = fmin(fmax((double)lrow_next1, -34.538776394910684), 0.0);
+      if (c0 < V1) lp[c0] = d0;
+      if (c1 < V1) lp[c1] = d1;
+      if (t + 1 < frames) {
+        if (c0 < V1) lrow_next = lrow[(int64_t)(t + 1) * V1 + c0];
+        if (c1 < V1) lrow_next1 = lrow[(int64_t)(t + 1) * V1 + c1];
+      }
+      const float v0 = c0 < V1 ? (float)d0 : 0.f, v1 = c1 < V1 ? (float)d1 : 0.f;
       auto okey = [](float v) { const unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
       const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
       const unsigned kmax = wave_max_u32(max(key0, key1));
@@ -422,21 +440,22 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     int want = beam_width;   // how many still to take among keys matching the prefix
     {
       int tot_live;
-      block_scan_excl(__popc(live), misc + 16, &tot_live);
+      block_scan_excl(__popc(live), misc + 16, &tot_live, flip);
       if (tot_live > beam_width) {
 #pragma unroll 1
+        // three barriers per digit: the histogram is all zero on entry (cleared with the table at the top of the frame)
+        // and every thread re-zeroes its own bin right after reading it
         for (int shift = 56; shift >= 0; shift -= 8) {
-          if (tid < 256) hist[tid] = 0;
-          lds_barrier();
 #pragma unroll
           for (int j = 0; j < kSpt; ++j)
             if ((live >> j & 1) && (u8[j] & mask) == prefix) atomicAdd(&hist[(int)((u8[j] >> shift) & 255)], 1);
           lds_barrier();
           // the bucket holding the want-th largest key, searched from the top by all threads at once: thread tid owns
           // bin 255 - tid and a block scan gives it the number of keys in the bins above
-          const int mine = tid < 256 ? hist[255 - tid] : 0;
+          int mine = 0;
+          if (tid < 256) { mine = hist[255 - tid]; hist[255 - tid] = 0; }
           int all;
-          const int above = block_scan_excl(mine, misc + 16, &all);
+          const int above = block_scan_excl(mine, misc + 16, &all, flip);
           if (above < want && want <= above + mine) {
             misc[2] = 255 - tid; misc[3] = want - above;
             misc[8] = (mine == want - above);   // the whole bucket is taken: no need to refine further
@@ -445,9 +464,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
           prefix |= (unsigned long long)misc[2] << shift;
           mask |= 0xFFull << shift;
           want = misc[3];
-          const int done = misc[8];
-          lds_barrier();
-          if (done) break;
+          if (misc[8]) break;
         }
       }
     }
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
       if (mask == 0 || u > prefix) gt |= 1u << j; else if (u == prefix) eq |= 1u << j;
     }
     int tot_pk;   // both counts through one scan: < 2048 each, packed 16 + 16 bits
-    const int off_pk = block_scan_excl(__popc(gt) | (__popc(eq) << 16), misc + 16, &tot_pk);
+    const int off_pk = block_scan_excl(__popc(gt) | (__popc(eq) << 16), misc + 16, &tot_pk, flip);
     const int off_gt = off_pk & 0xffff, off_eq = off_pk >> 16, tot_gt = tot_pk & 0xffff, tot_eq = tot_pk >> 16;
     const int take_eq = mask == 0 ? 0 : min(want, tot_eq);
     const int n_new = min(kMaxBeams, tot_gt + take_eq);
@@ -574,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 }  // namespace
 
 size_t beam_lds_bytes() {
-  return kSlotBytes + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 32) + 16 +
+  return kSlotBytes + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 16 + 2 * kWaves) + 16 +
          8 * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2 + kMaxBeams) + 16;
 }
 
