@@ -2,7 +2,7 @@
 """Time the device beam search on BASELINE config-4 shaped input (dev tool)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import viet_asr_amd
 from viet_asr_amd import configs, synth
 from viet_asr_amd.beam import BeamSearchDecoder

@@ -2,7 +2,7 @@
 """fp32-MFMA vs 3xbf16 GEMM: isolated layer timing + error against an fp64 reference (dev tool)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import viet_asr_amd
 from viet_asr_amd import _lib, configs, synth
 from viet_asr_amd.engine import QuartzNetCTC

@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import viet_asr_amd  # noqa
 from viet_asr_amd import _lib, configs, stages, synth
 from viet_asr_amd.engine import QuartzNetCTC, blocks_from_config

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   }
   lds_barrier();
 
-#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals of workgroup 0 (tools/bench_beam.py with VASR_LIB_PATH)
+#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals of workgroup 0 (tests/devtools/bench_beam.py with VASR_LIB_PATH)
   long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = clock64();
 #define BEAM_TICK(k) { const long long now = clock64(); prof[k] += now - pt; pt = now; }
 #else
