@@ -66,7 +66,8 @@ struct Beam {
 //   key   0 = empty                                  mx   ordered bits of the max score, later of the combined score
 //   sum   fixed-point sum of exp(score - max), later the bits of the merged logit
 //   src   (beam << 8) | class
-// After the expand phase every thread keeps its 8 slots (i = tid + 256 j) in registers for scoring and selection.
+// After the expand phase every thread keeps its kSlots / kThreads slots (i = tid + kThreads j) in registers for
+// scoring and selection.
 struct Slots {
   unsigned long long* key; long long* mx; unsigned long long* sum; int* src;
 };
