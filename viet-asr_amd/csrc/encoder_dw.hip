@@ -367,20 +367,39 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
                                                               const int32_t* __restrict__ lens_out,
                                                               int channels, int K, int stride, int dil, int pad,
                                                               float* __restrict__ y, int64_t ldy) {
+  constexpr int kSpan = 2048;
+  __shared__ float xs[kSpan];
   const int c = blockIdx.y, b = blockIdx.z;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ldy) return;
+  const int t0 = blockIdx.x * blockDim.x;
+  const int t = t0 + threadIdx.x;
   int len_in = lens_in[b];
   if (len_in > frames_in) len_in = frames_in;
   const int64_t row = (int64_t)b * channels + c;
   const float* xr = x + row * ldx;
-  const float* wc = w + (int64_t)c * K;
+  const float* wc = w + (int64_t)c * K;   // block-uniform: scalar loads
+  // the masked input span of the block's 256 outputs goes through LDS once (the stride-2 prologue block read every
+  // sample ~16 times from L1); a masked sample is a zero term of the same fmaf chain
+  const int span = 255 * stride + dil * (K - 1) + 1, s_base = t0 * stride - pad;
+  const bool staged = span <= kSpan;
+  if (staged) {
+    for (int j = threadIdx.x; j < span; j += blockDim.x) {
+      const int s = s_base + j;
+      xs[j] = (s >= 0 && s < len_in) ? xr[s] : 0.f;
+    }
+    __syncthreads();
+  }
+  if (t >= ldy) return;
   float acc = 0.f;
   if (t < lens_out[b]) {
-    const int s0 = t * stride - pad;
-    for (int k = 0; k < K; ++k) {
-      const int s = s0 + k * dil;
-      if (s >= 0 && s < len_in) acc = fmaf(wc[k], xr[s], acc);
+    if (staged) {
+      const float* xt = xs + threadIdx.x * stride;
+      for (int k = 0; k < K; ++k) acc = fmaf(wc[k], xt[k * dil], acc);
+    } else {
+      const int s0 = t * stride - pad;
+      for (int k = 0; k < K; ++k) {
+        const int s = s0 + k * dil;
+        if (s >= 0 && s < len_in) acc = fmaf(wc[k], xr[s], acc);
+      }
     }
   }
   y[row * ldy + t] = acc;
