@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="lengths uniform in [L/2, L] instead of full clips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-gemm", action="store_true", help="skip the comparison pass in the other GEMM arithmetic")
-    ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
+    ap.add_argument("--gemm", choices=["bf16x3", "fp32", "bf16x2"], default="bf16x3",
                     help="arithmetic of the 1x1-conv GEMMs: 3 x bf16 split operands on the bf16 MFMA pipe "
                          "(fp32-equivalent accuracy, default) or exact-fp32 MFMA")
     a = ap.parse_args()
@@ -220,9 +220,10 @@ def main():
         pw_ms = prof["pointwise"]["ms"] / a.steps
         dw_ms = prof["depthwise"]["ms"] / a.steps
         pw_tflops = work["pointwise_flops"] / (pw_ms * 1e-3) / 1e12       # fp32-equivalent (algorithmic) rate
-        split = a.gemm == "bf16x3"
+        split = a.gemm in ("bf16x3", "bf16x2")
+        terms = {"bf16x3": 6.0, "bf16x2": 3.0}.get(a.gemm, 1.0)
         # the split kernel executes 6 bf16 MFMA products per fp32 multiply-add: that is the work the matrix pipe sees
-        exec_tflops = pw_tflops * (6.0 if split else 1.0)
+        exec_tflops = pw_tflops * terms
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
         default_workload = a.model == "quartznet15x5" and a.batch == 64 and a.seconds == 10.0 and not a.ragged
@@ -233,7 +234,9 @@ def main():
             "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 via 3xbf16 split operands (6 bf16 MFMA products per multiply, fp32 accumulate)" if split else "f32",
+            "dtype": {"bf16x3": "f32 via 3xbf16 split operands (6 bf16 MFMA products per multiply, fp32 accumulate)",
+                      "bf16x2": "REDUCED: 2xbf16 split operands (16-bit significands, 3 bf16 MFMA products, fp32 accumulate) -- "
+                                "opt-in mode, not the headline configuration", "fp32": "f32"}[a.gemm],
             "data": "synthetic",
             "config": {"workload": f"{a.model} greedy CTC, batch={a.batch}x{a.seconds:g}s 16kHz mono per GPU"
                                    f"{' (ragged lengths)' if a.ragged else ''}, wav in HBM -> collapsed ids",

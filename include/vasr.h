@@ -145,9 +145,14 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
  *   0            v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;
  *   1 (default)  every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
  *                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error < one fp32 rounding, measured
- *                error against fp64 not larger than mode 0's; 2.67x less matrix time).  Layers whose shape the
- *                split kernel does not cover (the CTC head) keep mode 0.
- * The environment variable VASR_GEMM=fp32 / bf16x3 sets the initial mode of new handles. */
+ *                error against fp64 not larger than mode 0's; 2.67x less matrix time);
+ *   2 (opt-in)   REDUCED precision: only the two upper bf16 terms of each operand (16 significant bits) and the
+ *                three largest cross products -- half the MFMA work of mode 1 (QuartzNet15x5, B = 64: 5.5 instead of
+ *                7.4 ms per batch), log-prob error against the reference goldens 5-10x mode 1's (still inside the
+ *                2e-3 tolerance there, identical predictions), more accurate than the TF32 convolutions PyTorch
+ *                runs by default on the GPUs the reference targets.  Never the default, never the headline number.
+ * Layers whose shape the split kernel does not cover keep mode 0.
+ * The environment variable VASR_GEMM=fp32 / bf16x3 / bf16x2 sets the initial mode of new handles. */
 int vasr_set_gemm_mode(vasr_handle* h, int mode);
 
 /* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */

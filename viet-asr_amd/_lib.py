@@ -181,7 +181,7 @@ class Handle:
 
     def set_gemm_mode(self, mode):
         """'fp32' (exact fp32 MFMA) or 'bf16x3' (3 x bf16 split operands, fp32-equivalent accuracy)."""
-        check(lib().vasr_set_gemm_mode(self.h, {"fp32": 0, "bf16x3": 1}[mode] if isinstance(mode, str) else int(mode)))
+        check(lib().vasr_set_gemm_mode(self.h, {"fp32": 0, "bf16x3": 1, "bf16x2": 2}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_slices(self, n):
         check(lib().vasr_set_slices(self.h, int(n)))

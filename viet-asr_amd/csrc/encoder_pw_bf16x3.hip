@@ -85,7 +85,9 @@ struct Geom {
   static_assert(PATCHES % NT == 0 && PPT >= 1, "staging patches must divide evenly over the threads");
 };
 
-template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL>
+// LITE: only the hi/mid planes and the three largest cross terms (hi*hi, hi*mid, mid*hi): 16-bit operands,
+// opt-in "bf16x2" mode (vasr_set_gemm_mode(h, 2)); the default keeps all three planes and six terms.
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, bool LITE>
 __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
   using G = Geom<NW, TM, TN>;
   constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
       split3(rb[p], hi, mid, lo);
       bs(buf, 0, g >> 1, g & 1, n) = hi;
       bs(buf, 1, g >> 1, g & 1, n) = mid;
-      bs(buf, 2, g >> 1, g & 1, n) = lo;
+      if (!LITE) bs(buf, 2, g >> 1, g & 1, n) = lo;
     }
   };
 
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * 3 + p) * 64];
+      for (int p = 0; p < (LITE ? 2 : 3); ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * 3 + p) * 64];
   };
 
   // A time tile on which every input is zero (past the utterance's length in a ragged batch) has nothing to reduce:
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
     uint4 bf[2][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
+    for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
         if (!(VASR_ABLATE & 2)) {
           if (j + 1 < TN) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+            for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
           } else if (s + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
+            for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
           }
         } else {
 #pragma unroll
@@ -222,12 +224,14 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
         }
         const uint4 bh = bf[cur][0], bm = bf[cur][1], bl = bf[cur][2];
         // six cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
+        if constexpr (!LITE) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][2], bh, acc[i][j]);   // lo  * hi
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][2], bh, acc[i][j]);   // lo  * hi
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bl, acc[i][j]);   // hi  * lo
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bl, acc[i][j]);   // hi  * lo
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bm, acc[i][j]);   // mid * mid
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bm, acc[i][j]);   // mid * mid
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bh, acc[i][j]);   // mid * hi
 #pragma unroll
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[i][p] = an[i][p];
+        for (int p = 0; p < (LITE ? 2 : 3); ++p) af[i][p] = an[i][p];
     }
     // also unconditional (after the last chunk it refills the idle buffer): inside a branch LLVM sinks the global
     // loads above down to this, their only use, and their whole HBM latency is exposed
@@ -307,13 +311,13 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
   }
 }
 
-template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL>
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, bool LITE>
 void launch_k(const PwArgs& a, hipStream_t st) {
   using G = Geom<NW, TM, TN>;
   const int blocks_m = a.M / G::BM;
   const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
-  auto kern = pw_gemm_bf16x3_kernel<NW, TM, TN, MASK, RES, DUAL>;
+  auto kern = pw_gemm_bf16x3_kernel<NW, TM, TN, MASK, RES, DUAL, LITE>;
   static bool once = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     return true;
@@ -322,14 +326,20 @@ void launch_k(const PwArgs& a, hipStream_t st) {
   VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
 }
 
+template <int NW, int TM, int TN, bool LITE>
+void launch_l(const PwArgs& a, hipStream_t st) {
+  const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
+  if (dual) launch_k<NW, TM, TN, false, false, true, LITE>(a, st);
+  else if (mask && res) launch_k<NW, TM, TN, true, true, false, LITE>(a, st);
+  else if (mask) launch_k<NW, TM, TN, true, false, false, LITE>(a, st);
+  else if (res) launch_k<NW, TM, TN, false, true, false, LITE>(a, st);
+  else launch_k<NW, TM, TN, false, false, false, LITE>(a, st);
+}
+
 template <int NW, int TM, int TN>
 void launch_t(const PwArgs& a, hipStream_t st) {
-  const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) launch_k<NW, TM, TN, false, false, true>(a, st);
-  else if (mask && res) launch_k<NW, TM, TN, true, true, false>(a, st);
-  else if (mask) launch_k<NW, TM, TN, true, false, false>(a, st);
-  else if (res) launch_k<NW, TM, TN, false, true, false>(a, st);
-  else launch_k<NW, TM, TN, false, false, false>(a, st);
+  if (a.relu & 4) launch_l<NW, TM, TN, true>(a, st);   // bit 2 of `relu`: the 3-term "bf16x2" arithmetic
+  else launch_l<NW, TM, TN, false>(a, st);
 }
 
 inline unsigned short bf16_rne(float x, float* back) {

@@ -101,7 +101,7 @@ struct vasr_handle {
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16
   // Default 1: measured max error against fp64 is slightly LOWER than mode 0's (tools/kscan.py: 3.6e-6 vs 4.7e-6 at
   // K=512) and every parity test passes unchanged, at 1.6x the GEMM throughput.  VASR_GEMM=fp32 selects mode 0.
-  int gemm_mode = getenv("VASR_GEMM") && !strcmp(getenv("VASR_GEMM"), "fp32") ? 0 : 1;
+  int gemm_mode = !getenv("VASR_GEMM") ? 1 : !strcmp(getenv("VASR_GEMM"), "fp32") ? 0 : !strcmp(getenv("VASR_GEMM"), "bf16x2") ? 2 : 1;
   bool profiling = false;
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;
@@ -449,8 +449,9 @@ int check_launch(const char* what) {
 
 // GEMM dispatch: exact-fp32 MFMA kernel, or the 3 x bf16 split kernel when selected and the layer has that pack.
 static void run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStream_t st) {
-  if (h->gemm_mode == 1 && W.d_w3) {
+  if (h->gemm_mode >= 1 && W.d_w3) {
     a.wt = reinterpret_cast<const float*>(W.d_w3);
+    if (h->gemm_mode == 2) a.relu |= 4;   // 3-term "bf16x2" arithmetic (opt-in, 16-bit operands)
     launch_pointwise_bf16x3(a, st);
   } else {
     a.wt = W.d_w;
@@ -849,7 +850,8 @@ int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in,
 }
 
 int vasr_set_gemm_mode(vasr_handle* h, int mode) {
-  if (!h || mode < 0 || mode > 1) return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA) or 1 (3 x bf16 split)");
+  if (!h || mode < 0 || mode > 2)
+    return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA), 1 (3 x bf16 split) or 2 (2 x bf16 split, reduced)");
   h->gemm_mode = mode;
   return 0;
 }
