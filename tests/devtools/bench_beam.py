@@ -43,3 +43,19 @@ for bw in (16, 128):
     for _ in range(3): dec.decode_ids(logp, bw)
     torch.cuda.synchronize()
     print(f"beam_width {bw} + 2-gram LM ({len(words)} words): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per batch of 64 x 501 frames")
+
+# peaky posteriors (what a trained CTC model emits: one or two classes above token_min_logp per frame)
+def peaky(T, V1, seed, k=4.0):
+    r = np.random.RandomState(seed)
+    z = r.randn(T, V1) * k
+    z[:, -1] += 2.0; z[:, 0] += 1.0
+    return (z - np.log(np.exp(z).sum(1, keepdims=True))).astype(np.float32)
+lp = torch.from_numpy(np.stack([peaky(501, 29, b) for b in range(64)])).cuda()
+for use_lm in (False, True):
+    dec = BeamSearchDecoder(cfg["labels"], lm_path=path if use_lm else None, alpha=0.5, beta=1.5)
+    for bw in (16, 128):
+        dec.decode_ids(lp, bw); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): dec.decode_ids(lp, bw)
+        torch.cuda.synchronize()
+        print(f"peaky posteriors, beam_width {bw}{' + LM' if use_lm else ''}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per batch of 64 x 501 frames")

@@ -206,6 +206,18 @@ __device__ inline unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+__device__ inline unsigned wave_or_u32(unsigned v) {
+  const int lane = threadIdx.x & 63, rl = lane & 15;
+  unsigned x = v, t;
+  t = (unsigned)dpp_mov<0x111>((int)x); if (rl >= 1) x |= t;
+  t = (unsigned)dpp_mov<0x112>((int)x); if (rl >= 2) x |= t;
+  t = (unsigned)dpp_mov<0x114>((int)x); if (rl >= 4) x |= t;
+  t = (unsigned)dpp_mov<0x118>((int)x); if (rl >= 8) x |= t;
+  t = (unsigned)dpp_mov<0x142>((int)x); if ((lane & 31) >= 16) x |= t;
+  t = (unsigned)dpp_mov<0x143>((int)x); if (lane >= 32) x |= t;
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // max of a signed 64-bit value over the wavefront: high words first, then the low words of the lanes that tie
 __device__ inline long long wave_max_i64(long long v) {
   const unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ull;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     // log(clip(exp(x), 1e-15, 1)) = clip(x, log 1e-15, 0): the same value without two fp64 transcendentals
     // Wavefront 0 owns the log-probs (two classes per lane) and picks the candidates while the others clear the merge
     // table: one barrier for both.
-    if (tid == 0) *best = ord64(-1e300);
+    if (tid == 0) { best[0] = ord64(-1e300); best[1] = 0; }   // running max; OR of (key ^ best key) over the live keys
     if (tid < 256) hist[tid] = 0;
 #pragma unroll
     for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.mx[i] = ord64(-1e300); sl.sum[i] = 0; }
@@ -440,13 +452,25 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     unsigned long long prefix = 0, mask = 0;
     int want = beam_width;   // how many still to take among keys matching the prefix
     {
+      // Scores of live beams lie within beam_prune_logp of the best, so their keys share the sign, the exponent and
+      // usually the top mantissa bits: the leading digits all keys have in common are skipped instead of costing a
+      // pass each.  The OR of (key ^ best key) tells where they first differ; it rides on the barrier of the scan.
+      const unsigned long long ubest = (unsigned long long)*best ^ 0x8000000000000000ull;
+      unsigned long long d = 0;
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) d |= (live >> j & 1) ? (u8[j] ^ ubest) : 0ull;
+      d = ((unsigned long long)wave_or_u32((unsigned)(d >> 32)) << 32) | wave_or_u32((unsigned)d);
+      if ((tid & 63) == 0 && d) atomicOr(reinterpret_cast<unsigned long long*>(best + 1), d);
       int tot_live;
       block_scan_excl(__popc(live), misc + 16, &tot_live, flip);
       if (tot_live > beam_width) {
+        const unsigned long long diff = (unsigned long long)best[1];
+        const int same = diff ? __clzll((long long)diff) / 8 : 8;       // leading bytes common to every live key
+        if (same > 0) { mask = ~0ull << (64 - 8 * same); if (same == 8) mask = ~0ull; prefix = ubest & mask; }
 #pragma unroll 1
         // three barriers per digit: the histogram is all zero on entry (cleared with the table at the top of the frame)
         // and every thread re-zeroes its own bin right after reading it
-        for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
 #pragma unroll
           for (int j = 0; j < kSpt; ++j)
             if ((live >> j & 1) && (u8[j] & mask) == prefix) atomicAdd(&hist[(int)((u8[j] >> shift) & 255)], 1);
