@@ -96,6 +96,65 @@ def test_argument_and_lifecycle_errors():
     with pytest.raises(RuntimeError):
         srv.submit(np.ones(3, dtype=np.float32))
 
+class _FakePending:
+    def __init__(self, signals, log):
+        self._s, self._log = signals, log
+
+    def texts(self):
+        time.sleep(0.002)
+        self._log.append(("done", len(self._s)))
+        return [f"{len(x)}:{float(x[0]):.1f}" for x in self._s]
+
+
+def test_pipelined_mode_launches_ahead_and_completes_in_order():
+    log = []
+
+    def launch(signals):
+        log.append(("launch", len(signals)))
+        return _FakePending(signals, log)
+
+    with BatchingTranscriber(launch_batch=launch, max_batch=2, max_wait_ms=50.0) as srv:
+        futs = [srv.submit(np.full(8, float(i), np.float32)) for i in range(6)]
+        got = [f.result(10) for f in futs]
+    assert got == [f"8:{float(i):.1f}" for i in range(6)]
+    assert [e for e in log if e[0] == "launch"] and sum(n for k, n in log if k == "done") == 6
+    with pytest.raises(ValueError):
+        BatchingTranscriber(lambda s: s, launch_batch=launch)
+    with pytest.raises(ValueError):
+        BatchingTranscriber()
+
+
+def test_pipelined_mode_failures_reach_the_requests():
+    class Bad:
+        def texts(self):
+            raise RuntimeError("device lost")
+
+    def launch(signals):
+        if len(signals[0]) == 3:
+            raise ValueError("refused at launch")
+        return Bad()
+
+    with BatchingTranscriber(launch_batch=launch, max_batch=4, max_wait_ms=5.0) as srv:
+        a = srv.submit(np.ones(3, np.float32))
+        b = srv.submit(np.ones(5, np.float32))
+        with pytest.raises(ValueError, match="refused at launch"):
+            a.result(10)
+        with pytest.raises(RuntimeError, match="device lost"):
+            b.result(10)
+
+
+def test_int16_pcm_requests_stay_int16():
+    seen = []
+
+    def fn(signals):
+        seen.extend(s.dtype for s in signals)
+        return [""] * len(signals)
+
+    with BatchingTranscriber(fn, max_batch=4, max_wait_ms=5.0) as srv:
+        srv.transcribe(np.ones(4, np.int16), timeout=10)
+        srv.transcribe(np.ones(4, np.float64), timeout=10)
+    assert seen == [np.dtype(np.int16), np.dtype(np.float32)]
+
 
 @pytest.mark.gpu
 def test_served_answers_equal_unbatched_transcribe_on_device():
@@ -115,3 +174,36 @@ def test_served_answers_equal_unbatched_transcribe_on_device():
         served = [f.result(120) for f in futs]
     assert served == alone
     assert max(srv.stats["device_calls_by_size"]) >= 2      # the equal-length requests went out together
+
+@pytest.mark.gpu
+def test_pipelined_launch_equals_blocking_transcribe_and_int16_equals_float():
+    import torch
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    assert torch.cuda.is_available()
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 5))
+    rng = np.random.default_rng(11)
+    batches = []
+    for k in range(5):                       # more batches than staging slots, different shapes: buffers get reused and regrown
+        lens = rng.integers(8000, 20000 + 6000 * k, size=3 + k)
+        batches.append([rng.integers(-3000, 3000, size=int(n)).astype(np.int16) for n in lens])
+    as_float = [[s.astype(np.float32) / 32768.0 for s in b] for b in batches]
+    want = []
+    for b in as_float:                        # reference: one blocking device call per batch, plain tensors
+        lens = torch.tensor([len(s) for s in b], device="cuda")
+        wav = torch.zeros((len(b), int(lens.max())), device="cuda")
+        for i, s in enumerate(b):
+            wav[i, : len(s)] = torch.from_numpy(s).cuda()
+        r = eng.forward(wav, lens)
+        want.append(eng.texts(r["ids"], r["id_len"]))
+    pend = [eng.launch(b) for b in batches]             # int16, all enqueued before any result is read
+    assert [p.texts() for p in pend] == want
+    pend = [eng.launch(b) for b in as_float]
+    assert [p.texts() for p in reversed(pend)] == want[::-1]
+    with BatchingTranscriber(launch_batch=eng.launch, max_batch=8, max_wait_ms=100.0, policy="padded",
+                             max_pad_ratio=1e9) as srv:
+        futs = [srv.submit(s) for s in batches[2]]
+        served = [f.result(120) for f in futs]
+    assert served == want[2]

@@ -4,6 +4,8 @@ This is what bench.py times and what ``VietASR.transcribe_batch`` uses.  It exis
 to* the per-module NeuralModule classes in asr.py (same kernels, port tensors materialised);
 both sit on libvasr_hip.so.  PyTorch is used for device memory and streams only.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -62,6 +64,7 @@ class QuartzNetCTC:
             if gemm is not None:
                 self.handle.set_gemm_mode(gemm)
         self._ws = None
+        self._slots, self._copy_stream, self._launched = None, None, 0
 
     # -- shapes
     def frames(self, samples):
@@ -108,14 +111,115 @@ class QuartzNetCTC:
         return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]
 
     def transcribe(self, signals):
-        """List of 1-D float arrays (16 kHz) -> list of strings; zero-pad-to-max collate
+        """List of 1-D arrays (model sample rate; float, or int16 PCM) -> list of strings; zero-pad-to-max collate
         (parts/dataset.py:14-53)."""
-        lens = np.array([len(s) for s in signals], dtype=np.int64)
-        L = int(lens.max())
-        batch = np.zeros((len(signals), L), dtype=np.float32)
-        for i, s in enumerate(signals):
-            batch[i, : len(s)] = np.asarray(s, dtype=np.float32)
-        wav = torch.from_numpy(batch).to(self.device)
-        ln = torch.from_numpy(lens).to(self.device)
-        r = self.forward(wav, ln)
-        return self.texts(r["ids"], r["id_len"])
+        return self.launch(signals).texts()
+
+    # -- pipelined host path: pinned staging, copies on their own stream, two batches in flight
+    def launch(self, signals):
+        """Enqueue one batch and return at once; ``.texts()`` of the returned PendingBatch waits for it.
+
+        Two staging slots alternate: while batch k computes, batch k+1 is collated into pinned memory and its
+        host->device copy runs on a separate stream (``torch.from_numpy(x).to(device)`` from pageable memory costs
+        more than the whole forward pass of a 64 x 10 s batch).  int16 PCM signals cross PCIe as int16 and are scaled
+        by 2^-15 on the device (segment.py:61-74) -- half the bytes, same floats.
+        """
+        if len(signals) == 0:
+            raise ValueError("empty batch")
+        if self._slots is None:
+            self._slots = [_Slot(self), _Slot(self)]
+            self._copy_stream = torch.cuda.Stream(self.device)
+        slot = self._slots[self._launched % 2]
+        self._launched += 1
+        return slot.launch(signals)
+
+
+class PendingBatch:
+    """Result handle of QuartzNetCTC.launch()."""
+
+    def __init__(self, slot, batch, frames):
+        self._slot, self._batch, self._frames = slot, batch, frames
+        self._lock = threading.Lock()
+        self._texts = None
+
+    def done(self):
+        return self._texts is not None or self._slot.ev_out.query()
+
+    def texts(self):
+        with self._lock:
+            if self._texts is None:
+                s, B, t1 = self._slot, self._batch, self._frames
+                s.ev_out.synchronize()
+                ids = s.pin_ids[: B * t1].view(B, t1).numpy()
+                n = s.pin_idlen[:B].numpy()
+                labels = s.eng.labels
+                self._texts = ["".join(labels[c] for c in ids[b, : n[b]]) for b in range(B)]
+                s.pending = None
+            return self._texts
+
+
+class _Slot:
+    """Pinned staging + device input buffers of one in-flight batch (grown on demand, never shrunk)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.pin = self.dev = self.dev_f32 = None
+        self.pin_len = self.dev_len = None
+        self.pin_ids = self.pin_idlen = None
+        self.out = None               # device outputs of the batch in flight (kept alive until its results are read)
+        self.pending = None
+        self.ev_h2d = torch.cuda.Event()
+        self.ev_out = torch.cuda.Event()
+
+    def _reserve(self, B, nbytes, t1, pcm16):
+        dev = self.eng.device
+        if self.pin is None or self.pin.numel() < nbytes:
+            self.pin = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+            self.dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if pcm16 and (self.dev_f32 is None or self.dev_f32.numel() < nbytes // 2):
+            self.dev_f32 = torch.empty(nbytes // 2, dtype=torch.float32, device=dev)
+        if self.pin_len is None or self.pin_len.numel() < B:
+            self.pin_len = torch.empty(B, dtype=torch.int64, pin_memory=True)
+            self.dev_len = torch.empty(B, dtype=torch.int64, device=dev)
+            self.pin_idlen = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        if self.pin_ids is None or self.pin_ids.numel() < B * t1:
+            self.pin_ids = torch.empty(B * t1, dtype=torch.int32, pin_memory=True)
+
+    def launch(self, signals):
+        eng = self.eng
+        if self.pending is not None:
+            self.pending.texts()          # the slot's previous batch: fetch before its buffers are overwritten
+        B = len(signals)
+        lens = [len(s) for s in signals]
+        L = max(lens)
+        if min(lens) == 0:
+            raise ValueError("empty signal in batch")
+        pcm16 = all(getattr(s, "dtype", None) == np.int16 for s in signals)
+        dtype, item = (torch.int16, 2) if pcm16 else (torch.float32, 4)
+        nbytes = B * L * item
+        _, t1 = eng.frames(L)
+        with torch.cuda.device(eng.device):
+            self.ev_out.synchronize()     # batch k-2 has left the device buffers
+            self._reserve(B, nbytes, t1, pcm16)
+            host = self.pin[:nbytes].view(dtype).view(B, L).numpy()
+            for i, s in enumerate(signals):
+                host[i, : lens[i]] = s
+                host[i, lens[i]:] = 0
+            self.pin_len[:B] = torch.tensor(lens, dtype=torch.int64)
+            comp = torch.cuda.current_stream(eng.device)
+            with torch.cuda.stream(eng._copy_stream):
+                self.dev[:nbytes].copy_(self.pin[:nbytes], non_blocking=True)
+                self.dev_len[:B].copy_(self.pin_len[:B], non_blocking=True)
+                self.ev_h2d.record(eng._copy_stream)
+            comp.wait_event(self.ev_h2d)
+            wav = self.dev[:nbytes].view(dtype).view(B, L)
+            if pcm16:
+                f32 = self.dev_f32[: B * L].view(B, L)
+                _lib.check(_lib.lib().vasr_pcm16_to_f32(wav.data_ptr(), B * L, f32.data_ptr(), comp.cuda_stream))
+                wav = f32
+            self.out = eng.forward(wav, self.dev_len[:B], want_pred=False)
+            self.pin_ids[: B * t1].copy_(self.out["ids"].view(-1), non_blocking=True)
+            self.pin_idlen[:B].copy_(self.out["id_len"], non_blocking=True)
+            self.ev_out.record(comp)
+        self.pending = PendingBatch(self, B, t1)
+        return self.pending

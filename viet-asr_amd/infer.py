@@ -85,9 +85,22 @@ class VietASR:
             return post_process_predictions(evaluated[0], self.labels)[0]
         return evaluated[0][0]
 
-    def transcribe_batch(self, signals, sample_rate=None):
-        """Greedy transcripts of a list of 1-D signals through the fused one-call path."""
-        signals = [self._to_model_rate(s, sample_rate) for s in signals]
+    def _fused_engine(self):
         if self._fused is None:
             self._fused = QuartzNetCTC(self.model_definition, self.encoder.state_dict(), self.decoder.state_dict())
-        return self._fused.transcribe([np.asarray(s, dtype=np.float32) for s in signals])
+        return self._fused
+
+    def _batch_signals(self, signals, sample_rate):
+        rate = self.model_definition["AudioToMelSpectrogramPreprocessor"]["sample_rate"]
+        if sample_rate is None or int(sample_rate) == int(rate):
+            if all(getattr(s, "dtype", None) == np.int16 for s in signals):
+                return signals                      # int16 PCM goes to the device as it is (scaled there)
+        return [self._to_model_rate(s, sample_rate) for s in signals]
+
+    def transcribe_batch(self, signals, sample_rate=None):
+        """Greedy transcripts of a list of 1-D signals through the fused one-call path."""
+        return self._fused_engine().transcribe(self._batch_signals(signals, sample_rate))
+
+    def launch_batch(self, signals, sample_rate=None):
+        """Asynchronous ``transcribe_batch``: returns a handle at once, ``.texts()`` waits (engine.QuartzNetCTC.launch)."""
+        return self._fused_engine().launch(self._batch_signals(signals, sample_rate))

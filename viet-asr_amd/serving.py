@@ -17,6 +17,11 @@ padded frames are decoded, reflect padding sees the padded row), and the referen
   * ``policy="padded"`` merges anything up to ``max_batch`` / ``max_pad_ratio`` (zero-pad-to-max collate,
     parts/dataset.py:14-53): the reference's *batched* semantics, maximum throughput.
 Requests are taken in arrival order; a cycle waits at most ``max_wait_ms`` after its first request.
+
+Pipelining.  With ``launch_batch=vietasr.launch_batch`` (returns at once with a handle whose ``.texts()`` waits) the
+worker collates and enqueues the next group while the device still runs the previous one, and a second thread
+completes the futures: the host side of a batch (collate into pinned memory, PCIe, ids -> str) overlaps the kernels
+instead of adding to them.  ``tools/bench_serving.py`` measures both.
 """
 import queue
 import threading
@@ -27,12 +32,16 @@ import numpy as np
 
 
 class BatchingTranscriber:
-    def __init__(self, transcribe_batch, max_batch=64, max_wait_ms=4.0, policy="exact", max_pad_ratio=1.25):
+    def __init__(self, transcribe_batch=None, max_batch=64, max_wait_ms=4.0, policy="exact", max_pad_ratio=1.25,
+                 launch_batch=None):
         if policy not in ("exact", "padded"):
             raise ValueError(f"policy must be 'exact' or 'padded', got {policy!r}")
         if max_batch < 1:
             raise ValueError("max_batch must be >= 1")
+        if (transcribe_batch is None) == (launch_batch is None):
+            raise ValueError("give exactly one of transcribe_batch and launch_batch")
         self._fn = transcribe_batch
+        self._launch = launch_batch
         self.max_batch = int(max_batch)
         self.max_wait = float(max_wait_ms) / 1e3
         self.policy = policy
@@ -40,6 +49,11 @@ class BatchingTranscriber:
         self._q = queue.Queue()
         self._closed = False
         self.stats = {"requests": 0, "batches": 0, "device_calls_by_size": {}}
+        self._inflight = queue.Queue(maxsize=2)      # (futures, pending handle): the engine holds two batches
+        self._finisher = None
+        if launch_batch is not None:
+            self._finisher = threading.Thread(target=self._finish, name="vasr-finisher", daemon=True)
+            self._finisher.start()
         self._worker = threading.Thread(target=self._run, name="vasr-batcher", daemon=True)
         self._worker.start()
 
@@ -47,7 +61,8 @@ class BatchingTranscriber:
     def submit(self, audio_signal):
         if self._closed:
             raise RuntimeError("BatchingTranscriber is closed")
-        sig = np.ascontiguousarray(audio_signal, dtype=np.float32)
+        sig = np.asarray(audio_signal)
+        sig = np.ascontiguousarray(sig, dtype=np.int16 if sig.dtype == np.int16 else np.float32)
         if sig.ndim != 1 or sig.size == 0:
             raise ValueError("audio_signal must be a non-empty 1-D array")
         fut = Future()
@@ -62,6 +77,9 @@ class BatchingTranscriber:
             self._closed = True
             self._q.put(None)
             self._worker.join()
+            if self._finisher is not None:
+                self._inflight.put(None)
+                self._finisher.join()
 
     def __enter__(self):
         return self
@@ -105,6 +123,27 @@ class BatchingTranscriber:
             groups.append(cur)
         return groups
 
+    def _resolve(self, futs, get_texts):
+        try:
+            texts = get_texts()
+            if len(texts) != len(futs):
+                raise RuntimeError(f"the engine returned {len(texts)} results for {len(futs)} signals")
+        except BaseException as e:   # noqa: BLE001 -- the request threads must see the failure
+            for f in futs:
+                f.set_exception(e)
+            return
+        by = self.stats["device_calls_by_size"]
+        by[len(futs)] = by.get(len(futs), 0) + 1
+        for f, t in zip(futs, texts):
+            f.set_result(t)
+
+    def _finish(self):
+        while True:
+            job = self._inflight.get()
+            if job is None:
+                return
+            self._resolve(job[0], job[1].texts)
+
     def _run(self):
         while True:
             items = self._collect()
@@ -114,15 +153,14 @@ class BatchingTranscriber:
             self.stats["batches"] += 1
             for grp in self.plan([len(s) for s, _ in items]):
                 futs = [items[i][1] for i in grp]
+                sigs = [items[i][0] for i in grp]
+                if self._launch is None:
+                    self._resolve(futs, lambda: self._fn(sigs))
+                    continue
                 try:
-                    texts = self._fn([items[i][0] for i in grp])
-                    if len(texts) != len(grp):
-                        raise RuntimeError(f"transcribe_batch returned {len(texts)} results for {len(grp)} signals")
-                except BaseException as e:   # noqa: BLE001 -- the request threads must see the failure
+                    pending = self._launch(sigs)
+                except BaseException as e:   # noqa: BLE001
                     for f in futs:
                         f.set_exception(e)
                     continue
-                by = self.stats["device_calls_by_size"]
-                by[len(grp)] = by.get(len(grp), 0) + 1
-                for f, t in zip(futs, texts):
-                    f.set_result(t)
+                self._inflight.put((futs, pending))
