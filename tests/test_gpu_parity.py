@@ -307,3 +307,45 @@ def test_reduced_bf16x2_mode_is_opt_in_and_stays_inside_the_tolerance(gpu, name)
     default = _engine(cfg, enc_sd, dec_sd)          # the library default is NOT this mode
     rd = default.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
     assert np.abs(rd["logp"].cpu().numpy() - g["logp"]).max() <= np.abs(r["logp"].cpu().numpy() - g["logp"]).max() + 1e-6
+
+
+def _random_architecture(rng):
+    """A JasperEncoder block list inside what the library accepts (filters % 128 == 0, dense convs 1x1 only, stride
+    only on a residual-free block), with kernel sizes, repeats, dilation and residuals the builtin models do not use."""
+    def blk(filters, kernel, repeat, stride=1, dilation=1, residual=False, separable=True):
+        return dict(filters=int(filters), repeat=int(repeat), kernel=[int(kernel)], stride=[int(stride)],
+                    dilation=[int(dilation)], dropout=0.0, residual=bool(residual), separable=bool(separable))
+    odd = lambda lo, hi: int(rng.integers(lo // 2, hi // 2 + 1)) * 2 + 1
+    blocks = [blk(rng.choice([128, 256]), odd(3, 41), rng.integers(1, 3), stride=rng.choice([1, 2]))]
+    for _ in range(int(rng.integers(1, 4))):
+        blocks.append(blk(rng.choice([128, 256, 384, 512]), odd(3, 99), rng.integers(1, 4), residual=rng.random() < 0.6))
+    blocks.append(blk(rng.choice([128, 256]), odd(3, 91), 1, dilation=2))
+    blocks.append(blk(rng.choice([128, 384]), 1, 1, separable=False))
+    return blocks
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_architectures_and_shapes_match_oracle(gpu, seed):
+    import copy
+    from viet_asr_amd import configs, synth
+    rng = np.random.default_rng(1000 + seed)
+    cfg = copy.deepcopy(configs.builtin("quartznet15x5"))
+    jas = cfg["JasperEncoder"]["jasper"] = _random_architecture(rng)
+    enc_sd = synth.encoder_state_dict(jas, 64, seed)
+    dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    B, L = int(rng.integers(1, 6)), int(rng.integers(1500, 30000))
+    sig, lens = synth.audio_batch(B, L, seed, ragged=True)
+    lens[int(rng.integers(0, B))] = L                        # the collate pads to the longest row
+    lens[int(rng.integers(0, B))] = max(300, lens.min() // 3)
+    for b in range(B):
+        sig[b, lens[b]:] = 0
+    ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
+    r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
+    lp, want = r["logp"].cpu(), ref["logp"]
+    assert lp.shape == want.shape, (jas, B, L)
+    assert (lp - want).abs().max() <= LOGP_TOL, (float((lp - want).abs().max()), jas, B, L)
+    assert r["enc_len"].cpu().tolist() == ref["enc_len"].tolist()
+    top2 = want.topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL    # random weights: near-ties may flip inside the tolerance
+    assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
