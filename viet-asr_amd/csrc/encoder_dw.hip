@@ -409,21 +409,31 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
 // (lens + 2p - d(K-1) - 1) / stride + 1 as a FLOAT tensor (quirk Q3).
 __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, const LenStep* __restrict__ steps,
                                  int n_steps, int32_t* __restrict__ lens_tab, float* __restrict__ enc_len) {
-  // the chain is serial per utterance; the step table goes through LDS once so that an iteration costs an LDS read
-  // instead of a dependent global load (33 us -> 3 us for the 77 steps of QuartzNet15x5)
+  // The chain is serial per utterance and one wavefront runs it alone, so its cost is the length of the dependent
+  // instruction sequence of one iteration: the step table goes through LDS once (no dependent global load, and no
+  // vector-memory wait inside the loop), the arithmetic is 32-bit (frame counts are far below 2^24, where the
+  // int64 <-> float conversions -- software sequences on this ISA -- and the int32 ones give the same values), and
+  // x / 1.0f is skipped for the stride-1 steps.
   __shared__ LenStep sh_steps[256];
   for (int s = threadIdx.x; s < n_steps && s < 256; s += blockDim.x) sh_steps[s] = steps[s];
   __syncthreads();
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  float lf = (float)seq[b];
-  int64_t li = seq[b];
-  for (int s = 0; s < n_steps; ++s) {
-    if (s > 0) li = (int64_t)lf;  // .to(dtype=torch.long): truncation
-    lens_tab[(int64_t)s * batch + b] = (int32_t)li;
-    const LenStep st = s < 256 ? sh_steps[s] : steps[s];
-    lf = (float)(li + 2 * st.pad - st.dilation * (st.kernel - 1) - 1) / (float)st.stride + 1.0f;
-  }
+  const int64_t l0 = seq[b];
+  int32_t li = (int32_t)(l0 > 0x7fffff00 ? 0x7fffff00 : l0);
+  float lf = (float)li;
+  auto advance = [&](int s, const LenStep st) {
+    if (s > 0) li = (int32_t)lf;  // .to(dtype=torch.long): truncation
+    lens_tab[(int64_t)s * batch + b] = li;
+    lf = (float)(li + 2 * st.pad - st.dilation * (st.kernel - 1) - 1);
+    if (st.stride != 1) lf = lf / (float)st.stride;
+    lf += 1.0f;
+  };
+  // two loops, not one with `s < 256 ? sh_steps[s] : steps[s]`: that select becomes a flat load, whose wait
+  // (vmcnt(0)) also waits for the previous iteration's store to complete -- 660 cycles per step instead of ~60
+  const int n_lds = n_steps < 256 ? n_steps : 256;
+  for (int s = 0; s < n_lds; ++s) advance(s, sh_steps[s]);
+  for (int s = n_lds; s < n_steps; ++s) advance(s, steps[s]);
   lens_tab[(int64_t)n_steps * batch + b] = (int32_t)(int64_t)lf;
   if (enc_len) enc_len[b] = lf;
 }
