@@ -5,7 +5,7 @@
 //
 // One workgroup = 32 consecutive frames of one utterance.  The 5472-sample window those
 // frames cover is staged ONCE into LDS with coalesced loads (62.5 % frame overlap is served
-// from LDS, not HBM); each of the 4 wavefronts then runs 8 real 512-point FFTs as a
+// from LDS, not HBM); each of the 8 wavefronts then runs 4 real 512-point FFTs as a
 // 256-point complex radix-4 Stockham FFT (4 LDS-exchanged stages, 4 points per lane) and the
 // even/odd split.  The 64 mel filters map one-per-lane; the [64 mel][32 frame] tile goes
 // back to HBM as 128-byte row segments.
@@ -16,7 +16,9 @@ namespace vasr {
 namespace {
 
 constexpr int kFramesPerBlock = 32;
-constexpr int kFramesPerWave = 8;
+constexpr int kWaves = 8;                       // 4 wavefronts x 8 frames left the LDS round trips of a frame exposed
+constexpr int kThreads = 64 * kWaves;
+constexpr int kFramesPerWave = kFramesPerBlock / kWaves;
 constexpr int kNfft = 512;
 
 struct cf { float re, im; };
@@ -34,32 +36,43 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// grid (ceil(T/32), B), block 256
-__global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
+// grid (ceil(T/32), B), block kThreads
+__global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
                                                           int64_t samples, int hop, float preemph,
                                                           float log_guard, float* __restrict__ mel,
                                                           int64_t mel_ld, int frames) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int seg_len = (kFramesPerBlock - 1) * hop + kNfft;
   float* seg = smem;                                   // [seg_len]
-  float* win = seg + ((seg_len + 3) & ~3);             // [512]
-  cf* tw256 = reinterpret_cast<cf*>(win + kNfft);      // [256]
-  cf* tw512 = tw256 + 256;                             // [257] (+1 pad)
-  cf* fftbuf = tw512 + 258;                            // [4 waves][2][256]
-  float* pbuf = reinterpret_cast<float*>(fftbuf + 4 * 2 * 256);  // [4 waves][257 + kMelTaps] power spectrum
-  float* tile = pbuf + 4 * (260 + kMelTaps);           // [64][33]
+  cf* fftbuf = reinterpret_cast<cf*>(seg + ((seg_len + 3) & ~3));     // [kWaves][256], the stages run in place
+  float* pbuf = reinterpret_cast<float*>(fftbuf + kWaves * 256);      // [kWaves][257 + kMelTaps] power spectrum
+  float* tile = pbuf + kWaves * (260 + kMelTaps);      // [64][33]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFramesPerBlock;
   const float* x = wav + (int64_t)b * samples;
 
-  // ---- stage tables + the pre-emphasised, reflect-padded segment ----
-  for (int i = tid; i < kNfft; i += 256) win[i] = tb.window[i];
-  for (int i = tid; i < 256; i += 256) tw256[i] = {tb.tw256[2 * i], tb.tw256[2 * i + 1]};
-  for (int i = tid; i < 257; i += 256) tw512[i] = {tb.tw512[2 * i], tb.tw512[2 * i + 1]};
+  // ---- window and twiddles: a lane needs the same few entries for every frame, so they live in registers ----
+  const float2* win2 = reinterpret_cast<const float2*>(tb.window);
+  const float2* t256 = reinterpret_cast<const float2*>(tb.tw256);
+  const float2* t512 = reinterpret_cast<const float2*>(tb.tw512);
+  float2 wn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wn[r] = win2[lane + 64 * r];
+  cf tws[3][3];     // stage Ns = 4, 16, 64: w^step, w^2step, w^3step
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int Ns = 4 << (2 * g), step = (lane & (Ns - 1)) * (64 / Ns);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { const float2 w = t256[(m + 1) * step]; tws[g][m] = {w.x, w.y}; }
+  }
+  cf twk[5];        // real-FFT split: e^{-2 pi i k/512} for k = lane + 64 i
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { const float2 w = t512[min(lane + 64 * i, 256)]; twk[i] = {w.x, w.y}; }
+  // ---- stage the pre-emphasised, reflect-padded segment ----
   const int64_t p0 = (int64_t)f0 * hop - kNfft / 2;  // sample index of seg[0] before reflection
-  for (int i = tid; i < seg_len; i += 256) {
+  for (int i = tid; i < seg_len; i += kThreads) {
     int64_t n = p0 + i;
     if (n < 0) n = -n;                       // torch.stft(center=True, pad_mode="reflect"), features.py:181-188
     if (n >= samples) n = 2 * (samples - 1) - n;
@@ -80,8 +93,9 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
   for (int i = lane; i < 260 + kMelTaps; i += 64) P[i] = 0.f;
   __syncthreads();
 
-  cf* bufA = fftbuf + wave * 512;
-  cf* bufB = bufA + 256;
+  // One buffer per wavefront: a stage reads its four points per lane into registers before any lane writes (the
+  // wavefront executes the reads as one instruction stream ahead of the writes), so the exchange can be in place.
+  cf* buf = fftbuf + wave * 256;
 
   for (int jf = 0; jf < kFramesPerWave; ++jf) {
     const int fl = wave * kFramesPerWave + jf;  // frame within block
@@ -92,46 +106,47 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = lane + 64 * r;
-        v[r] = {s[2 * q] * win[2 * q], s[2 * q + 1] * win[2 * q + 1]};
+        v[r] = {s[2 * q] * wn[r].x, s[2 * q + 1] * wn[r].y};
       }
       cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = cmul_negi(csub(v[1], v[3]));
-      bufA[4 * lane + 0] = cadd(t0, t2);
-      bufA[4 * lane + 1] = cadd(t1, t3);
-      bufA[4 * lane + 2] = csub(t0, t2);
-      bufA[4 * lane + 3] = csub(t1, t3);
+      buf[4 * lane + 0] = cadd(t0, t2);
+      buf[4 * lane + 1] = cadd(t1, t3);
+      buf[4 * lane + 2] = csub(t0, t2);
+      buf[4 * lane + 3] = csub(t1, t3);
     }
     wave_fence();
-    cf* in = bufA;
-    cf* out = bufB;
 #pragma unroll
-    for (int Ns = 4; Ns < 256; Ns *= 4) {
+    for (int g = 0; g < 3; ++g) {
+      const int Ns = 4 << (2 * g);
       const int k = lane & (Ns - 1);
       cf v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = in[lane + 64 * r];
-      const int step = k * (64 / Ns);
-      v[1] = cmul(v[1], tw256[step]);
-      v[2] = cmul(v[2], tw256[2 * step]);
-      v[3] = cmul(v[3], tw256[3 * step]);
+      for (int r = 0; r < 4; ++r) v[r] = buf[lane + 64 * r];
+      wave_fence();
+      v[1] = cmul(v[1], tws[g][0]);
+      v[2] = cmul(v[2], tws[g][1]);
+      v[3] = cmul(v[3], tws[g][2]);
       cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = cmul_negi(csub(v[1], v[3]));
       const int j0 = (lane / Ns) * Ns * 4 + k;
-      out[j0] = cadd(t0, t2);
-      out[j0 + Ns] = cadd(t1, t3);
-      out[j0 + 2 * Ns] = csub(t0, t2);
-      out[j0 + 3 * Ns] = csub(t1, t3);
+      buf[j0] = cadd(t0, t2);
+      buf[j0 + Ns] = cadd(t1, t3);
+      buf[j0 + 2 * Ns] = csub(t0, t2);
+      buf[j0 + 3 * Ns] = csub(t1, t3);
       wave_fence();
-      cf* t = in; in = out; out = t;
     }
     // ---- real-FFT split + power spectrum (features.py:260-263 pow(2).sum(-1)) ----
-    const cf* Z = in;
-    for (int k = lane; k <= 256; k += 64) {
+    const cf* Z = buf;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = lane + 64 * i;
+      if (k > 256) break;
       cf zk = Z[k & 255];
       cf zc = Z[(256 - k) & 255];
       zc.im = -zc.im;
       cf e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
       cf d = {zk.re - zc.re, zk.im - zc.im};
       cf o = {0.5f * d.im, -0.5f * d.re};  // -i/2 * d
-      cf xk = cadd(e, cmul(tw512[k], o));
+      cf xk = cadd(e, cmul(twk[i], o));
       P[k] = xk.re * xk.re + xk.im * xk.im;
     }
     wave_fence();
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables tb, con
   }
   __syncthreads();
   // ---- [64][32] tile -> HBM rows ----
-  for (int idx = tid; idx < 64 * kFramesPerBlock; idx += 256) {
+  for (int idx = tid; idx < 64 * kFramesPerBlock; idx += kThreads) {
     const int f = idx / kFramesPerBlock, j = idx % kFramesPerBlock;
     const int t = f0 + j;
     if (t < frames) mel[((int64_t)b * 64 + f) * mel_ld + t] = tile[f * (kFramesPerBlock + 1) + j];
@@ -201,10 +216,10 @@ void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, i
                         float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st) {
   const int seg_len = (kFramesPerBlock - 1) * hop + kNfft;
-  size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kNfft * 4 + 256 * 8 + 258 * 8 + 4 * 2 * 256 * 8 +
-               4 * (260 + kMelTaps) * 4 + 64 * (kFramesPerBlock + 1) * 4;
+  size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kWaves * 256 * 8 + kWaves * (260 + kMelTaps) * 4 +
+               64 * (kFramesPerBlock + 1) * 4;
   dim3 grid((frames + kFramesPerBlock - 1) / kFramesPerBlock, batch);
-  hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(256), lds, st, tb, wav, samples, hop, preemph, log_guard,
+  hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(kThreads), lds, st, tb, wav, samples, hop, preemph, log_guard,
                      mel, mel_ld, frames);
 }
 
