@@ -59,3 +59,23 @@ for use_lm in (False, True):
         for _ in range(3): dec.decode_ids(lp, bw)
         torch.cuda.synchronize()
         print(f"peaky posteriors, beam_width {bw}{' + LM' if use_lm else ''}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per batch of 64 x 501 frames")
+
+# CTC-like posteriors: ~70 % of the frames are blank with p ~ 0.9999 (nothing else passes token_min_logp), the others carry
+# one dominant character and a couple of alternatives -- what a converged CTC model emits
+def ctc_like(T, V1, seed):
+    r = np.random.RandomState(seed)
+    z = r.randn(T, V1)
+    blank = r.rand(T) < 0.7
+    z[blank, -1] += 14.0
+    idx = np.where(~blank)[0]
+    z[idx, r.randint(0, V1 - 1, len(idx))] += 6.0
+    return (z - np.log(np.exp(z).sum(1, keepdims=True))).astype(np.float32)
+lp = torch.from_numpy(np.stack([ctc_like(501, 29, b) for b in range(64)])).cuda()
+for use_lm in (False, True):
+    dec = BeamSearchDecoder(cfg["labels"], lm_path=path if use_lm else None, alpha=0.5, beta=1.5)
+    for bw in (16, 128):
+        dec.decode_ids(lp, bw); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): dec.decode_ids(lp, bw)
+        torch.cuda.synchronize()
+        print(f"CTC-like posteriors, beam_width {bw}{' + LM' if use_lm else ''}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per batch of 64 x 501 frames")

@@ -141,3 +141,39 @@ def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (texts[b], ref[:2])
         if texts[b] == ref[0][0]:
             assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (float(score[b]), ref[0][2])
+
+
+def ctc_like_posteriors(T, V1, seed, p_blank=0.7):
+    """Long runs of frames where only blank clears token_min_logp, separated by frames with one dominant character and
+    a few alternatives: what a converged CTC model emits."""
+    r = np.random.RandomState(seed)
+    z = r.randn(T, V1)
+    blank = r.rand(T) < p_blank
+    z[blank, -1] += 14.0
+    idx = np.where(~blank)[0]
+    z[idx, r.randint(0, V1 - 1, len(idx))] += 6.0
+    z[idx[::5], 0] += 6.0                            # word boundaries, so that the LM is consulted
+    lp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    return lp.astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_lm", [False, True])
+@pytest.mark.parametrize("beam_width", [4, 32, 128])
+def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
+    """Blank-only frames on beams that all end in blank take an early exit in the kernel (scores shift, nothing else
+    changes); the first frame of every run must still merge beams that differ in their last character only."""
+    from viet_asr_amd.beam import BeamSearchDecoder
+    path, _ = toy_lm(str(tmp_path))
+    lp = np.stack([ctc_like_posteriors(120, 29, 300 + b, p_blank=(0.5, 0.7, 0.9, 1.0)[b]) for b in range(4)])
+    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    ids, n, score = dec.decode_ids(torch.from_numpy(lp).to(gpu), beam_width)
+    texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), beam_width)
+    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
+    for b in range(4):
+        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, beam_width, lm=lm, table_fill=1434,
+                              eos_ignores_cache=True)
+        close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
+        assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (b, texts[b], ref[:2])
+        if texts[b] == ref[0][0]:
+            assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (float(score[b]), ref[0][2])

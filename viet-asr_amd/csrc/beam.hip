@@ -281,6 +281,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     if (use_lm) s.ctx[kMaxCtx - 1] = lm.bos;
     beams[0] = s;
     misc[0] = 1;  // live beams
+    misc[9] = 0;  // not every live beam ends in blank
   }
   lds_barrier();
 
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     // Wavefront 0 owns the log-probs (two classes per lane) and picks the candidates while the others clear the merge
     // table: one barrier for both.
     if (tid == 0) { best[0] = ord64(-1e300); best[1] = 0; }   // running max; OR of (key ^ best key) over the live keys
+    const int all_blank = misc[9];   // every live beam ends in blank (set by the frame that built them)
     if (tid < 256) hist[tid] = 0;
 #pragma unroll
     for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.mx[i] = ord64(-1e300); sl.sum[i] = 0; }
@@ -350,6 +352,24 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     lds_barrier();
     const int nc = misc[1];
     BEAM_TICK(0)
+    // A frame whose only candidate is blank, met by beams that all end in blank already, changes nothing but the
+    // scores, and those by the same amount: prefixes and last characters stay distinct (no merge), the LM parts and
+    // every score difference stay what the previous frame's prune and selection saw.  A trained CTC model emits long
+    // runs of such frames; the first of a run goes the general way (beams that differ only in their last character
+    // merge there), the rest take this exit.  s.logit + lp is the sum the general path would have stored.
+#ifdef VASR_BEAM_NO_BLANK_EXIT   // dev build for A/B runs
+    if (false) {
+#else
+    if (nc == 1 && all_blank && cand[0] == V) {
+#endif
+      if (tid < nb) {
+        beams[tid].logit += lp[V];
+        bp[(int64_t)t * kMaxBeams + tid] = (unsigned)tid << 8;
+      }
+      lds_barrier();   // lp is rewritten by wavefront 0 at the top of the next frame
+      continue;
+    }
+    if (tid == 0) misc[9] = 1;   // cleared below by any new beam that ends in a character
     // ---- 2. expand: every (beam, character) pair claims / finds its slot and raises the slot's max, then (after a
     //         barrier) adds exp(score - max).  Deliberately NOT unrolled: the kernel must stay inside the 64 KB
     //         instruction cache it shares with the neighbouring CU (68 KB unrolled: every section fetch-bound). ----
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
         }
       }
       n.last = c;
+      if (c != V) misc[9] = 0;
       n.logit = __longlong_as_double(sel_lgt[tid]);
       nbeams[tid] = n;
       bp[(int64_t)t * kMaxBeams + tid] = ((unsigned)bi << 8) | appended;
@@ -568,6 +589,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   const int nb = misc[0];
   double* fin = lp;  // [kMaxBeams] combined score per beam
   unsigned long long* fkey = sl.key;  // [kMaxBeams]
+  double* frank = reinterpret_cast<double*>(sl.mx);   // [kMaxBeams]
   if (tid < nb) {
     const Beam& s = beams[tid];
     double total = s.logit;
@@ -579,11 +601,16 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     }
     fin[tid] = total;
     fkey[tid] = s.wlen > 0 ? hmix(s.key, (unsigned long long)space_id) : s.key;
+    // the beam's combined score of the last frame: pyctcdecode keeps its beams sorted by it, and that order decides
+    // below which member of a merged group provides the LM part
+    frank[tid] = s.logit + (use_lm ? (double)(s.lm_text + partial_penalty(lm.unk_offset, s.wlen)) : 0.0);
   }
   __syncthreads();
   if (tid == 0) {
-    // merge by text: log-sum-exp of the LOGIT scores is what pyctcdecode does; the LM part is per text.  Beams with the
-    // same final text share the LM score, so combine through the logit difference.
+    // Merge by text: log-sum-exp of the LOGIT scores, as pyctcdecode does.  "abc" with the word still pending and
+    // "abc " with it committed are the same final text but not the same LM part (only the pending word is scored with
+    // </s>): pyctcdecode's _merge_beams overwrites the group's entry with every further member it meets while walking
+    // its score-sorted beam list, so the member with the LOWEST last-frame score provides the LM part.
     int bi = 0;
     double bs = -1e300;
     for (int i = 0; i < nb; ++i) {
@@ -591,10 +618,12 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
       for (int j = 0; j < i; ++j) if (fkey[j] == fkey[i]) { first = false; break; }
       if (!first) continue;
       double m = beams[i].logit;
-      for (int j = i + 1; j < nb; ++j) if (fkey[j] == fkey[i]) m = fmax(m, beams[j].logit);
+      int rep = i;
+      for (int j = i + 1; j < nb; ++j)
+        if (fkey[j] == fkey[i]) { m = fmax(m, beams[j].logit); if (frank[j] < frank[rep]) rep = j; }
       double ssum = 0;
       for (int j = i; j < nb; ++j) if (fkey[j] == fkey[i]) ssum += exp(beams[j].logit - m);
-      const double merged = (fin[i] - beams[i].logit) + m + log(ssum);
+      const double merged = (fin[rep] - beams[rep].logit) + m + log(ssum);
       if (merged > bs) { bs = merged; bi = i; }
     }
     // trace back
