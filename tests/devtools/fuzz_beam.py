@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised device-vs-oracle beam search comparison (dev tool): python tests/devtools/fuzz_beam.py [n_cases] [seed0]."""
+import os, sys, tempfile, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import viet_asr_amd  # noqa
+from viet_asr_amd.beam import BeamSearchDecoder
+from oracle import beam_oracle as BO
+import test_beam as T
+
+tmp = tempfile.mkdtemp()
+toy, _ = T.toy_lm(tmp)
+# a second LM whose words the search can actually spell: everything over {a, b, c}
+rng = np.random.default_rng(7)
+words = sorted({"".join(rng.choice(list("abc"), rng.integers(1, 4))) for _ in range(40)})
+ng = {("<s>",): (-99.0, -0.4), ("</s>",): (-1.3, 0.0), ("<unk>",): (-2.2, 0.0)}
+for w in words:
+    ng[(w,)] = (float(-1.0 - rng.random()), float(-0.5 * rng.random()))
+for _ in range(120):
+    a, b = rng.choice(words, 2)
+    ng[(a, b)] = (float(-0.3 - rng.random()), float(-0.3 * rng.random()))
+for _ in range(60):
+    a, b, c = rng.choice(words, 3)
+    if (a, b) in ng:
+        ng[(a, b, c)] = (float(-0.2 - rng.random()), 0.0)
+for w in words[:10]:
+    ng[("<s>", w)] = (float(-0.5 - rng.random()), -0.1)
+    ng[(w, "</s>")] = (float(-0.4 - rng.random()), 0.0)
+abc = os.path.join(tmp, "abc.arpa")
+BO.write_arpa(abc, 3, ng)
+
+
+def small_alphabet(Tn, V1, seed, k):
+    r = np.random.RandomState(seed)
+    z = r.randn(Tn, V1) * k
+    z[:, [0, 1, 2, 3, V1 - 1]] += 5.0 + k          # ' ', a, b, c, blank
+    return (z - np.log(np.exp(z).sum(1, keepdims=True))).astype(np.float32)
+
+
+def run_case(case):
+    """None when device and oracle agree, else a description of the disagreement."""
+    r = np.random.RandomState(10_000 + case)
+    kind = r.randint(3)
+    Tn = int(r.randint(3, 140))
+    bw = int(r.choice([1, 2, 4, 16, 32, 64, 128]))
+    lm_kind = int(r.randint(3))            # none, toy, abc
+    alpha, beta = float(r.choice([0.3, 0.7, 1.2])), float(r.choice([0.0, 1.1, 2.5]))
+    if kind == 0:
+        lp = T.random_posteriors(Tn, 29, case, peaky=float(r.choice([0.7, 1.5, 4.0, 8.0])))
+    elif kind == 1:
+        lp = T.ctc_like_posteriors(Tn, 29, case, p_blank=float(r.choice([0.3, 0.6, 0.85, 1.0])))
+    else:
+        lp = small_alphabet(Tn, 29, case, float(r.choice([0.5, 1.0, 2.0])))
+    path = [None, toy, abc][lm_kind]
+    dec = BeamSearchDecoder(T.LABELS, lm_path=path, alpha=alpha, beta=beta)
+    x = torch.from_numpy(lp[None]).cuda()
+    ids, n, score = dec.decode_ids(x, bw)
+    text = dec.decode_batch(x, bw)[0]
+    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=alpha, beta=beta) if path else None
+    ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm, table_fill=1434, eos_ignores_cache=True)
+    close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
+    ok_text = text == ref[0][0] or (close and text == ref[1][0])
+    ok_score = (not ok_text) or text != ref[0][0] or abs(float(score[0]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50)
+    if ok_text and ok_score:
+        return None
+    mine = [q for q in ref if q[0] == text]
+    return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} a {alpha} b {beta}: device {text[-30:]!r} {float(score[0]):.4f} | "
+            f"oracle {ref[0][0][-30:]!r} {ref[0][2]:.4f} | oracle's score of the device text {[round(float(q[2]), 4) for q in mine][:1]}")
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0, bad = time.time(), 0
+    for case in range(S0, S0 + N):
+        msg = run_case(case)
+        if msg:
+            bad += 1
+            print("MISMATCH", msg, flush=True)
+    print(f"{N} cases, {bad} mismatches, {time.time() - t0:.0f} s")

@@ -177,3 +177,14 @@ def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (b, texts[b], ref[:2])
         if texts[b] == ref[0][0]:
             assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (float(score[b]), ref[0][2])
+
+
+@pytest.mark.gpu
+def test_device_beam_search_randomised_cases(gpu):
+    """Sixty cases of tests/devtools/fuzz_beam.py (posterior shape, length, beam width, LM and its weights all drawn at
+    random; 4 000 cases of it ran clean when this test was added)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    import fuzz_beam
+    bad = [m for m in (fuzz_beam.run_case(c) for c in range(60)) if m]
+    assert not bad, bad
