@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised device-vs-oracle check of the mel front end (dev tool): batch shapes, ragged lengths, hop multiples,
+rows shorter than the reflect padding, silent rows, loud rows."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import viet_asr_amd  # noqa
+from viet_asr_amd import _lib, configs, stages
+from viet_asr_amd.frontend_tables import frontend_description
+from oracle import quartznet_oracle as O
+
+cfg = configs.builtin("quartznet15x5")
+pre = dict(cfg["AudioToMelSpectrogramPreprocessor"])
+hp = _lib.Handle(frontend=frontend_description(pre))
+hp.finalize()
+hraw = _lib.Handle(frontend=frontend_description(dict(pre, normalize=None)))      # log-mel before normalisation
+hraw.finalize()
+
+
+def frontend_case(case, tol=2e-4):
+    r = np.random.RandomState(40_000 + case)
+    B = int(r.randint(1, 7))
+    L = int(r.choice([r.randint(257, 2000), r.randint(2000, 40000), 160 * r.randint(2, 200), 160 * r.randint(2, 200) + 1]))
+    lens = r.randint(2, L + 1, size=B).astype(np.int64)
+    lens[r.randint(B)] = L
+    if B > 1:
+        lens[r.randint(B)] = int(r.choice([2, 3, 159, 160, 161, 320, 321]))      # seq_len 1..3: NaN / tiny-sample statistics
+        lens[r.randint(B)] = max(2, (L // 160) * 160)                            # exact hop multiple (quirk Q2)
+        lens[int(np.argmax(lens))] = L
+    amp = float(r.choice([1e-4, 0.1, 0.9]))
+    x = np.zeros((B, L), dtype=np.float32)
+    for b in range(B):
+        x[b, : lens[b]] = (amp * r.randn(lens[b])).astype(np.float32)
+    if B > 2:
+        x[1] = 0.0                                                               # a silent row: log of the guard value
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
+    raw, seq = stages.melspec(hraw, xd, ld)
+    mel, _ = stages.melspec(hp, xd, ld)
+    wraw, wseq = O.melspec_forward(x, lens, normalize=None)
+    want, _ = O.melspec_forward(x, lens)
+    raw, mel, seq = raw.cpu(), mel.cpu(), seq.cpu()
+    if not torch.equal(seq, wseq):
+        return f"frontend case {case}: seq {seq.tolist()} vs {wseq.tolist()}"
+    if mel.shape != want.shape or raw.shape != wraw.shape:
+        return f"frontend case {case}: shape {tuple(mel.shape)} vs {tuple(want.shape)}"
+    # (1) log-mel before normalisation: bins far below the frame's energy carry the FFT's absolute rounding error, hence MEL_TOL
+    err = (raw - wraw).abs().max().item()
+    if err > tol:
+        return f"frontend case {case}: raw log-mel max err {err:.2e} (B {B} L {L} lens {lens.tolist()} amp {amp})"
+    # (2) normalised: (x - mean) / (std + 1e-5) turns an error e of x into e / std, and rows whose log-mel barely moves
+    # (digital silence: std = 0; bins under the log guard) have std << 1: the bound follows the row's own std
+    nan_w, nan_m = torch.isnan(want), torch.isnan(mel)
+    if not torch.equal(nan_w, nan_m):
+        return f"frontend case {case}: NaN pattern differs (B {B} L {L} lens {lens.tolist()})"
+    for b in range(B):
+        n = int(wseq[b])
+        if n < 2:
+            continue
+        std = wraw[b, :, :n].double().std(dim=1) + 1e-5
+        e_raw = (raw[b, :, :n] - wraw[b, :, :n]).abs().max(dim=1).values.double()      # what (1) let through for this bin
+        bound = (tol + (2 * e_raw + 4e-6) / std).float()[:, None]
+        bad = ((mel[b, :, :n] - want[b, :, :n]).abs() > bound)
+        if bad.any():
+            f, t = [int(v[0]) for v in torch.nonzero(bad)[0:1].T]
+            return (f"frontend case {case}: row {b} bin {f} frame {t}: {mel[b, f, t].item():.6f} vs {want[b, f, t].item():.6f}, "
+                    f"row std {std[f].item():.2e} (B {B} L {L} lens {lens.tolist()} amp {amp})")
+    masked = torch.arange(mel.shape[-1])[None, :] >= wseq[:, None]
+    if (mel.transpose(1, 2)[masked] != 0).any():
+        return f"frontend case {case}: masked frames not exactly zero"
+    return None
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    t0, bad = time.time(), 0
+    for case in range(N):
+        msg = frontend_case(case)
+        if msg:
+            bad += 1
+            print("MISMATCH", msg, flush=True)
+    print(f"{N} cases, {bad} mismatches, {time.time() - t0:.0f} s")

@@ -88,3 +88,26 @@ def test_pcm16_to_float_on_device(gpu):
     assert out.dtype == np.float32 and np.array_equal(out, pcm.cpu().numpy().astype(np.float32) / 32768.0)
     big = torch.randint(-32768, 32767, (3, 4001), dtype=torch.int16, device=gpu)
     assert torch.equal(audio.pcm16_to_float(big), big.float() / 32768.0)
+
+
+@pytest.mark.gpu
+def test_randomised_resampler_and_greedy_tail_cases(gpu):
+    """Forty cases each of tests/devtools/fuzz_audio.py: random rate pairs / batch shapes / ragged lengths through the
+    resampler, random shapes and class counts (with exact ties) through argmax + CTC collapse."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    import fuzz_audio
+    bad = [m for fn in (fuzz_audio.resample_case, fuzz_audio.greedy_case) for m in (fn(c) for c in range(40)) if m]
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_randomised_front_end_cases(gpu):
+    """Forty cases of tests/devtools/fuzz_frontend.py: batch shapes, ragged lengths, exact hop multiples, rows of 1-3
+    frames (NaN statistics like the reference), silent and loud rows.  Log-mel before normalisation within MEL_TOL,
+    normalised features within what (x - mean) / (std + 1e-5) makes of that error, NaN pattern and masks identical."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    import fuzz_frontend
+    bad = [m for m in (fuzz_frontend.frontend_case(c) for c in range(40)) if m]
+    assert not bad, bad
