@@ -349,3 +349,27 @@ def test_random_architectures_and_shapes_match_oracle(gpu, seed):
     top2 = want.topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL    # random weights: near-ties may flip inside the tolerance
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
+
+
+def test_strongly_ragged_batch_skipped_tiles_match_oracle(gpu):
+    """Rows far shorter than the batch maximum: most time tiles of those rows lie past their length, where the GEMM
+    skips its K loop and the depthwise kernel writes zeros -- the padded frames must still come out as the reference
+    computes them (it decodes them, quirk Q4)."""
+    from viet_asr_amd import configs, synth
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 9), synth.decoder_state_dict(1024, 91, 9)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    L = 160000
+    sig, lens = synth.audio_batch(5, L, 9, ragged=False)
+    lens[:] = [L // 8, L, L // 3, 400, 41000]
+    for b in range(5):
+        sig[b, lens[b]:] = 0
+    ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
+    r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
+    assert (r["logp"].cpu() - ref["logp"]).abs().max() <= LOGP_TOL
+    assert r["enc_len"].cpu().tolist() == ref["enc_len"].tolist()
+    top2 = ref["logp"].topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL
+    assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
+    assert clear.float().mean() > 0.9
