@@ -173,6 +173,17 @@ int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in,
  * GEMM epilogue stores) then overlap another part's MFMA-bound GEMM main loops.  Results do not depend on it. */
 int vasr_set_slices(vasr_handle* h, int slices);
 
+/* Row-independent batching (net-new; default off = the reference's batched semantics).  The reference's results
+ * depend on the padded batch a signal sits in: torch.stft reflects at the end of the PADDED row (parts/features.py:
+ * 181-188) and the greedy decoder collapses the padded frames too (helpers.py:7-33, quirk Q4), which is
+ * why it serves one utterance per call (app.py:66-67).  With on != 0, vasr_melspec_f32 and vasr_transcribe_greedy_f32
+ * treat row b as if it were alone: reflect padding at length[b], ids / id_len collapsed over the 1 + length[b] / hop mel
+ * frames (taken through the conv chain) an unbatched call would have produced.  Everything in between is already
+ * row-local (masks at the row's length, eval-mode BN), so ids / id_len equal those of batch-1 calls bit for bit
+ * whatever the other rows are.  Every length[b] must exceed n_fft / 2 (an unbatched torch.stft refuses shorter input);
+ * pred / logp keep their [B, T'] shapes, frames past a row's own count are unspecified. */
+int vasr_set_row_independent(vasr_handle* h, int on);
+
 /* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */
 /* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,
  * algorithm restated in oracle/beam_oracle.py).  Unlike the reference any batch size is accepted.

@@ -156,6 +156,21 @@ def test_int16_pcm_requests_stay_int16():
     assert seen == [np.dtype(np.int16), np.dtype(np.float32)]
 
 
+def test_independent_policy_merges_any_lengths_and_asks_for_row_independent_results():
+    seen = []
+
+    def fn(signals, row_independent=False):
+        seen.append((sorted(len(s) for s in signals), row_independent))
+        return [str(len(s)) for s in signals]
+
+    with BatchingTranscriber(fn, max_batch=8, max_wait_ms=100.0, policy="independent", max_pad_ratio=4.0) as srv:
+        futs = [srv.submit(np.ones(n, np.float32)) for n in (300, 900, 450, 1000)]
+        assert [f.result(10) for f in futs] == ["300", "900", "450", "1000"]
+    assert all(flag for _, flag in seen) and max(len(l) for l, _ in seen) >= 2
+    with pytest.raises(ValueError):
+        BatchingTranscriber(fn, policy="sorted")
+
+
 @pytest.mark.gpu
 def test_served_answers_equal_unbatched_transcribe_on_device():
     import torch
@@ -207,3 +222,32 @@ def test_pipelined_launch_equals_blocking_transcribe_and_int16_equals_float():
         futs = [srv.submit(s) for s in batches[2]]
         served = [f.result(120) for f in futs]
     assert served == want[2]
+
+
+@pytest.mark.gpu
+def test_row_independent_batches_equal_unbatched_calls_bit_for_bit():
+    """vasr_set_row_independent: whatever else is in the batch, a row's collapsed ids are those of the batch-1 call
+    (the reference's own batched results are not: reflect padding at the padded end, padded frames decoded)."""
+    import torch
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 5))
+    rng = np.random.default_rng(21)
+    lens = [257, 160 * 40, 160 * 40 + 1, 160 * 40 - 1, 31999, 9000, 320, 50000, 48000, 12345]
+    sigs = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    alone = [eng.transcribe([s])[0] for s in sigs]
+    assert eng.transcribe(sigs, row_independent=True) == alone
+    assert eng.transcribe(sigs[::-1], row_independent=True) == alone[::-1]
+    assert eng.transcribe(sigs[2:7], row_independent=True) == alone[2:7]
+    batched = eng.transcribe(sigs)                         # reference semantics: depends on the batch
+    assert batched[lens.index(max(lens))] == alone[lens.index(max(lens))]
+    assert batched != alone                                # ... and differs for the shorter rows (padded frames are decoded)
+    with pytest.raises(ValueError, match="n_fft/2"):
+        eng.transcribe([sigs[0][:256], sigs[1]], row_independent=True)
+    with BatchingTranscriber(launch_batch=eng.launch, max_batch=16, max_wait_ms=200.0, policy="independent",
+                             max_pad_ratio=1e9) as srv:
+        futs = [srv.submit(s) for s in sigs]
+        assert [f.result(120) for f in futs] == alone
+    assert max(srv.stats["device_calls_by_size"]) >= 5

@@ -113,3 +113,20 @@ for name, data in (("served fp32, 8 clients", f32), ("served int16, 8 clients", 
     lat = np.sort(np.array(lat)) * 1e3
     report(name, dt, len(lat), f"latency p50 {lat[len(lat) // 2]:.1f} ms p99 {lat[int(len(lat) * 0.99)]:.1f} ms; "
                                f"device calls by size {sizes}")
+
+# mixed lengths (2-10 s, what a service sees): "exact" can only merge equal lengths, i.e. runs batch 1; "independent"
+# merges everything and still returns the batch-1 answers (vasr_set_row_independent)
+rng = np.random.default_rng(11)
+mixed = [np.ascontiguousarray(f32[i % B][: int(rng.integers(32000, 160001))]) for i in range(4 * B)]
+audio_s = sum(len(s) for s in mixed) / 16000.0
+for policy, n_req in (("exact", 256), ("padded", len(mixed) * 4), ("independent", len(mixed) * 4)):
+    with BatchingTranscriber(launch_batch=eng.launch, max_batch=B, max_wait_ms=2.0, policy=policy, max_pad_ratio=1.25) as srv:
+        srv.transcribe(mixed[0])
+        t = time.perf_counter()
+        futs = [srv.submit(mixed[i % len(mixed)]) for i in range(n_req)]
+        [f.result(120) for f in futs]
+        dt = time.perf_counter() - t
+        sizes = srv.stats["device_calls_by_size"]
+    secs = sum(len(mixed[i % len(mixed)]) for i in range(n_req)) / 16000.0
+    print(f"mixed 2-10 s, policy {policy:12s} {n_req / dt:8,.0f} utt/s  {secs / dt:9,.0f}x real time   "
+          f"mean device batch {sum(k * v for k, v in sizes.items()) / sum(sizes.values()):.1f}", flush=True)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
     "vasr_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
+    "vasr_set_row_independent": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
                                        _P, _P, _P, _P, C.c_size_t, _P]),
@@ -185,6 +186,9 @@ class Handle:
 
     def set_slices(self, n):
         check(lib().vasr_set_slices(self.h, int(n)))
+
+    def set_row_independent(self, on):
+        check(lib().vasr_set_row_independent(self.h, int(bool(on))))
 
     def profile_begin(self):
         check(lib().vasr_profile_begin(self.h))

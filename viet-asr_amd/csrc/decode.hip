@@ -66,16 +66,29 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 // One wavefront per utterance: ballot + popcount stream compaction over all frames (quirk Q4).
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int64_t* __restrict__ pred, int64_t frames,
                                                           int blank, int32_t* __restrict__ ids,
-                                                          int32_t* __restrict__ id_len) {
+                                                          int32_t* __restrict__ id_len,
+                                                          const int64_t* __restrict__ wav_len, int hop,
+                                                          const LenStep* __restrict__ steps, int n_steps) {
   const int lane = threadIdx.x, b = blockIdx.x;
   const int64_t* p = pred + (int64_t)b * frames;
   int32_t* out = ids + (int64_t)b * frames;
+  int64_t own = frames;
+  if (wav_len) {
+    // frames of an unbatched call on this row: torch.stft(center=True) gives 1 + L // hop, every conv
+    // floor((t + 2 p - d (K - 1) - 1) / stride) + 1
+    int64_t t = 1 + wav_len[b] / hop;
+    for (int s = 0; s < n_steps; ++s) {
+      const LenStep st = steps[s];
+      t = (t + 2 * st.pad - st.dilation * (st.kernel - 1) - 1) / st.stride + 1;
+    }
+    own = t < frames ? (t < 0 ? 0 : t) : frames;
+  }
   int count = 0;
-  for (int64_t t0 = 0; t0 < frames; t0 += 64) {
+  for (int64_t t0 = 0; t0 < own; t0 += 64) {
     const int64_t t = t0 + lane;
     bool keep = false;
     int cur = blank;
-    if (t < frames) {
+    if (t < own) {
       cur = (int)p[t];
       const int prev = t > 0 ? (int)p[t - 1] : blank;  // previous = blank before the first frame
       keep = (cur != prev || prev == blank) && cur != blank;
@@ -104,8 +117,9 @@ void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes
 }
 
 void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids, int32_t* id_len,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(batch), dim3(64), 0, st, pred, frames, blank, ids, id_len);
+                         hipStream_t st, const int64_t* wav_len, int hop, const LenStep* steps, int n_steps) {
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(batch), dim3(64), 0, st, pred, frames, blank, ids, id_len, wav_len,
+                     hop, steps, n_steps);
 }
 
 }  // namespace vasr

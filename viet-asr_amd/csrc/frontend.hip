@@ -38,7 +38,8 @@ __device__ __forceinline__ void wave_fence() {
 
 // grid (ceil(T/32), B), block kThreads
 __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
-                                                          int64_t samples, int hop, float preemph,
+                                                          int64_t samples, const int64_t* __restrict__ row_len,
+                                                          int hop, float preemph,
                                                           float log_guard, float* __restrict__ mel,
                                                           int64_t mel_ld, int frames) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -52,6 +53,8 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFramesPerBlock;
   const float* x = wav + (int64_t)b * samples;
+  // row-independent mode (vasr_set_row_independent): the row ends at its own length, as if it were alone in the batch
+  const int64_t ns = row_len ? min(row_len[b], samples) : samples;
 
   // ---- window and twiddles: a lane needs the same few entries for every frame, so they live in registers ----
   const float2* win2 = reinterpret_cast<const float2*>(tb.window);
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
   for (int i = tid; i < seg_len; i += kThreads) {
     int64_t n = p0 + i;
     if (n < 0) n = -n;                       // torch.stft(center=True, pad_mode="reflect"), features.py:181-188
-    if (n >= samples) n = 2 * (samples - 1) - n;
+    if (n >= ns) n = 2 * (ns - 1) - n;
     float v = 0.f;
-    if (n >= 0 && n < samples) {
+    if (n >= 0 && n < ns) {
       v = x[n];
       // features.py:254-255  x[:,1:] - preemph * x[:,:-1]  (two roundings, no fma contraction)
       if (preemph >= 0.f && n > 0) v = __fsub_rn(v, __fmul_rn(preemph, x[n - 1]));
@@ -212,15 +215,15 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ mel,
 
 }  // namespace
 
-void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, int hop,
-                        float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
+void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, const int64_t* row_len,
+                        int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st) {
   const int seg_len = (kFramesPerBlock - 1) * hop + kNfft;
   size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kWaves * 256 * 8 + kWaves * (260 + kMelTaps) * 4 +
                64 * (kFramesPerBlock + 1) * 4;
   dim3 grid((frames + kFramesPerBlock - 1) / kFramesPerBlock, batch);
-  hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(kThreads), lds, st, tb, wav, samples, hop, preemph, log_guard,
-                     mel, mel_ld, frames);
+  hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(kThreads), lds, st, tb, wav, samples, row_len, hop, preemph,
+                     log_guard, mel, mel_ld, frames);
 }
 
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st) {

@@ -96,6 +96,7 @@ struct vasr_handle {
   // useful way (one workgroup per CU each), so slicing is OFF by default
   int slices = getenv("VASR_SLICES") ? atoi(getenv("VASR_SLICES")) : 1;
   bool slice_ready = false;
+  bool row_independent = false;   // vasr_set_row_independent
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16
@@ -682,7 +683,8 @@ int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T = (int)vasr_mel_frames(h, samples);
   launch_seq_len(d_len, batch, h->fe.hop_length, d_seq, st);
-  launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, d_mel, T, T, st);
+  launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
+                     h->fe.preemph, h->fe.log_guard, d_mel, T, T, st);
   launch_normalize(d_mel, T, d_seq, batch, h->fe.n_mels, T, h->fe.normalize, st);
   return check_launch("melspec");
 }
@@ -747,8 +749,8 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
   {
     ProfScope ps(h, kProfFrontend, st);
     launch_seq_len(d_len, batch, h->fe.hop_length, seq, st);
-    launch_stft_logmel(h->ft, d_wav, batch, samples, h->fe.hop_length, h->fe.preemph, h->fe.log_guard, melp, p.Tp0,
-                       (int)T, st);
+    launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
+                       h->fe.preemph, h->fe.log_guard, melp, p.Tp0, (int)T, st);
     launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
   }
   int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st);
@@ -756,7 +758,11 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
   if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st))) return rc;
   if (d_ids && d_id_len) {
     ProfScope ps(h, kProfHead, st);
-    launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
+    if (h->row_independent)
+      launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st, d_len, h->fe.hop_length,
+                          h->d_steps, (int)h->steps.size());
+    else
+      launch_ctc_collapse(pred, batch, p.T1, h->num_classes - 1, d_ids, d_id_len, st);
   }
   return 0;
 }
@@ -853,6 +859,12 @@ int vasr_set_gemm_mode(vasr_handle* h, int mode) {
   if (!h || mode < 0 || mode > 2)
     return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA), 1 (3 x bf16 split) or 2 (2 x bf16 split, reduced)");
   h->gemm_mode = mode;
+  return 0;
+}
+
+int vasr_set_row_independent(vasr_handle* h, int on) {
+  if (!h) return fail(VASR_ERR_INVALID, "null handle");
+  h->row_independent = on != 0;
   return 0;
 }
 

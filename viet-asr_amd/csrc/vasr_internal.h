@@ -39,8 +39,10 @@ struct FrontendTables {
 };
 constexpr int kMelTaps = 32;  // >= max non-zeros per Slaney filter at 64 mels / 512 fft (23)
 
-void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, int hop,
-                        float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
+// row_len: nullptr = the reference's batched semantics (every row is `samples` long, reflect padding at the padded
+// end, quirk Q5); else each row ends at row_len[b] like an unbatched call
+void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, const int64_t* row_len,
+                        int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st);
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st);
 void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,
@@ -100,8 +102,11 @@ void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad,
 void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
                               int num_classes, float* logp, int64_t* pred, hipStream_t st);
 void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes, int64_t* pred, hipStream_t st);
+// wav_len != nullptr (row-independent mode): row b is collapsed over the frames an unbatched call on wav_len[b]
+// samples would have produced -- 1 + wav_len / hop mel frames taken through the conv chain `steps` -- not over `frames`
 void launch_ctc_collapse(const int64_t* pred, int batch, int64_t frames, int blank, int32_t* ids,
-                         int32_t* id_len, hipStream_t st);
+                         int32_t* id_len, hipStream_t st, const int64_t* wav_len = nullptr, int hop = 0,
+                         const LenStep* steps = nullptr, int n_steps = 0);
 
 // ---- audio ingest (audio.hip) ----
 void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st);

@@ -65,6 +65,7 @@ class QuartzNetCTC:
                 self.handle.set_gemm_mode(gemm)
         self._ws = None
         self._slots, self._copy_stream, self._launched = None, None, 0
+        self._row_independent = False
 
     # -- shapes
     def frames(self, samples):
@@ -78,11 +79,16 @@ class QuartzNetCTC:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, wav, length, want_logp=False, want_pred=True):
+    def forward(self, wav, length, want_logp=False, want_pred=True, row_independent=False):
         """wav [B, L] f32 cuda (rows zero padded), length [B] i64 cuda.
 
         Returns dict(ids [B,T'] i32, id_len [B] i32, pred [B,T'] i64, enc_len [B] f32, logp or None).
         Everything is enqueued on the current stream; nothing synchronises.
+
+        row_independent=False is the reference's batched semantics (a row's result depends on the padded batch: reflect
+        padding at the padded end, padded frames decoded).  True makes ids / id_len of every row what a batch-1 call on
+        that row alone returns, bit for bit (vasr_set_row_independent in include/vasr.h); every length must then
+        exceed n_fft / 2, which the caller checks (the lengths live on the device here).
         """
         if wav.device.type != "cuda" or wav.dtype != torch.float32 or not wav.is_contiguous():
             raise ValueError("wav must be a contiguous float32 cuda tensor")
@@ -97,6 +103,9 @@ class QuartzNetCTC:
         pred = torch.empty((B, t1), dtype=torch.int64, device=dev) if want_pred else None
         enc_len = torch.empty((B,), dtype=torch.float32, device=dev)
         logp = torch.empty((B, t1, len(self.labels) + 1), dtype=torch.float32, device=dev) if want_logp else None
+        if bool(row_independent) != self._row_independent:
+            self.handle.set_row_independent(row_independent)
+            self._row_independent = bool(row_independent)
         _lib.check(_lib.lib().vasr_transcribe_greedy_f32(
             self.handle.h, wav.data_ptr(), length.data_ptr(), B, L,
             pred.data_ptr() if pred is not None else None, ids.data_ptr(), id_len.data_ptr(),
@@ -110,13 +119,13 @@ class QuartzNetCTC:
         n = id_len.cpu().numpy()
         return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]
 
-    def transcribe(self, signals):
+    def transcribe(self, signals, row_independent=False):
         """List of 1-D arrays (model sample rate; float, or int16 PCM) -> list of strings; zero-pad-to-max collate
-        (parts/dataset.py:14-53)."""
-        return self.launch(signals).texts()
+        (parts/dataset.py:14-53).  row_independent: see forward()."""
+        return self.launch(signals, row_independent).texts()
 
     # -- pipelined host path: pinned staging, copies on their own stream, two batches in flight
-    def launch(self, signals):
+    def launch(self, signals, row_independent=False):
         """Enqueue one batch and return at once; ``.texts()`` of the returned PendingBatch waits for it.
 
         Two staging slots alternate: while batch k computes, batch k+1 is collated into pinned memory and its
@@ -131,7 +140,7 @@ class QuartzNetCTC:
             self._copy_stream = torch.cuda.Stream(self.device)
         slot = self._slots[self._launched % 2]
         self._launched += 1
-        return slot.launch(signals)
+        return slot.launch(signals, row_independent)
 
 
 class PendingBatch:
@@ -185,7 +194,7 @@ class _Slot:
         if self.pin_ids is None or self.pin_ids.numel() < B * t1:
             self.pin_ids = torch.empty(B * t1, dtype=torch.int32, pin_memory=True)
 
-    def launch(self, signals):
+    def launch(self, signals, row_independent=False):
         eng = self.eng
         if self.pending is not None:
             self.pending.texts()          # the slot's previous batch: fetch before its buffers are overwritten
@@ -194,6 +203,9 @@ class _Slot:
         L = max(lens)
         if min(lens) == 0:
             raise ValueError("empty signal in batch")
+        if row_independent and min(lens) <= eng.frontend["n_fft"] // 2:
+            raise ValueError(f"row-independent batching needs more than n_fft/2 = {eng.frontend['n_fft'] // 2} samples "
+                             f"per signal (got {min(lens)}): an unbatched call refuses such input too")
         pcm16 = all(getattr(s, "dtype", None) == np.int16 for s in signals)
         dtype, item = (torch.int16, 2) if pcm16 else (torch.float32, 4)
         nbytes = B * L * item
@@ -217,7 +229,7 @@ class _Slot:
                 f32 = self.dev_f32[: B * L].view(B, L)
                 _lib.check(_lib.lib().vasr_pcm16_to_f32(wav.data_ptr(), B * L, f32.data_ptr(), comp.cuda_stream))
                 wav = f32
-            self.out = eng.forward(wav, self.dev_len[:B], want_pred=False)
+            self.out = eng.forward(wav, self.dev_len[:B], want_pred=False, row_independent=row_independent)
             self.pin_ids[: B * t1].copy_(self.out["ids"].view(-1), non_blocking=True)
             self.pin_idlen[:B].copy_(self.out["id_len"], non_blocking=True)
             self.ev_out.record(comp)

@@ -97,10 +97,12 @@ class VietASR:
                 return signals                      # int16 PCM goes to the device as it is (scaled there)
         return [self._to_model_rate(s, sample_rate) for s in signals]
 
-    def transcribe_batch(self, signals, sample_rate=None):
-        """Greedy transcripts of a list of 1-D signals through the fused one-call path."""
-        return self._fused_engine().transcribe(self._batch_signals(signals, sample_rate))
+    def transcribe_batch(self, signals, sample_rate=None, row_independent=False):
+        """Greedy transcripts of a list of 1-D signals through the fused one-call path.  row_independent=True: every
+        transcript is what the signal alone would give (engine.QuartzNetCTC.forward); default: the reference's
+        padded-batch semantics."""
+        return self._fused_engine().transcribe(self._batch_signals(signals, sample_rate), row_independent)
 
-    def launch_batch(self, signals, sample_rate=None):
+    def launch_batch(self, signals, sample_rate=None, row_independent=False):
         """Asynchronous ``transcribe_batch``: returns a handle at once, ``.texts()`` waits (engine.QuartzNetCTC.launch)."""
-        return self._fused_engine().launch(self._batch_signals(signals, sample_rate))
+        return self._fused_engine().launch(self._batch_signals(signals, sample_rate), row_independent)

@@ -15,7 +15,11 @@ padded frames are decoded, reflect padding sees the padded row), and the referen
   * ``policy="exact"`` (default) only merges requests with the same number of samples: every answer is identical to
     what ``transcribe`` returns for that signal alone;
   * ``policy="padded"`` merges anything up to ``max_batch`` / ``max_pad_ratio`` (zero-pad-to-max collate,
-    parts/dataset.py:14-53): the reference's *batched* semantics, maximum throughput.
+    parts/dataset.py:14-53): the reference's *batched* semantics, maximum throughput;
+  * ``policy="independent"`` merges like "padded" but calls the engine with ``row_independent=True`` (include/vasr.h,
+    vasr_set_row_independent: every row reflects at its own end and is decoded over its own frames): every answer is
+    identical to what ``transcribe`` returns for that signal alone, at the throughput of "padded".  Needs an engine
+    callable that takes the keyword (``VietASR.launch_batch`` / ``transcribe_batch`` do).
 Requests are taken in arrival order; a cycle waits at most ``max_wait_ms`` after its first request.
 
 Pipelining.  With ``launch_batch=vietasr.launch_batch`` (returns at once with a handle whose ``.texts()`` waits) the
@@ -34,14 +38,15 @@ import numpy as np
 class BatchingTranscriber:
     def __init__(self, transcribe_batch=None, max_batch=64, max_wait_ms=4.0, policy="exact", max_pad_ratio=1.25,
                  launch_batch=None):
-        if policy not in ("exact", "padded"):
-            raise ValueError(f"policy must be 'exact' or 'padded', got {policy!r}")
+        if policy not in ("exact", "padded", "independent"):
+            raise ValueError(f"policy must be 'exact', 'padded' or 'independent', got {policy!r}")
         if max_batch < 1:
             raise ValueError("max_batch must be >= 1")
         if (transcribe_batch is None) == (launch_batch is None):
             raise ValueError("give exactly one of transcribe_batch and launch_batch")
-        self._fn = transcribe_batch
-        self._launch = launch_batch
+        kw = {"row_independent": True} if policy == "independent" else {}
+        self._fn = (lambda sigs: transcribe_batch(sigs, **kw)) if transcribe_batch is not None else None
+        self._launch = (lambda sigs: launch_batch(sigs, **kw)) if launch_batch is not None else None
         self.max_batch = int(max_batch)
         self.max_wait = float(max_wait_ms) / 1e3
         self.policy = policy
@@ -89,14 +94,16 @@ class BatchingTranscriber:
 
     # ---- worker ----
     def _collect(self):
-        """First request (blocking), then whatever arrives within max_wait, up to max_batch."""
+        """First request (blocking), then whatever arrives within max_wait, up to max_batch -- and, without waiting any
+        longer, whatever else is already queued (up to 8 batches' worth): under load plan() then has enough requests
+        of similar length to fill its groups."""
         first = self._q.get()
         if first is None:
             return None
         items = [first]
         deadline = time.monotonic() + self.max_wait
-        while len(items) < self.max_batch:
-            left = deadline - time.monotonic()
+        while len(items) < 8 * self.max_batch:
+            left = deadline - time.monotonic() if len(items) < self.max_batch else 0.0
             try:
                 nxt = self._q.get(timeout=left) if left > 0 else self._q.get_nowait()
             except queue.Empty:
