@@ -197,6 +197,13 @@ int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
                          int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_workspace,
                          size_t workspace_bytes, vasr_stream stream);
+/* Same with a frame count per row: d_row_frames [B] i32 (device), row b is searched over its first
+ * min(d_row_frames[b], frames) frames -- for batches of utterances of different lengths whose rows must come out as
+ * batch-1 calls would (vasr_set_row_independent); NULL = all frames for every row (the call above). */
+int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, int batch, int64_t frames,
+                              int num_classes, int space_id, int beam_width, float token_min_logp,
+                              float beam_prune_logp, const vasr_lm* lm, int32_t* d_ids, int32_t* d_id_len,
+                              float* d_score, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
 /* Back-off n-gram model as two open-addressing hash tables (keys built with vasr_beam_hash_*; 0 = empty slot,
  * stored keys have bit 0 set): word-hash -> word id, and hash(n, id_1..id_n) -> (log10 p, log10 back-off).
  * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel. */

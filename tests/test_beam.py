@@ -180,6 +180,29 @@ def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("use_lm", [False, True])
+def test_device_beam_search_per_row_frame_counts(gpu, tmp_path, use_lm):
+    """vasr_beam_search_rows_f32: a row searched over its own frame count inside a padded batch gives exactly what the
+    truncated row gives alone (ids and score bit-identical; 0 frames -> empty hypothesis)."""
+    from viet_asr_amd.beam import BeamSearchDecoder
+    path, _ = toy_lm(str(tmp_path))
+    T = 90
+    lp = np.stack([ctc_like_posteriors(T, 29, 500 + b, p_blank=0.6) for b in range(5)])
+    frames = [T, 37, 1, 64, 0]
+    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    x = torch.from_numpy(lp).to(gpu)
+    ids, n, score = dec.decode_ids(x, 32, frames=frames)
+    assert int(n[4]) == 0
+    for b in range(4):
+        ids1, n1, score1 = dec.decode_ids(x[b : b + 1, : frames[b]].contiguous(), 32)
+        assert int(n[b]) == int(n1[0]) and torch.equal(ids[b, : n[b]], ids1[0, : n1[0]])
+        assert float(score[b]) == float(score1[0])
+    assert dec.decode_batch(x, 32, frames=frames)[1] == dec.decode_batch(x[1:2, :37].contiguous(), 32)[0]
+    with pytest.raises(ValueError):
+        dec.decode_ids(x, 32, frames=[1, 2])
+
+
+@pytest.mark.gpu
 def test_device_beam_search_randomised_cases(gpu):
     """Sixty cases of tests/devtools/fuzz_beam.py (posterior shape, length, beam width, LM and its weights all drawn at
     random; 4 000 cases of it ran clean when this test was added)."""

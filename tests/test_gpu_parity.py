@@ -193,6 +193,12 @@ def test_vietasr_class_end_to_end(gpu, tmp_path):
     beam = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="beam", beam_width=8, lm_path=None)
     out = beam.transcribe(utts[0])
     assert isinstance(out, str)
+    # batched beam search, row-independent: the transcripts of the reference-style one-at-a-time calls; and the greedy
+    # batch in the same mode equals the one-at-a-time greedy calls (the padded batch above does not, quirks Q4/Q5)
+    assert beam.transcribe_batch(utts, decoder="beam", row_independent=True) == [beam.transcribe(u) for u in utts]
+    assert asr.transcribe_batch(utts, row_independent=True) == [asr.transcribe(u) for u in utts]
+    with pytest.raises(ValueError):
+        asr.transcribe_batch(utts, decoder="beam")
     with pytest.raises(AssertionError):
         VietASR("quartznet12x1_vi", str(tmp_path / "missing.pt"), dec_p)
 

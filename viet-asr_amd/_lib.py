@@ -62,6 +62,8 @@ SIGNATURES = {
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
                                        _P, _P, _P, _P, C.c_size_t, _P]),
+    "vasr_beam_search_rows_f32": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "vasr_lm_create": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_float, C.c_float, C.POINTER(_P)]),
     "vasr_lm_destroy": (None, [_P]),

@@ -143,8 +143,11 @@ class BeamSearchDecoder:
             self._lm = DeviceLM(self.lm_path, self.labels, self.alpha, self.beta)
         return self._lm
 
-    def decode_ids(self, log_probs, beam_width):
-        """log_probs [B,T,V+1] cuda f32 -> (ids [B,T] i32, id_len [B] i32, score [B] f32)."""
+    def decode_ids(self, log_probs, beam_width, frames=None):
+        """log_probs [B,T,V+1] cuda f32 -> (ids [B,T] i32, id_len [B] i32, score [B] f32).
+
+        frames: optional [B] frame counts (sequence or tensor); row b is then searched over its first frames[b]
+        frames only -- for batches of different lengths (the reference searches every frame of its batch-1 tensor)."""
         if log_probs.device.type != "cuda":
             raise _lib.VasrError("viet-asr_amd kernels need HIP-resident tensors; there is no CPU fallback for this path")
         x = log_probs.to(torch.float32).contiguous()
@@ -159,14 +162,19 @@ class BeamSearchDecoder:
         n = torch.empty((B,), dtype=torch.int32, device=x.device)
         score = torch.empty((B,), dtype=torch.float32, device=x.device)
         lm = self._get_lm()
-        _lib.check(L.vasr_beam_search_f32(x.data_ptr(), B, T, V1, self.space_id, int(beam_width),
-                                          float(self.token_min_logp), float(self.beam_prune_logp),
-                                          lm.handle if lm is not None else None, ids.data_ptr(), n.data_ptr(),
-                                          score.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                          torch.cuda.current_stream().cuda_stream))
+        rows = None
+        if frames is not None:
+            rows = torch.as_tensor(frames).to(device=x.device, dtype=torch.int32).contiguous()
+            if rows.shape != (B,):
+                raise ValueError(f"frames must have one entry per row ({B}), got shape {tuple(rows.shape)}")
+        _lib.check(L.vasr_beam_search_rows_f32(x.data_ptr(), rows.data_ptr() if rows is not None else None, B, T, V1,
+                                               self.space_id, int(beam_width), float(self.token_min_logp),
+                                               float(self.beam_prune_logp), lm.handle if lm is not None else None,
+                                               ids.data_ptr(), n.data_ptr(), score.data_ptr(), self._ws.data_ptr(),
+                                               self._ws.numel(), torch.cuda.current_stream().cuda_stream))
         return ids, n, score
 
-    def decode_batch(self, log_probs, beam_width):
-        ids, n, _ = self.decode_ids(log_probs, beam_width)
+    def decode_batch(self, log_probs, beam_width, frames=None):
+        ids, n, _ = self.decode_ids(log_probs, beam_width, frames)
         ids, n = ids.cpu().numpy(), n.cpu().numpy()
         return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]

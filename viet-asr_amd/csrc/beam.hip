@@ -245,7 +245,8 @@ __device__ inline int block_scan_excl(int v, int* scratch, int* total, int& flip
 }
 
 // grid (B), block kThreads
-__global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __restrict__ logp, int frames, int V1,
+__global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __restrict__ logp, int frames_ld,
+                                                          const int32_t* __restrict__ row_frames, int V1,
                                                           int space_id, int beam_width, float token_min_logp,
                                                           float beam_prune_logp, LmView lm, int use_lm,
                                                           unsigned int* __restrict__ bp_all,
@@ -271,8 +272,11 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   unsigned short* sel_slot = pair_slot + kMaxFill + 2;              // [kMaxBeams] slot of the survivor at each rank
 
   const int tid = threadIdx.x, b = blockIdx.x, V = V1 - 1;
-  const float* lrow = logp + (int64_t)b * frames * V1;
-  unsigned int* bp = bp_all + (int64_t)b * frames * kMaxBeams;
+  // frames searched: all of them (the reference hands pyctcdecode every frame of its batch-1 tensor), or the row's own
+  // count when the caller batches utterances of different lengths
+  const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
+  const float* lrow = logp + (int64_t)b * frames_ld * V1;
+  unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
 
   if (tid == 0) {
     Beam s{};
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     }
     // trace back
     int n = 0, cur = bi;
-    int32_t* out = out_ids + (int64_t)b * frames;
+    int32_t* out = out_ids + (int64_t)b * frames_ld;
     for (int t = frames - 1; t >= 0; --t) {
       const unsigned int e = bp[(int64_t)t * kMaxBeams + cur];
       const unsigned int ch = e & 255;
@@ -651,7 +655,8 @@ size_t beam_lds_bytes() {
 
 void launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
                         float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
-                        int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st) {
+                        int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
+                        const int32_t* row_frames) {
   LmView v{};
   int use_lm = 0;
   if (lm) {
@@ -667,8 +672,8 @@ void launch_beam_search(const float* logp, int batch, int frames, int V1, int sp
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, V1, space_id, beam_width,
-                     token_min_logp, beam_prune_logp, v, use_lm, bp, out_ids, out_len, out_score);
+  hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, row_frames, V1, space_id,
+                     beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, out_ids, out_len, out_score);
 }
 
 unsigned long long beam_hash_step(unsigned long long h, unsigned long long v) { return hmix(h, v); }

@@ -882,6 +882,14 @@ int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
                          int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_ws, size_t ws_bytes,
                          vasr_stream stream) {
+  return vasr_beam_search_rows_f32(d_logp, nullptr, batch, frames, num_classes, space_id, beam_width, token_min_logp,
+                                   beam_prune_logp, lm, d_ids, d_id_len, d_score, d_ws, ws_bytes, stream);
+}
+
+int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, int batch, int64_t frames,
+                              int num_classes, int space_id, int beam_width, float token_min_logp,
+                              float beam_prune_logp, const vasr_lm* lm, int32_t* d_ids, int32_t* d_id_len,
+                              float* d_score, void* d_ws, size_t ws_bytes, vasr_stream stream) {
   if (!d_logp || !d_ids || !d_id_len || !d_score || !d_ws || batch <= 0 || frames <= 0)
     return fail(VASR_ERR_INVALID, "bad argument");
   if (num_classes < 2 || num_classes > 128 || beam_width < 1 || beam_width > kBeamMax)
@@ -891,7 +899,7 @@ int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
   launch_beam_search(d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width,
                      token_min_logp, beam_prune_logp, lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws),
-                     d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream));
+                     d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream), d_row_frames);
   return check_launch("beam_search");
 }
 

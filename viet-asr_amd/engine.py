@@ -124,6 +124,22 @@ class QuartzNetCTC:
         (parts/dataset.py:14-53).  row_independent: see forward()."""
         return self.launch(signals, row_independent).texts()
 
+    def transcribe_beam(self, signals, beam_decoder, beam_width, row_independent=True):
+        """Batched counterpart of the reference's beam wiring (infer.py:132-139, 159-160; batch 1 there): one forward
+        pass for the log-probs, then viet_asr_amd.beam.BeamSearchDecoder over every row.  row_independent=True searches
+        each row over its own frames (and reflects it at its own end): the transcripts of batch-1 calls."""
+        lens = [len(s) for s in signals]
+        if row_independent and min(lens) <= self.frontend["n_fft"] // 2:
+            raise ValueError(f"row-independent batching needs more than n_fft/2 = {self.frontend['n_fft'] // 2} samples "
+                             f"per signal (got {min(lens)})")
+        batch = np.zeros((len(signals), max(lens)), dtype=np.float32)
+        for i, s in enumerate(signals):
+            batch[i, : lens[i]] = s
+        r = self.forward(torch.from_numpy(batch).to(self.device), torch.tensor(lens, device=self.device),
+                         want_logp=True, want_pred=False, row_independent=row_independent)
+        own = [self.frames(n)[1] for n in lens] if row_independent else None
+        return beam_decoder.decode_batch(r["logp"], beam_width, frames=own)
+
     # -- pipelined host path: pinned staging, copies on their own stream, two batches in flight
     def launch(self, signals, row_independent=False):
         """Enqueue one batch and return at once; ``.texts()`` of the returned PendingBatch waits for it.

@@ -97,11 +97,17 @@ class VietASR:
                 return signals                      # int16 PCM goes to the device as it is (scaled there)
         return [self._to_model_rate(s, sample_rate) for s in signals]
 
-    def transcribe_batch(self, signals, sample_rate=None, row_independent=False):
-        """Greedy transcripts of a list of 1-D signals through the fused one-call path.  row_independent=True: every
+    def transcribe_batch(self, signals, sample_rate=None, row_independent=False, decoder="greedy"):
+        """Transcripts of a list of 1-D signals through the fused one-call path.  row_independent=True: every
         transcript is what the signal alone would give (engine.QuartzNetCTC.forward); default: the reference's
-        padded-batch semantics."""
-        return self._fused_engine().transcribe(self._batch_signals(signals, sample_rate), row_independent)
+        padded-batch semantics.  decoder="beam" (instances built with decoder="beam" only) runs this instance's beam
+        search + LM over the batch instead of the greedy collapse."""
+        if decoder == "greedy":
+            return self._fused_engine().transcribe(self._batch_signals(signals, sample_rate), row_independent)
+        if decoder != "beam" or self.mode != "beam":
+            raise ValueError("decoder must be 'greedy', or 'beam' on an instance constructed with decoder='beam'")
+        sigs = [self._to_model_rate(s, sample_rate) for s in signals]
+        return self._fused_engine().transcribe_beam(sigs, self.beam.decoder, self.beam.beam_width, row_independent)
 
     def launch_batch(self, signals, sample_rate=None, row_independent=False):
         """Asynchronous ``transcribe_batch``: returns a handle at once, ``.texts()`` waits (engine.QuartzNetCTC.launch)."""
