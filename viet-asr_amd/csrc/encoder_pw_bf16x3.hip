@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "vasr_internal.h"
+#include <type_traits>
 
 namespace vasr {
 
@@ -187,12 +188,14 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
   }
   __syncthreads();
 
-  for (int c = 0; c < nchunks; ++c) {
-    // The next chunk's activations are requested unconditionally (the last chunk re-reads itself): a branch here
-    // would make the compiler merge the two paths' load counters and wait for these HBM loads (vmcnt(0)) before the
-    // first MFMA of every chunk.  They are issued behind the step-1 weight prefetch, because vmcnt retires in order
-    // and every later weight wait therefore also waits for them.
-    const int cn = c + 1 < nchunks ? c + 1 : c;
+  // One K chunk.  LAST = false: the next chunk's activations are requested (behind the step-1 weight prefetch, because
+  // vmcnt retires in order and every later weight wait therefore also waits for them), converted and stored into the
+  // idle LDS buffer -- unconditionally, no branch anywhere in this body: with one, the compiler merges the two paths'
+  // load counters and waits for the HBM loads (vmcnt(0)) before the first MFMA of every chunk, and it sinks the loads
+  // down to sstore, their only use.  LAST = true is the peeled final chunk, which stages nothing.
+  auto run_chunk = [&](const int c, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int cn = c + 1;
     // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
     uint4 bf[2][3];
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
-      if (s == 0 && !(VASR_ABLATE & 4)) gload(cn * BKC);
+      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload(cn * BKC);
       // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
       // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step, and the activation loads land
       // next to sstore.  It also keeps sstore's conversion (which may overlap the last step's MFMAs) from moving
@@ -244,11 +247,11 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
         for (int p = 0; p < (LITE ? 2 : 3); ++p) af[i][p] = an[i][p];
     }
-    // also unconditional (after the last chunk it refills the idle buffer): inside a branch LLVM sinks the global
-    // loads above down to this, their only use, and their whole HBM latency is exposed
-    if (!(VASR_ABLATE & 4)) sstore((c + 1) & 1, cn * BKC);
-    if (!(VASR_ABLATE & 8)) __syncthreads();
-  }
+    if (!LAST && !(VASR_ABLATE & 4)) sstore((c + 1) & 1, cn * BKC);
+    if (!(VASR_ABLATE & 8)) __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) run_chunk(c, std::false_type{});
+  if (nchunks) run_chunk(nchunks - 1, std::true_type{});
 
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
