@@ -357,6 +357,22 @@ def test_random_architectures_and_shapes_match_oracle(gpu, seed):
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
 
 
+def test_five_minute_signal_in_one_pass_matches_oracle(gpu):
+    """The reference CLI skips files longer than 10 s (infer.py:201-203); here a long recording is one pass (T = 30 001
+    frames, no halo tiling): same transcript as the oracle."""
+    from viet_asr_amd import configs, synth
+    from oracle import quartznet_oracle as O
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 4), synth.decoder_state_dict(1024, 91, 4)
+    eng = _engine(cfg, enc_sd, dec_sd)
+    n = 5 * 60 * 16000
+    x = (0.1 * np.random.default_rng(5).standard_normal(n)).astype(np.float32)
+    ref = O.forward_all(x[None], np.array([n]), enc_sd, dec_sd, jas)
+    text = eng.transcribe([x])[0]
+    assert len(text) > 1000 and text == O.ctc_decode_strings(ref["pred"], cfg["labels"])[0]
+
+
 def test_strongly_ragged_batch_skipped_tiles_match_oracle(gpu):
     """Rows far shorter than the batch maximum: most time tiles of those rows lie past their length, where the GEMM
     skips its K loop and the depthwise kernel writes zeros -- the padded frames must still come out as the reference
