@@ -168,14 +168,13 @@ void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st)
 void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int batch, const float* table, int nwin,
                      int num_table, double ratio, float* y, int64_t ld_out, int64_t* len_out, hipStream_t st) {
   // ratio as p/q: sample rates are integers, so ratio * 48000 * 44100 / ... is overkill -- try denominators up to 1000
-  int p = 0, q = 0;
+  int p = 0;   // numerator of the reduced ratio (the phase count); 0 = no small rational found
   for (int d = 1; d <= 1000 && !p; ++d) {
     const double num = ratio * d;
     const double rn = (double)(int64_t)(num + 0.5);
     if (rn >= 1.0 && rn < 1e6 && (num > rn ? num - rn : rn - num) <= 1e-12 * rn) {
       const int64_t g = gcd64((int64_t)rn, d);
       p = (int)((int64_t)rn / g);
-      q = d / (int)g;
     }
   }
   static const bool generic_only = getenv("VASR_RESAMPLE_GENERIC") && atoi(getenv("VASR_RESAMPLE_GENERIC")) != 0;

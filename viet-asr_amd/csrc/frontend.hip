@@ -29,7 +29,7 @@ __device__ __forceinline__ cf cmul_negi(cf a) { return {a.im, -a.re}; }
 
 // The FFT scratch, power spectrum and tile columns of a frame belong to ONE wavefront, and the LDS pipeline executes a
 // wavefront's accesses in issue order: a compiler-level fence is all the frame loop needs (it used six workgroup
-// barriers per frame, i.e. the four wavefronts kept waiting for each other 48 times per block).
+// barriers per frame, i.e. the wavefronts of a workgroup kept waiting for each other 48 times per block).
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
