@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 import viet_asr_amd  # noqa: E402,F401  (root shim -> viet-asr_amd/)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["vi12x1_b1_tiny", "vi12x1_b3_ragged", "vi12x1_b2_q2_realdec", "en15x5_b2_ragged"]
+GOLDEN_CASES = ["vi12x1_b1_tiny", "vi12x1_b3_ragged", "vi12x1_b2_q2_realdec", "en15x5_b2_ragged", "en12x1_b4_hopmult",
+                "en15x5_b1_10s"]
 
 
 def pytest_configure(config):

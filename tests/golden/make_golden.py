@@ -202,3 +202,5 @@ if __name__ == "__main__":
     run_case("vi12x1_b2_q2_realdec", "quartznet12x1_vi.yaml", 2, 24000, 2, True, real_decoder=VI_DEC)
     run_case("en15x5_b2_ragged", "quartznet15x5.yaml", 2, 20321, 3, True)
     run_case("vi12x1_b1_tiny", "quartznet12x1_vi.yaml", 1, 4000, 4, False)
+    run_case("en12x1_b4_hopmult", "quartznet12x1.yaml", 4, 160 * 150, 5, True)     # third shipped config; L % hop == 0
+    run_case("en15x5_b1_10s", "quartznet15x5.yaml", 1, 160000, 6, False)           # one full BASELINE-length clip
