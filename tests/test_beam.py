@@ -203,6 +203,24 @@ def test_device_beam_search_per_row_frame_counts(gpu, tmp_path, use_lm):
 
 
 @pytest.mark.gpu
+def test_beam_search_writes_stay_inside_its_buffers(gpu):
+    """Workspace (vasr_beam_workspace_bytes) and the [B][T] / [B] outputs between sentinel-filled guard regions."""
+    from viet_asr_amd import _lib
+    B, T, V1, G = 3, 77, 29, 1 << 16
+    lp = torch.from_numpy(np.stack([random_posteriors(T, V1, 900 + b, peaky=1.5) for b in range(B)])).to(gpu)
+    L = _lib.lib()
+    sizes = dict(ws=int(L.vasr_beam_workspace_bytes(B, T)), ids=B * T * 4, n=B * 4, score=B * 4)
+    bufs = {k: torch.full((((n + 15) // 16) * 16 + 2 * G,), 0xA5, dtype=torch.uint8, device=gpu) for k, n in sizes.items()}
+    p = {k: v[G:].data_ptr() for k, v in bufs.items()}
+    _lib.check(L.vasr_beam_search_f32(lp.data_ptr(), B, T, V1, 0, 128, -5.0, -10.0, None, p["ids"], p["n"], p["score"],
+                                      p["ws"], sizes["ws"], torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for k, buf in bufs.items():
+        assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + sizes[k]:] == 0xA5).all()), f"write outside {k}"
+    assert int(bufs["n"][G : G + 4 * B].view(torch.int32).min()) > 0
+
+
+@pytest.mark.gpu
 def test_device_beam_search_randomised_cases(gpu):
     """Sixty cases of tests/devtools/fuzz_beam.py (posterior shape, length, beam width, LM and its weights all drawn at
     random; 4 000 cases of it ran clean when this test was added)."""

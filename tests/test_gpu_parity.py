@@ -404,3 +404,37 @@ def test_strongly_ragged_batch_skipped_tiles_match_oracle(gpu):
     clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
     assert clear.float().mean() > 0.9
+
+
+@pytest.mark.parametrize("model,B,L", [("quartznet12x1_vi", 3, 20321), ("quartznet15x5", 2, 48000), ("quartznet12x1_vi", 1, 257)])
+def test_no_writes_outside_the_workspace_and_the_outputs(gpu, model, B, L):
+    """Every buffer the fused call writes sits between two guard regions holding a sentinel; nothing outside the
+    declared sizes (vasr_workspace_bytes, [B][T'] outputs) may change."""
+    from viet_asr_amd import _lib, configs, synth
+    cfg = configs.builtin(model)
+    jas = cfg["JasperEncoder"]["jasper"]
+    V1 = len(cfg["labels"]) + 1
+    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 7), synth.decoder_state_dict(1024, V1, 7))
+    sig, lens = synth.audio_batch(B, L, 7, ragged=B > 1)
+    wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    _, t1 = eng.frames(L)
+    G = 1 << 16                                            # guard bytes on each side
+
+    def guarded(nbytes):
+        buf = torch.full((((nbytes + 15) // 16) * 16 + 2 * G,), 0xA5, dtype=torch.uint8, device=gpu)
+        return buf, buf[G : G + nbytes]
+
+    need = eng.handle.workspace_bytes(B, samples=L)
+    bufs = {k: guarded(n) for k, n in dict(ws=need, ids=B * t1 * 4, id_len=B * 4, pred=B * t1 * 8, enc_len=B * 4,
+                                           logp=B * t1 * V1 * 4).items()}
+    p = {k: v[1].data_ptr() for k, v in bufs.items()}
+    _lib.check(_lib.lib().vasr_transcribe_greedy_f32(eng.handle.h, wav.data_ptr(), ln.data_ptr(), B, L, p["pred"], p["ids"],
+                                                     p["id_len"], p["logp"], p["enc_len"], p["ws"], need,
+                                                     torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for k, (whole, inner) in bufs.items():
+        n = inner.numel()
+        assert bool((whole[:G] == 0xA5).all()) and bool((whole[G + n :] == 0xA5).all()), f"write outside {k}"
+    ref = eng.forward(wav, ln, want_logp=True)             # and the guarded call computed the same thing
+    assert torch.equal(bufs["ids"][1].view(torch.int32).view(B, t1)[0, : int(ref["id_len"][0])], ref["ids"][0, : int(ref["id_len"][0])])
+    assert torch.equal(bufs["logp"][1].view(torch.float32).view(B, t1, V1), ref["logp"])
