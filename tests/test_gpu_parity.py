@@ -409,7 +409,9 @@ def test_strongly_ragged_batch_skipped_tiles_match_oracle(gpu):
 @pytest.mark.parametrize("model,B,L", [("quartznet12x1_vi", 3, 20321), ("quartznet15x5", 2, 48000), ("quartznet12x1_vi", 1, 257)])
 def test_no_writes_outside_the_workspace_and_the_outputs(gpu, model, B, L):
     """Every buffer the fused call writes sits between two guard regions holding a sentinel; nothing outside the
-    declared sizes (vasr_workspace_bytes, [B][T'] outputs) may change."""
+    declared sizes (vasr_workspace_bytes, [B][T'] outputs) may change.  The scratch itself starts filled with NaNs and
+    the results must equal an ordinary call's bit for bit: no kernel consumes scratch it (or a predecessor) has not
+    written, padding columns included."""
     from viet_asr_amd import _lib, configs, synth
     cfg = configs.builtin(model)
     jas = cfg["JasperEncoder"]["jasper"]
@@ -427,6 +429,7 @@ def test_no_writes_outside_the_workspace_and_the_outputs(gpu, model, B, L):
     need = eng.handle.workspace_bytes(B, samples=L)
     bufs = {k: guarded(n) for k, n in dict(ws=need, ids=B * t1 * 4, id_len=B * 4, pred=B * t1 * 8, enc_len=B * 4,
                                            logp=B * t1 * V1 * 4).items()}
+    bufs["ws"][1].fill_(0xFF)        # every float of the scratch starts as NaN: nothing may be read before it is written
     p = {k: v[1].data_ptr() for k, v in bufs.items()}
     _lib.check(_lib.lib().vasr_transcribe_greedy_f32(eng.handle.h, wav.data_ptr(), ln.data_ptr(), B, L, p["pred"], p["ids"],
                                                      p["id_len"], p["logp"], p["enc_len"], p["ws"], need,
