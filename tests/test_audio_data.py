@@ -102,6 +102,35 @@ def test_randomised_resampler_and_greedy_tail_cases(gpu):
 
 
 @pytest.mark.gpu
+def test_manifest_transcription_equals_file_by_file_calls(gpu, tmp_path):
+    """VietASR.transcribe_manifest: duration-sorted, batched, pipelined and row-independent -- the transcripts of the
+    reference-style one-file-at-a-time loop (infer.py:194-206), in manifest order, and a WER of 0 against them."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.infer import VietASR
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_p, dec_p = str(tmp_path / "JasperEncoder-STEP-1.pt"), str(tmp_path / "JasperDecoderForCTC-STEP-1.pt")
+    torch.save({k: torch.as_tensor(v) for k, v in synth.encoder_state_dict(jas, 64, 3).items()}, enc_p)
+    torch.save({k: torch.as_tensor(v) for k, v in synth.decoder_state_dict(1024, 91, 3).items()}, dec_p)
+    asr = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="greedy")
+    rng = np.random.default_rng(8)
+    lens = [9000, 31000, 16000, 16000, 4000, 25000, 8000, 12000, 20000]
+    rates = [16000] * 8 + [8000]
+    paths = []
+    for i, (n, sr) in enumerate(zip(lens, rates)):
+        p = str(tmp_path / f"u{i}.wav")
+        audio.write_wav(p, (0.1 * rng.standard_normal(n)).astype(np.float32), sr)
+        paths.append(p)
+    alone = [asr.transcribe(*audio.read_wav(p)) for p in paths]            # transcribe(signal, sample_rate)
+    man = str(tmp_path / "m.json")
+    with open(man, "w", encoding="utf-8") as f:
+        for p, n, sr, t in zip(paths, lens, rates, alone):
+            f.write(json.dumps({"audio_filepath": p, "duration": n / sr, "text": t}, ensure_ascii=False) + "\n")
+    hyps, wer = asr.transcribe_manifest(man, batch_size=4)
+    assert hyps == alone and wer == 0.0
+
+
+@pytest.mark.gpu
 def test_randomised_front_end_cases(gpu):
     """Forty cases of tests/devtools/fuzz_frontend.py: batch shapes, ragged lengths, exact hop multiples, rows of 1-3
     frames (NaN statistics like the reference), silent and loud rows.  Log-mel before normalisation within MEL_TOL,

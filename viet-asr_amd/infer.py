@@ -109,6 +109,45 @@ class VietASR:
         sigs = [self._to_model_rate(s, sample_rate) for s in signals]
         return self._fused_engine().transcribe_beam(sigs, self.beam.decoder, self.beam.beam_width, row_independent)
 
+    def transcribe_manifest(self, manifest_filepath, batch_size=64, row_independent=True):
+        """Greedy transcripts of every entry of a NeMo JSON-lines manifest (parts/manifest.py:21-94), in manifest order,
+        plus the word error rate against the entries' ``text`` (None when no entry has one).
+
+        The reference CLI walks a directory one file at a time (infer.py:194-206).  Here the entries are sorted by
+        duration, cut into batches of ``batch_size`` and pushed through the pipelined engine two batches at a time
+        (engine.QuartzNetCTC.launch); with row_independent=True (default) every transcript is what ``transcribe`` returns
+        for that file alone.  PCM WAV only; files at another rate are resampled on the device."""
+        import json
+        from . import audio
+        from .data_layer import word_error_rate
+        entries = []
+        for path in str(manifest_filepath).split(","):
+            with open(path, encoding="utf-8") as f:
+                entries += [json.loads(line) for line in f if line.strip()]
+        order = sorted(range(len(entries)), key=lambda i: float(entries[i].get("duration", 0.0)))
+        hyps, pending = [None] * len(entries), []
+
+        def collect(job):
+            idx, handle = job
+            for i, t in zip(idx, handle.texts()):
+                hyps[i] = t
+
+        for lo in range(0, len(order), batch_size):
+            idx = order[lo : lo + batch_size]
+            sigs = []
+            for i in idx:
+                x, sr = audio.read_wav(entries[i]["audio_filepath"])
+                sigs.append(self._to_model_rate(x, sr))
+            pending.append((idx, self._fused_engine().launch(sigs, row_independent)))
+            if len(pending) == 2:
+                collect(pending.pop(0))
+        for job in pending:
+            collect(job)
+        refs = [e.get("text") for e in entries]
+        scored = [i for i, r in enumerate(refs) if r]
+        wer = word_error_rate([hyps[i] for i in scored], [refs[i] for i in scored]) if scored else None
+        return hyps, wer
+
     def launch_batch(self, signals, sample_rate=None, row_independent=False):
         """Asynchronous ``transcribe_batch``: returns a handle at once, ``.texts()`` waits (engine.QuartzNetCTC.launch)."""
         return self._fused_engine().launch(self._batch_signals(signals, sample_rate), row_independent)
