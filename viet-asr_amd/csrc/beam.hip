@@ -387,7 +387,10 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
         else key = hmix(key, (unsigned long long)c);
       }
       unsigned long long k = hmix(key, (unsigned long long)(c + 7)) | 1ull;   // (prefix, last char)
-      int i = (int)(k & (kSlots - 1));
+      // home slot and probe stride from the upper bits (bit 0 of k is forced to 1: the low bits would reach only the
+      // odd slots); an odd stride visits every slot of the power-of-two table -- double hashing, no primary clustering
+      int i = (int)((k >> 17) & (kSlots - 1));
+      const int stride = (int)((k >> 40) & (kSlots - 1)) | 1;
       while (true) {
         const unsigned long long e = sl.key[i];
         if (e == k) break;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
           if (old == 0ull) { sl.src[i] = (bi << 8) | c; break; }
           if (old == k) break;
         }
-        i = (i + 1) & (kSlots - 1);
+        i = (i + stride) & (kSlots - 1);
       }
       atomicMax(&sl.mx[i], ord64(s.logit + lp[c]));
       pair_slot[p] = (unsigned short)i;
@@ -406,7 +409,12 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     for (int p = tid; p < nb * nc; p += kThreads) {
       const int i = pair_slot[p];
       const double score = beams[p / nc].logit + lp[cand[p % nc]];
-      atomicAdd(&sl.sum[i], (unsigned long long)(exp(score - unord64(sl.mx[i])) * kFix));
+      // exp(score - max) through the hardware 2^x (v_exp_f32, 1 ulp): the library's fp64 exp was most of this phase
+      // (150+ fp64 instructions per pair, three rounds of them per frame at 1434 pairs), and the sum only has to carry
+      // the 1e-7 a float term gives -- the log of it is compared at 1e-3.  exp2(0) is exactly 1, so a slot with a
+      // single contributor still holds exactly 2^44.
+      const float e = __builtin_amdgcn_exp2f((float)((score - unord64(sl.mx[i])) * 1.4426950408889634));
+      atomicAdd(&sl.sum[i], (unsigned long long)((double)e * kFix));
     }
     lds_barrier();
     BEAM_TICK(1)
