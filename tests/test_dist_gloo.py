@@ -53,7 +53,11 @@ def _worker(rank, world, port, q):
 
             @property
             def data_iterator(self):
-                return iter([(torch.full((2 + rank, 3 + 2 * rank), float(rank)),)])
+                # rank 0 has TWO batches, rank 1 one: the executor must not hang in all_gather (unequal batch counts)
+                class It(list):
+                    pass
+                return It([(torch.full((2 + rank, 3 + 2 * rank), float(rank)),)] +
+                          ([(torch.full((1, 4), 7.0),)] if rank == 0 else []))
 
         class Twice(NonTrainableNM):
             input_ports = property(lambda self: {"x": NeuralType(("B", "T"))})
@@ -67,10 +71,35 @@ def _worker(rank, world, port, q):
         out = nf.infer([y])
         if rank == 0:
             parts = out[0]
-            assert [tuple(p.shape) for p in parts] == [(2, 3), (3, 5)]       # de-padded per-rank shapes
-            assert parts[0].eq(1).all() and parts[1].eq(3).all()
+            # de-padded per-rank shapes; the second step has a part from rank 0 only
+            assert [tuple(p.shape) for p in parts] == [(2, 3), (3, 5), (1, 4)]
+            assert parts[0].eq(1).all() and parts[1].eq(3).all() and parts[2].eq(15).all()
         else:
             assert out is None                                               # only rank 0 keeps results
+
+        # -- dist.transcribe_sharded with a stand-in engine (same interface as engine.QuartzNetCTC): 5 utterances over
+        #    2 ranks -> shards of 3 and 2 with different padded widths; every rank gets all transcripts in order
+        class FakeEngine:
+            device = torch.device("cpu")
+            labels = list("abcdefghij")
+
+            def forward(self, wav, length):
+                ids = torch.zeros((wav.shape[0], wav.shape[1]), dtype=torch.int32)
+                n = torch.zeros((wav.shape[0],), dtype=torch.int32)
+                for b in range(wav.shape[0]):          # "transcript" = the first length[b] % 7 + 1 samples as label ids
+                    k = int(length[b]) % 7 + 1
+                    ids[b, :k] = wav[b, :k].to(torch.int32)
+                    n[b] = k
+                return dict(ids=ids, id_len=n)
+
+            def texts(self, ids, n):
+                return ["".join(self.labels[c] for c in ids[b, : n[b]].tolist()) for b in range(ids.shape[0])]
+
+        import numpy as np
+        sigs = [np.arange(L, dtype=np.float32) % 10 for L in (9, 15, 11, 30, 8)]
+        want = ["".join("abcdefghij"[int(v)] for v in s[: len(s) % 7 + 1]) for s in sigs]
+        assert vdist.transcribe_sharded(FakeEngine(), sigs) == want
+        assert vdist.transcribe_sharded(FakeEngine(), sigs[:1]) == want[:1]      # fewer utterances than ranks
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))

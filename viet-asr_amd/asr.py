@@ -57,11 +57,17 @@ class AudioToMelSpectrogramPreprocessor(NonTrainableNM):
             n_fft=n_fft, preemph=preemph, features=features, lowfreq=lowfreq, highfreq=highfreq, log=log,
             log_zero_guard_type=log_zero_guard_type, log_zero_guard_value=log_zero_guard_value,
             frame_splicing=frame_splicing, stft_conv=stft_conv, pad_value=pad_value, mag_power=mag_power))
-        # dither is training-time noise and pad_to only fires in eval mode, which the executor never sets on
-        # this module (quirk Q1); infer.py:89-90 forces both to 0 anyway.
-        if dither and dither > 1e-4:
-            raise NotImplementedError("dither > 0 (random noise) is not part of the inference path")
-        self.dither, self.pad_to = dither, pad_to
+        # dither adds random noise to the signal (features.py:250-251): not reproducible, not part of the inference
+        # path -- infer.py:89 forces it to 0 and so must the caller here.  pad_to: FilterbankFeatures zero-pads T up to
+        # a multiple of self.pad_to in training mode -- the mode the executor leaves this NonTrainableNM in, quirk Q1 --
+        # and of 16 in eval mode (features.py:292-300); infer.py:90 sets 0 = no padding.  A non-zero pad_to is applied
+        # here the way the reference's (training-mode) branch does it: extra all-zero frames appended on the device.
+        if dither:
+            raise NotImplementedError("dither > 0 (random noise on the input) is not implemented: pass dither=0 as "
+                                      "infer.py:89 does")
+        if pad_to is not None and (int(pad_to) != pad_to or pad_to < 0):
+            raise ValueError(f"pad_to must be a non-negative integer, got {pad_to!r}")
+        self.dither, self.pad_to = dither, int(pad_to or 0)
         self.win_length, self.hop_length = self._desc["win_length"], self._desc["hop_length"]
         self._handle = None
 
@@ -81,7 +87,10 @@ class AudioToMelSpectrogramPreprocessor(NonTrainableNM):
         return torch.ceil(seq_len.float() / self.hop_length).to(dtype=torch.long)
 
     def forward(self, input_signal, length):
-        return stages.melspec(self._get_handle(), input_signal, length)
+        mel, seq = stages.melspec(self._get_handle(), input_signal, length)
+        if self.pad_to > 0 and mel.shape[-1] % self.pad_to:
+            mel = torch.nn.functional.pad(mel, (0, self.pad_to - mel.shape[-1] % self.pad_to), value=self._desc.get("pad_value", 0.0))
+        return mel, seq
 
 
 class _MaskedConvParams(nn.Module):
@@ -279,7 +288,13 @@ class BeamSearchDecoderWithLM(NonTrainableNM):
             input_tensor
 
     def forward(self, log_probs, log_probs_length=None):
-        texts = self.decoder.decode_batch(log_probs, beam_width=self.beam_width)
+        # Batch 1 (all the reference accepts, :96) searches every frame, like pyctcdecode on log_probs[0].  In a padded
+        # batch the shorter rows' trailing frames hold the head's output on masked input, not blanks: each row is
+        # searched over its own log_probs_length[b] frames (float lengths from the encoder, quirk Q3, truncated).
+        frames = None
+        if log_probs.shape[0] > 1 and log_probs_length is not None:
+            frames = torch.as_tensor(log_probs_length).to(torch.float64).floor().clamp(0, log_probs.shape[1]).to(torch.int32)
+        texts = self.decoder.decode_batch(log_probs, beam_width=self.beam_width, frames=frames)
         return texts[0] if len(texts) == 1 else texts
 
 

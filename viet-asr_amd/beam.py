@@ -44,18 +44,35 @@ def read_arpa(path):
     return order, ngrams
 
 
+def _hstep_np(h, v):
+    """_hstep on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        return (h ^ (v.astype(np.uint64) + np.uint64(1))) * np.uint64(_FNV_PRIME)
+
+
 def _table(keys, cap):
+    """Open-addressing table the kernel probes linearly from ``key % cap`` (csrc/beam.hip lm_find): returns (slots
+    [cap] u64, position of every key).  Built in vectorised rounds -- a pure-Python insert loop takes minutes on the
+    multi-million-entry models the reference ships (.MISSING_LARGE_BLOBS:4-7): in round r every unplaced key looks at
+    slot (home + r) % cap; one key per free slot wins, the others move on.  A key only ever steps over slots that are
+    occupied for good, so every probe chain from a key's home to its slot is gap-free, which is all lookup needs."""
+    keys = np.asarray(keys, dtype=np.uint64) | np.uint64(1)
+    if len(np.unique(keys)) != len(keys):
+        raise ValueError("64-bit hash collision while building the n-gram tables")
     slots = np.zeros(cap, dtype=np.uint64)
-    where = {}
-    for k in keys:
-        k |= 1
-        i = k % cap
-        while slots[i] != 0:
-            if int(slots[i]) == k:
-                raise ValueError("64-bit hash collision while building the n-gram tables")
-            i = (i + 1) % cap
-        slots[i] = k
-        where[k] = i
+    where = np.full(len(keys), -1, dtype=np.int64)
+    pos = (keys % np.uint64(cap)).astype(np.int64)
+    todo = np.arange(len(keys))
+    while len(todo):
+        p = pos[todo]
+        free = slots[p] == 0
+        cand, cp = todo[free], p[free]
+        _, first = np.unique(cp, return_index=True)          # one winner per free slot
+        win = cand[first]
+        slots[pos[win]] = keys[win]
+        where[win] = pos[win]
+        todo = todo[where[todo] < 0]
+        pos[todo] = (pos[todo] + 1) % cap
     return slots, where
 
 
@@ -95,21 +112,29 @@ class DeviceLM:
         vcap = _cap(len(vkeys))
         vslots, vwhere = _table(vkeys, vcap)
         vid = np.full(vcap, -1, dtype=np.int32)
-        for k, v in zip(vkeys, vvals):
-            vid[vwhere[k | 1]] = v
+        vid[vwhere] = np.asarray(vvals, dtype=np.int32)
+        # n-gram keys: hash(n, id_1 .. id_n), one vectorised pass per order
+        by_n = {}
+        for ng, pb in ngrams.items():
+            by_n.setdefault(len(ng), ([], []))
+            by_n[len(ng)][0].append([wid[w] for w in ng])
+            by_n[len(ng)][1].append(pb)
         nkeys, nvals = [], []
-        for ng, (p, bo) in ngrams.items():
-            h = _hstep(h0, len(ng))
-            for w in ng:
-                h = _hstep(h, wid[w])
+        for n, (ids, pbs) in sorted(by_n.items()):
+            ids = np.asarray(ids, dtype=np.uint64).reshape(len(ids), n)
+            h = _hstep_np(np.full(len(ids), h0, dtype=np.uint64), np.full(len(ids), n, dtype=np.uint64))
+            for i in range(n):
+                h = _hstep_np(h, ids[:, i])
             nkeys.append(h)
-            nvals.append((p, bo))
+            nvals.append(np.asarray(pbs, dtype=np.float32).reshape(len(ids), 2))
+        nkeys = np.concatenate(nkeys) if nkeys else np.zeros(0, dtype=np.uint64)
+        nvals = np.concatenate(nvals) if nvals else np.zeros((0, 2), dtype=np.float32)
         ncap = _cap(len(nkeys))
         nslots, nwhere = _table(nkeys, ncap)
         nval = np.zeros((ncap, 2), dtype=np.float32)
-        for k, v in zip(nkeys, nvals):
-            nval[nwhere[k | 1]] = v
+        nval[nwhere] = nvals
         self.order, self.n_words, self.n_ngrams = order, len(words), len(ngrams)
+        self.table_load = len(nkeys) / ncap
         self._h = C.c_void_p()
         _lib.check(L.vasr_lm_create(vslots.ctypes.data, vid.ctypes.data, vcap, nslots.ctypes.data, nval.ctypes.data,
                                     ncap, order, wid["<s>"], wid["</s>"], wid["<unk>"], float(alpha), float(beta),
@@ -127,6 +152,18 @@ class DeviceLM:
             pass
 
 
+def lm_file_usable(path):
+    """True for an ARPA text model; False (with the reason) for anything else, e.g. KenLM's binary formats."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(64)
+    except OSError as e:
+        return False, str(e)
+    if not head.lstrip().startswith(b"\\data\\"):
+        return False, "only ARPA text n-gram models are supported (KenLM binary formats are a third-party layout)"
+    return True, ""
+
+
 class BeamSearchDecoder:
     def __init__(self, labels, lm_path=None, alpha=0.5, beta=1.5, token_min_logp=-5.0, beam_prune_logp=-10.0):
         self.labels = list(labels)
@@ -134,6 +171,14 @@ class BeamSearchDecoder:
             raise NotImplementedError("beam search supports at most 127 labels + blank")
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
         self.token_min_logp, self.beam_prune_logp = token_min_logp, beam_prune_logp
+        # An LM that cannot be used is decided HERE, not at the first decode: the reference checks at construction and
+        # falls back to searching without a language model (infer.py:117-128, kenlm import failure -> lm_path = None).
+        if lm_path:
+            ok, why = lm_file_usable(lm_path)
+            if not ok:
+                import warnings
+                warnings.warn(f"language model {lm_path!r} not usable ({why}); beam search runs without a language model")
+                lm_path = None
         self.lm_path, self.alpha, self.beta = lm_path, alpha, beta
         self._lm = None
         self._ws = None

@@ -341,6 +341,40 @@ def _pad_to(t, shape):
     return out
 
 
+_GATHER_DTYPES = [torch.float32, torch.int64, torch.int32, torch.float64, torch.float16, torch.bfloat16, torch.int16,
+                  torch.int8, torch.uint8, torch.bool]
+
+
+def _gather_ragged(v, device):
+    """all_gather of one tensor per rank whose shapes may differ, as PtActions._infer does it (actions.py:774-807:
+    all_gather(shape) -> pad to max -> all_gather(padded) -> de-pad), extended by one case: ``v is None`` = this rank
+    has no batch left; its (empty) part is dropped.  Returns the de-padded parts of the ranks that had one, in rank
+    order, or None when no rank had a tensor."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    desc = torch.full((10,), -1, dtype=torch.int64, device=device)       # [ndim, dtype code, dims...]
+    if v is not None:
+        if v.dim() > 8:
+            raise ValueError("tensors of more than 8 dimensions are not gathered")
+        desc[0], desc[1] = v.dim(), _GATHER_DTYPES.index(v.dtype)
+        if v.dim():
+            desc[2 : 2 + v.dim()] = torch.tensor(v.shape, dtype=torch.int64)
+    descs = [torch.empty_like(desc) for _ in range(world)]
+    dist.all_gather(descs, desc)
+    descs = [d.tolist() for d in descs]
+    have = [d for d in descs if d[0] >= 0]
+    if not have:
+        return None
+    ndim, dtype = have[0][0], _GATHER_DTYPES[have[0][1]]
+    if any(d[0] != ndim or d[1] != have[0][1] for d in have):
+        raise ValueError("ranks returned tensors of different rank / dtype for one port")
+    mx = [max(d[2 + i] for d in have) for i in range(ndim)]
+    padded = _pad_to(v, mx) if v is not None else torch.zeros(mx, dtype=dtype, device=device)
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    return [g[tuple(slice(0, int(n)) for n in d[2 : 2 + ndim])] for g, d in zip(gathered, descs) if d[0] >= 0]
+
+
 class _Actions:
     """The inference half of PtActions (actions.py:104-221, 380-442, 639-821)."""
 
@@ -382,7 +416,12 @@ class _Actions:
                 module.eval()                     # NOT reached for NonTrainableNM (quirk Q1)
             call_set = {port: registered[t.unique_name] for port, t in call_args.items()}
             result = module(force_pt=True, **call_set)
-            if not isinstance(result, (tuple, list)):
+            # A module with ONE output port hands back that port's value, whatever its type: the batched beam decoder
+            # returns a Python list of B transcripts, which must not be zipped against its single port (the reference
+            # only ever sees a str there, batch 1: beam_search_decoder.py:95-102).
+            if len(module.output_ports) == 1 and not isinstance(result, tuple):
+                result = (result,)
+            elif not isinstance(result, (tuple, list)):
                 result = (result,)
             # results are zipped against output_ports order (actions.py:430-442)
             for name, value in zip(module.output_ports, result):
@@ -415,31 +454,45 @@ class _Actions:
         else:
             loader = dl.data_iterator
         values = {t.unique_name: [] for t in tensors}
+        n_steps = None
+        if distributed:
+            # The reference pads every rank to the same number of batches (DistributedSampler); a data layer that shards
+            # by itself (data_iterator) may leave ranks with different counts -- 5 utterances, 2 ranks, batch 2 gives 2
+            # and 1 -- and the rank with more would wait in all_gather for ever.  Every rank therefore takes
+            # max-over-ranks steps; a rank that has run out joins the collectives with an empty contribution.
+            if not hasattr(loader, "__len__"):
+                raise ValueError("AllGpu placement needs a data iterator with a length")
+            n = torch.tensor([len(loader)], dtype=torch.int64, device=dl._device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            n_steps = int(n.item())
         with torch.no_grad():
-            for data in loader:
-                if isinstance(data, torch.Tensor):
-                    data = (data,)
-                batch = [d.to(dl._device) if isinstance(d, torch.Tensor) else d for d in data]   # H2D: actions.py:740-746
-                registered = {dl_tensors[n].unique_name: v for n, v in zip(dl_out_names, batch) if n in dl_tensors}
-                self.forward_pass(chain, registered)
+            it = iter(loader)
+            step = 0
+            while True:
+                data = next(it, None)
+                if data is None and (n_steps is None or step >= n_steps):
+                    break
+                step += 1
+                registered = None
+                if data is not None:
+                    if isinstance(data, torch.Tensor):
+                        data = (data,)
+                    batch = [d.to(dl._device) if isinstance(d, torch.Tensor) else d for d in data]   # H2D: actions.py:740-746
+                    registered = {dl_tensors[n].unique_name: v for n, v in zip(dl_out_names, batch) if n in dl_tensors}
+                    self.forward_pass(chain, registered)
                 for t in tensors:
-                    v = registered[t.unique_name]
-                    if distributed and isinstance(v, torch.Tensor):
-                        # all_gather(shape) -> pad to max -> all_gather(padded) -> de-pad   (actions.py:774-807)
-                        world = dist.get_world_size()
-                        shape = torch.tensor(v.shape, device=v.device)
-                        shapes = [torch.empty_like(shape) for _ in range(world)]
-                        dist.all_gather(shapes, shape)
-                        mx = torch.stack(shapes).max(dim=0).values
-                        padded = _pad_to(v, mx.tolist())
-                        gathered = [torch.empty_like(padded) for _ in range(world)]
-                        dist.all_gather(gathered, padded)
-                        parts = [g[tuple(slice(0, int(s)) for s in sh)] for g, sh in zip(gathered, shapes)]
+                    v = registered[t.unique_name] if registered is not None else None
+                    if distributed and (v is None or isinstance(v, torch.Tensor)):
+                        parts = _gather_ragged(v, dl._device)
+                        if parts is None:             # no rank holds a tensor for this port (e.g. strings): keep local
+                            if v is not None:
+                                values[t.unique_name].append(v)
+                            continue
                         if offload_to_cpu:
                             parts = [p.cpu() for p in parts]
                         if dist.get_rank() == 0:
                             values[t.unique_name] += parts
-                    else:
+                    elif v is not None:
                         if offload_to_cpu and isinstance(v, torch.Tensor):
                             v = v.cpu()
                         values[t.unique_name].append(v)

@@ -41,8 +41,8 @@ def mel_filterbank(sr=16000, n_fft=512, n_mels=64, fmin=0.0, fmax=None):
 def frontend_description(pre_cfg):
     """AudioToMelSpectrogramPreprocessor kwargs (audio_preprocessing.py:314-373) -> library front-end dict.
 
-    Mirrors the constructor's argument handling and its ValueErrors; dither and pad_to are
-    accepted and must be inference values (infer.py:89-90 forces dither=0, pad_to=0).
+    Mirrors the constructor's argument handling and its ValueErrors; dither / pad_to are the module's business
+    (asr.AudioToMelSpectrogramPreprocessor).
     """
     c = dict(pre_cfg)
     sr = int(c.get("sample_rate", 16000))
@@ -60,9 +60,13 @@ def frontend_description(pre_cfg):
         raise ValueError("got an invalid value for either n_window_size or n_window_stride. "
                          "Both must be positive ints.")
     n_fft = c.get("n_fft") or 2 ** math.ceil(math.log2(nws))
-    if c.get("stft_conv", False):
-        raise NotImplementedError("stft_conv=True (torch_stft conv STFT) is not implemented; the vi config "
-                                  "uses stft_conv=false")
+    # stft_conv=True (configs/quartznet15x5.yaml:26) routes the STFT through the third-party torch_stft package
+    # (features.py:155-166), neither vendored nor installed: "parity unpinned".  What that package publishes is the same
+    # centred, reflect-padded DFT computed as a conv1d with a Fourier basis, windowed by
+    # scipy.signal.get_window(window, win_length, fftbins=True) -- the PERIODIC window, where torch.stft gets the
+    # symmetric one (features.py:178) -- and returned as a magnitude that features.py:260-261 squares again.  The kernels
+    # therefore run the same transform with the periodic window (power = re^2 + im^2 instead of sqrt(.)^2: <= 1 ulp).
+    periodic = bool(c.get("stft_conv", False))
     if c.get("log", True) is not True or c.get("log_zero_guard_type", "add") != "add":
         raise NotImplementedError("only log=True with log_zero_guard_type='add' is implemented")
     if float(c.get("mag_power", 2.0)) != 2.0 or int(c.get("frame_splicing", 1)) != 1:
@@ -75,7 +79,7 @@ def frontend_description(pre_cfg):
            "bartlett": torch.bartlett_window}
     if window not in fns:
         raise NotImplementedError(f"window {window!r} is not implemented")
-    win = fns[window](nws, periodic=False).to(torch.float32).numpy()
+    win = fns[window](nws, periodic=periodic).to(torch.float32).numpy()
     n_mels = int(c.get("features", 64))
     fb = mel_filterbank(sr, n_fft, n_mels, c.get("lowfreq", 0) or 0.0, c.get("highfreq") or sr / 2)
     norm = c.get("normalize", "per_feature")
