@@ -1,27 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- whole-job throughput of the viet-asr hot path on N MI355X of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model quartznet15x5] [--batch 64] [--seconds 10]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--gemm ...]
 
-One *step* = one pass of the hot path (wav already resident in HBM -> mel -> QuartzNet encoder ->
-CTC head -> greedy argmax -> CTC collapse) over one batch of synthetic 16 kHz audio per GPU, then
-the gather of the collapsed id sequences to every rank (the reference's _infer gathers each
-returned tensor with all_gather, nemo/backends/pytorch/actions.py:774-807).  Utterances are
-independent, so ranks shard them with no other data-path collective: weak scaling, per-GPU work
-fixed.  Workload at any N: BASELINE.json configs[2] = QuartzNet15x5, batch 64 x 10 s per GPU
-(the configuration the metric/target is quoted on).
+One *step* = one pass of the hot path over one batch of synthetic audio per GPU (input already resident in HBM),
+then the gather of the collapsed id sequences to every rank (the reference's _infer gathers each returned tensor with
+all_gather, nemo/backends/pytorch/actions.py:774-807).  Utterances are independent, so ranks shard them with no other
+data-path collective: weak scaling, per-GPU work fixed.
+
+Workloads (BASELINE.json `configs`, 0-based):
+  --config 3 (default)  configs[2]  QuartzNet15x5 greedy CTC, 64 x 10 s per GPU -- the configuration the metric and the
+                                    north-star target are quoted on
+  --config 2            configs[1]  QuartzNet12x1 (Vietnamese head), 32 x 10 s, greedy
+  --config 4            configs[3]  QuartzNet15x5 log-probs -> device beam search, beam_width 128, with a synthetic 3-gram
+                                    ARPA model of ~1.2e5 n-grams (the reference's KenLM binaries are absent), 64 x 10 s;
+                                    the search of batch k runs on a side stream under the acoustic pass of batch k + 1
+  --config 5            configs[4]  one GPU's shard of the 8-GPU job: 512 clips of 30 s at 8 kHz -> device resampling to
+                                    16 kHz -> QuartzNet15x5 greedy
+
+`python bench.py --gpus N` with N > 1 starts its own N ranks (re-executes itself under torch.distributed.run on a free
+port of 127.0.0.1); launched by torchrun / the driver it uses the ranks it is given.  One process per GPU, backend
+"nccl" = RCCL over xGMI.
 
 Prints ONE JSON line on rank 0 with the driver contract keys plus
-  roofline      -- dominant kernel (1x1-conv GEMM, fp32 operands as 3 x bf16 on the bf16 MFMA pipe): executed flops /
-                   summed kernel durations (per-launch dispatch timestamps, hipExtLaunchKernelGGL) vs the 2.5 PFLOP/s
-                   nominal peak, plus the rate a bare MFMA stream sustains on this box (sustained_peak)
+  roofline      -- dominant kernel (1x1-conv GEMM): executed MFMA flops / summed kernel durations (per-launch dispatch
+                   timestamps, hipExtLaunchKernelGGL) vs the dense MFMA peak of the operand type
   depthwise     -- depthwise-conv kernels: algorithmic HBM bytes / summed kernel durations vs 8 TB/s
-  cpu_baseline  -- the CPU oracle (same ATen ops as the reference) on this box's host cores
+  beam          -- (--config 4) the search kernel: ms per batch, workgroups (= CUs) it occupies
+  cpu_baseline  -- the CPU oracle (same ATen ops as the reference) on this box's host cores, bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,14 +49,30 @@ from viet_asr_amd import _lib, configs, synth  # noqa: E402
 from viet_asr_amd.engine import QuartzNetCTC  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0 # same guide, "Peak BF16/FP16 MFMA" dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E spec peak
+
+WORKLOADS = {   # config -> (model, batch per GPU, clip seconds, input rate, decoder)
+    2: ("quartznet12x1_vi", 32, 10.0, 16000, "greedy"),
+    3: ("quartznet15x5", 64, 10.0, 16000, "greedy"),
+    4: ("quartznet15x5", 64, 10.0, 16000, "beam"),
+    5: ("quartznet15x5", 512, 30.0, 8000, "greedy"),
+}
+# MFMA products issued per fp32 multiply-add, operand type, dtype string of the JSON line
+GEMM_MODES = {
+    "f16x2": (3.0, "f16", "f32 via 2xf16 split operands (22-bit significands, 3 f16 MFMA products per multiply, fp32 accumulate)"),
+    "bf16x3": (6.0, "bf16", "f32 via 3xbf16 split operands (6 bf16 MFMA products per multiply, fp32 accumulate)"),
+    "bf16x2": (3.0, "bf16", "REDUCED: 2xbf16 split operands (16-bit significands, 3 bf16 MFMA products, fp32 accumulate) -- "
+                            "opt-in mode, not the headline configuration"),
+    "fp32": (1.0, "f32", "f32"),
+}
 
 
 def pmc_traffic(prefix):
     """Launch-weighted mean HBM bytes per launch of the kernels whose name starts with ``prefix``, from the newest
-    committed PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
-    tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no summary exists."""
+    COMMITTED PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_round.sh;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  An offline figure: reported under traffic_offline, never as a
+    live measurement.  None when no summary exists."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_summary.json")))
     if not files:
@@ -56,30 +86,63 @@ def pmc_traffic(prefix):
     return (round(b / n) if n else None), os.path.basename(files[-1])
 
 
-def cpu_baseline(model, seed, seconds, budget_s=20.0):
-    """Time the CPU oracle (port of the reference path on the same ATen CPU ops) on a bounded sample."""
+def cpu_baseline(model, seed, decoder, lm_path, budget_s=30.0):
+    """Time the CPU oracle (port of the reference path on the same ATen CPU ops) on a bounded sample of the workload:
+    best of >= 5 runs after one warm-up, inside ~30 s; the intra-op thread count is set explicitly and reported."""
     from oracle import quartznet_oracle as O   # checker / baseline only -- never on the product path
     cfg = configs.builtin(model)
     jas = cfg["JasperEncoder"]["jasper"]
     enc_sd = synth.encoder_state_dict(jas, 64, seed)
     dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
-    b = 8
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if decoder == "beam":
+        from oracle import beam_oracle as BO
+        b, seconds = 1, 2.0       # the restated pyctcdecode loop is pure Python: one 2 s utterance is ~10 s of CPU
+        lm = BO.LanguageModel(BO.NgramLM.from_arpa(lm_path), alpha=0.5, beta=1.5) if lm_path else None
+    else:
+        b, seconds = 4, 10.0
     sig, lens = synth.audio_batch(b, int(seconds * 16000), seed, ragged=False)
-    cores = torch.get_num_threads()
+
+    def once():
+        r = O.forward_all(sig, lens, enc_sd, dec_sd, jas)
+        if decoder == "beam":
+            return [BO.decode(r["logp"][i].numpy(), cfg["labels"], 128, lm=lm, table_fill=1434, eos_ignores_cache=True)
+                    for i in range(b)]
+        return O.ctc_decode_strings(r["pred"], cfg["labels"])
+
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.forward_all(sig, lens, enc_sd, dec_sd, jas)          # warm-up
+        once()                                                   # warm-up
         warm = time.perf_counter() - t0
         times = []
-        while len(times) < 3 and sum(times) + warm < budget_s:
+        while len(times) < 5 or (len(times) < 9 and warm + sum(times) < budget_s):
             t0 = time.perf_counter()
-            r = O.forward_all(sig, lens, enc_sd, dec_sd, jas)
-            O.ctc_decode_strings(r["pred"], cfg["labels"])
+            once()
             times.append(time.perf_counter() - t0)
-    best = min(times) if times else warm
+    best = min(times)
     return {"value": round(b * seconds / best, 2), "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
-            "sample": f"{model} greedy, batch {b} x {seconds:g} s, best of {max(len(times), 1)} after 1 warm-up",
-            "utts_per_sec": round(b / best, 3)}
+            "sample": f"{model} {decoder}{' beam 128 + 3-gram LM' if decoder == 'beam' else ''}, batch {b} x {seconds:g} s, "
+                      f"best of {len(times)} after 1 warm-up, torch.set_num_threads({cores})"
+                      + (" (acoustic model on all cores, the search loop is single-threaded Python)" if decoder == "beam" else ""),
+            "utts_per_sec": round(b / best, 3), "median_value": round(b * seconds / float(np.median(times)), 2)}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible HIP devices, found {have}; nothing was run\n")
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VASR_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -87,28 +150,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="quartznet15x5")
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--config", type=int, choices=sorted(WORKLOADS), default=3, help="BASELINE.json workload (see docstring)")
+    ap.add_argument("--model", default=None, help="override the workload's model")
+    ap.add_argument("--batch", type=int, default=None, help="override the workload's batch per GPU")
+    ap.add_argument("--seconds", type=float, default=None, help="override the workload's clip length")
     ap.add_argument("--ragged", action="store_true", help="lengths uniform in [L/2, L] instead of full clips")
+    ap.add_argument("--beam-width", type=int, default=128)
+    ap.add_argument("--no-lm", action="store_true", help="--config 4 without the n-gram model")
+    ap.add_argument("--no-overlap", action="store_true", help="--config 4: search on the acoustic stream (serialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-gemm", action="store_true", help="skip the comparison pass in the other GEMM arithmetic")
-    ap.add_argument("--gemm", choices=["bf16x3", "fp32", "bf16x2"], default="bf16x3",
-                    help="arithmetic of the 1x1-conv GEMMs: 3 x bf16 split operands on the bf16 MFMA pipe "
-                         "(fp32-equivalent accuracy, default) or exact-fp32 MFMA")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-launcher even for --gpus 1 (RCCL world of 1)")
+    ap.add_argument("--gemm", choices=sorted(GEMM_MODES), default=None,
+                    help="arithmetic of the 1x1-conv GEMMs (default: the library's default mode)")
     a = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and (a.gpus > 1 or a.spawn):
+        self_launch(a.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1 or os.environ.get("VASR_BENCH_FORCE_DIST"):      # the switch runs the gather path on a 1-GPU box
+    if world > 1 or os.environ.get("VASR_BENCH_FORCE_DIST") or os.environ.get("VASR_BENCH_LAUNCHED"):
         import torch.distributed as dist_
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)
@@ -116,17 +184,40 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)   # RCCL over xGMI
 
+    model, batch, seconds, rate, decoder = WORKLOADS[a.config]
+    model, batch, seconds = a.model or model, a.batch or batch, a.seconds or seconds
     seed = 3
-    cfg = configs.builtin(a.model)
+    cfg = configs.builtin(model)
     jas = cfg["JasperEncoder"]["jasper"]
     enc_sd = synth.encoder_state_dict(jas, 64, seed)
     dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
     eng = QuartzNetCTC(cfg, enc_sd, dec_sd, device=dev, gemm=a.gemm)
-    samples = int(a.seconds * 16000)
-    sig, lens = synth.audio_batch(a.batch, samples, seed + 100 * rank, ragged=a.ragged)
-    wav = torch.from_numpy(sig).to(dev)
-    ln = torch.from_numpy(lens).to(dev)
-    audio_sec_per_step = float(lens.sum()) / 16000.0
+    gemm = a.gemm or eng.handle.gemm_mode_name()
+    in_samples = int(seconds * rate)
+    sig, lens = synth.audio_batch(batch, in_samples, seed + 100 * rank, ragged=a.ragged)
+    wav_in = torch.from_numpy(sig).to(dev)
+    ln_in = torch.from_numpy(lens).to(dev)
+    audio_sec_per_step = float(lens.sum()) / rate
+    samples = int(seconds * 16000)               # at the model's rate
+
+    beam_dec, lm_path, lm_info = None, None, None
+    if decoder == "beam":
+        from viet_asr_amd.beam import BeamSearchDecoder
+        if not a.no_lm:        # every rank writes its own copy (deterministic, < 1 s)
+            lm_path = os.path.join(tempfile.mkdtemp(prefix="vasr_lm_"), "synthetic3.arpa")
+            synth.synthetic_arpa(lm_path, cfg["labels"], seed=seed)
+        beam_dec = BeamSearchDecoder(cfg["labels"], lm_path=lm_path, alpha=0.5, beta=1.5)
+        lm = beam_dec._get_lm()
+        if lm is not None:
+            lm_info = {"order": lm.order, "ngrams": lm.n_ngrams, "words": lm.n_words, "table_load": round(lm.table_load, 3)}
+
+    if rate != 16000:
+        from viet_asr_amd import audio
+
+    def acoustic_input():
+        if rate == 16000:
+            return wav_in, ln_in
+        return audio.resample(wav_in, ln_in, rate, 16000)
 
     gathered, inflight, n_steps = None, [None, None], 0
 
@@ -138,17 +229,23 @@ def main():
 
     def step():
         nonlocal gathered, n_steps
-        r = eng.forward(wav, ln, want_logp=False, want_pred=False)
+        wav, ln = acoustic_input()
+        if decoder == "beam":
+            r = eng.forward_beam(wav, ln, beam_dec, a.beam_width, overlap=not a.no_overlap)
+        else:
+            r = eng.forward(wav, ln, want_logp=False, want_pred=False)
         if dist is not None:
             # Result gather, one collective per returned tensor like actions.py:774-807.  Issued asynchronously on
             # RCCL's own stream into one of two buffers: the next batch's kernels do not wait for the other ranks, a
             # buffer is reused only after its previous gather has been waited for, and sync() drains both.
             if gathered is None:
                 gathered = [(torch.empty((world,) + tuple(r["ids"].shape), dtype=torch.int32, device=dev),
-                             torch.empty((world, a.batch), dtype=torch.int32, device=dev)) for _ in range(2)]
+                             torch.empty((world, batch), dtype=torch.int32, device=dev)) for _ in range(2)]
             slot = n_steps % 2
             n_steps += 1
             drain(slot)
+            if r.get("done") is not None:
+                torch.cuda.current_stream().wait_event(r["done"])     # the gather reads what the side stream wrote
             inflight[slot] = (dist.all_gather_into_tensor(gathered[slot][0], r["ids"], async_op=True),
                               dist.all_gather_into_tensor(gathered[slot][1], r["id_len"], async_op=True), r)
         return r
@@ -168,6 +265,7 @@ def main():
         r = step()
     sync()
     elapsed = time.perf_counter() - t0
+    rccl = None
     if dist is not None:
         last = (n_steps - 1) % 2       # the gathered copy of this rank's last batch must be what the engine returned
         if not (torch.equal(gathered[last][0][rank], r["ids"]) and torch.equal(gathered[last][1][rank], r["id_len"])):
@@ -178,112 +276,141 @@ def main():
         tot = torch.tensor([audio_sec_per_step], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         audio_all = float(tot.item())
+        ids_dev = torch.tensor([local], dtype=torch.int32, device=dev)
+        all_dev = torch.empty((world,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(all_dev, ids_dev)
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": all_dev.tolist()}
     else:
         audio_all = audio_sec_per_step
 
     # ---- second pass, same K steps, with per-kernel-class HIP events on the launch stream ----
+    wav16, ln16 = acoustic_input()
+    torch.cuda.synchronize()
     eng.handle.profile_begin()
     for _ in range(a.steps):
-        eng.forward(wav, ln, want_logp=False, want_pred=False)
+        eng.forward(wav16, ln16, want_logp=False, want_pred=False)
     torch.cuda.synchronize()
     prof = eng.handle.profile_end()
     # depthwise / pointwise launches carry their own (start, stop) events (hipExtLaunchKernelGGL: the dispatch packet's
     # begin / end timestamps), so these are kernel durations as rocprofv3 --kernel-trace reports them
     # (profiles/rNN_bench_kernel_stats.csv); the 2-3 us dispatch gap between dependent launches is in ms_per_step only.
-    work = eng.handle.algorithmic_work(a.batch, samples)
+    work = eng.handle.algorithmic_work(batch, samples)
 
-    # ---- what the matrix pipe sustains on this box: the GEMM's MFMA stream alone (no loads, LDS, barriers) ----
-    sustained = None
-    if rank == 0 and a.gemm == "bf16x3":
-        import ctypes
-        sink = torch.zeros(16, device=dev)
-        fl = ctypes.c_double()
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        st = torch.cuda.current_stream().cuda_stream
-        run = lambda: _lib.check(_lib.lib().vasr_bench_mfma_bf16_sustained(n_cu, 2000, sink.data_ptr(), ctypes.byref(fl), st))
-        run(); torch.cuda.synchronize()
+    def timed(fn, n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
         e0.record()
-        for _ in range(3):
-            run()
-        e1.record(); torch.cuda.synchronize()
-        sustained = 3 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    extra = {}
+    if decoder == "beam" and rank == 0:
+        lp = eng.forward(wav16, ln16, want_logp=True, want_pred=False)["logp"]
+        ms_beam = timed(lambda: beam_dec.decode_ids(lp, a.beam_width), max(3, a.steps // 4))
+        ms_ac = timed(lambda: eng.forward(wav16, ln16, want_logp=True, want_pred=False), max(3, a.steps // 4))
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        # the random-weight model's posteriors are near-deterministic (~1.1 classes per frame clear token_min_logp), which
+        # is the cheapest input a beam search can get; the same search on CTC-like posteriors of the same shape that spell
+        # words of the LM's vocabulary (beams branch, merge, LM re-ranks at word boundaries) is timed beside it
+        ms_ctc = None
+        if lm_path:
+            from viet_asr_amd.beam import read_arpa
+            words = sorted(w[0] for w in read_arpa(lm_path)[1] if len(w) == 1 and not w[0].startswith("<"))
+            lp_ctc = torch.from_numpy(synth.ctc_like_log_probs(batch, lp.shape[1], cfg["labels"], words, seed=seed)).to(dev)
+            ms_ctc = timed(lambda: beam_dec.decode_ids(lp_ctc, a.beam_width), max(3, a.steps // 4))
+        extra["beam"] = {"kernel": "beam_search_kernel (one 512-thread workgroup per utterance, merge table in LDS)",
+                         "bound": "LDS latency (dependent round trips per frame)", "beam_width": a.beam_width,
+                         "ms_per_batch_alone": round(ms_beam, 3), "acoustic_ms_per_batch_alone": round(ms_ac, 3),
+                         "ms_per_batch_on_ctc_like_posteriors": round(ms_ctc, 3) if ms_ctc else None,
+                         "serial_sum_ms": round(ms_beam + ms_ac, 3), "workgroups": batch, "cus": n_cu,
+                         "cus_busy_frac": round(min(1.0, batch / n_cu), 3), "overlapped": not a.no_overlap, "lm": lm_info}
+    if rate != 16000 and rank == 0:
+        ms_rs = timed(lambda: audio.resample(wav_in, ln_in, rate, 16000), max(3, a.steps // 4))
+        in_b, out_b = wav_in.numel() * 4, wav16.numel() * 4
+        extra["resample"] = {"kernel": "resample_poly_kernel (windowed-sinc, wings in LDS)", "ms_per_batch": round(ms_rs, 3),
+                             "bound": "hbm", "achieved": round((in_b + out_b) / (ms_rs * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round((in_b + out_b) / (ms_rs * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
     # ---- the other GEMM arithmetic on the same workload, for reference (rank 0 of a single-GPU run only) ----
     other = None
-    if world == 1 and not a.no_other_gemm:
-        other_mode = "fp32" if a.gemm == "bf16x3" else "bf16x3"
+    if world == 1 and not a.no_other_gemm and decoder == "greedy" and rate == 16000:
+        other_mode = "fp32" if gemm != "fp32" else "bf16x3"
         eng.handle.set_gemm_mode(other_mode)
         for _ in range(2):
-            eng.forward(wav, ln, want_logp=False, want_pred=False)
+            eng.forward(wav16, ln16, want_logp=False, want_pred=False)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(a.steps):
-            eng.forward(wav, ln, want_logp=False, want_pred=False)
+            eng.forward(wav16, ln16, want_logp=False, want_pred=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         eng.handle.profile_begin()
         for _ in range(a.steps):
-            eng.forward(wav, ln, want_logp=False, want_pred=False)
+            eng.forward(wav16, ln16, want_logp=False, want_pred=False)
         torch.cuda.synchronize()
         p2 = eng.handle.profile_end()
         tf = work["pointwise_flops"] / (p2["pointwise"]["ms"] / a.steps * 1e-3) / 1e12
         other = {"gemm": other_mode, "value": round(audio_sec_per_step * a.steps / dt, 1),
                  "ms_per_step": round(dt / a.steps * 1e3, 3), "pointwise_ms_per_step": round(p2["pointwise"]["ms"] / a.steps, 3),
                  "pointwise_fp32_equivalent_tflops": round(tf, 2)}
-        eng.handle.set_gemm_mode(a.gemm)
+        eng.handle.set_gemm_mode(gemm)
 
     if rank == 0:
+        if r.get("done") is not None:
+            r["done"].synchronize()
         hyp = eng.texts(r["ids"], r["id_len"])
         pw_ms = prof["pointwise"]["ms"] / a.steps
         dw_ms = prof["depthwise"]["ms"] / a.steps
         pw_tflops = work["pointwise_flops"] / (pw_ms * 1e-3) / 1e12       # fp32-equivalent (algorithmic) rate
-        split = a.gemm in ("bf16x3", "bf16x2")
-        terms = {"bf16x3": 6.0, "bf16x2": 3.0}.get(a.gemm, 1.0)
-        # the split kernel executes 6 bf16 MFMA products per fp32 multiply-add: that is the work the matrix pipe sees
+        terms, optype, dtype_str = GEMM_MODES[gemm]
+        # a split kernel executes `terms` 16-bit MFMA products per fp32 multiply-add: that is the work the matrix pipe sees
         exec_tflops = pw_tflops * terms
-        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if gemm == "fp32" else PEAK_16BIT_MFMA_TFLOPS
         dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
-        default_workload = a.model == "quartznet15x5" and a.batch == 64 and a.seconds == 10.0 and not a.ragged
-        pw_traffic, traffic_src = pmc_traffic("pw_gemm_bf16x3" if split else "pw_gemm_kernel") if default_workload else (None, None)
-        dw_traffic, _ = pmc_traffic("dw_pair_kernel") if default_workload else (None, None)
+        headline = a.config == 3 and not (a.model or a.batch or a.seconds or a.ragged)
+        kname = {"f16x2": "pw_gemm_f16x2_kernel", "fp32": "pw_gemm_kernel"}.get(gemm, "pw_gemm_bf16x3_kernel")
+        pw_traffic, traffic_src = pmc_traffic(kname) if headline else (None, None)
+        dw_traffic, _ = pmc_traffic("dw_") if headline else (None, None)
+        what = {"greedy": "greedy CTC", "beam": f"beam search (width {a.beam_width}" + (", 3-gram LM" if lm_info else ", no LM") + ")"}[decoder]
         out = {
             "metric": "real_time_factor", "value": round(audio_all * a.steps / elapsed, 1),
             "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"bf16x3": "f32 via 3xbf16 split operands (6 bf16 MFMA products per multiply, fp32 accumulate)",
-                      "bf16x2": "REDUCED: 2xbf16 split operands (16-bit significands, 3 bf16 MFMA products, fp32 accumulate) -- "
-                                "opt-in mode, not the headline configuration", "fp32": "f32"}[a.gemm],
-            "data": "synthetic",
-            "config": {"workload": f"{a.model} greedy CTC, batch={a.batch}x{a.seconds:g}s 16kHz mono per GPU"
-                                   f"{' (ragged lengths)' if a.ragged else ''}, wav in HBM -> collapsed ids",
-                       "batch_per_gpu": a.batch, "clip_seconds": a.seconds, "parallelism": f"utterance-shard x{world}"},
-            "utts_per_sec": round(a.batch * world * a.steps / elapsed, 1),
-            "roofline": {"kernel": ("pw_gemm_bf16x3_kernel (1x1 conv as 3xbf16-split MFMA GEMM" if split else
-                                    "pw_gemm_kernel (1x1 conv fp32 MFMA GEMM") + " + BN/residual/ReLU epilogue)",
+            "vs_baseline": None, "dtype": dtype_str, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{a.config - 1}]: {model} {what}, batch={batch}x{seconds:g}s "
+                                   f"{rate // 1000}kHz mono per GPU{' (ragged lengths)' if a.ragged else ''}"
+                                   f"{' -> 16 kHz on the device' if rate != 16000 else ''}, wav in HBM -> "
+                                   f"{'collapsed ids' if decoder == 'greedy' else 'best-hypothesis ids'}",
+                       "batch_per_gpu": batch, "clip_seconds": seconds, "parallelism": f"utterance-shard x{world}"},
+            "utts_per_sec": round(batch * world * a.steps / elapsed, 1),
+            "roofline": {"kernel": f"{kname} (1x1 conv as {'split-operand ' if terms > 1 else ''}MFMA GEMM + BN/residual/ReLU epilogue)",
                          "bound": "mfma", "achieved": round(exec_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(exec_tflops / peak, 4),
-                         "fp32_equivalent_tflops": round(pw_tflops, 2), "traffic": pw_traffic,
-                         "sustained_peak": round(sustained, 1) if sustained else None,
-                         "frac_of_sustained_peak": round(exec_tflops / sustained, 4) if sustained else None,
-                         "sustained_peak_note": "the same MFMA stream with no loads / LDS / barriers, measured in this run: "
-                                                "what the chip holds under its power limit (nominal peak assumes 2.4 GHz)",
-                         "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
+                         "mfma_products_per_multiply": terms, "fp32_equivalent_tflops": round(pw_tflops, 2),
+                         "traffic": None, "traffic_offline": pw_traffic,
+                         "traffic_note": "HBM bytes per launch from the committed PMC pass named in traffic_source (not measured in "
+                                         "this run; null off the headline workload)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps},
-            "depthwise": {"kernel": "dw_pair_kernel<K, DIL> (utterance-pair packed-FMA depthwise)", "bound": "hbm", "achieved": round(dw_gbs, 1),
-                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": dw_traffic,
-                          "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
+            "depthwise": {"kernel": "depthwise conv kernels (dw_*)", "bound": "hbm", "achieved": round(dw_gbs, 1),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                          "traffic_offline": dw_traffic, "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
                           "launches_per_step": prof["depthwise"]["launches"] // a.steps},
             "other_ms_per_step": {"frontend": round(prof["frontend"]["ms"] / a.steps, 3),
                                   "head": round(prof["head"]["ms"] / a.steps, 3)},
             "sample_transcript": hyp[0][:32],
         }
+        out.update(extra)
+        if rccl is not None:
+            out.update(rccl)
         if other is not None:
             out["other_gemm_arithmetic"] = other
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.model, seed, a.seconds)
+            out["cpu_baseline"] = cpu_baseline(model, seed, decoder, lm_path)
         if dist is not None:
             import ctypes
             ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in C stdio's buffer: keep the JSON line last

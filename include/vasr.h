@@ -151,9 +151,19 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
  *                7.4 ms per batch), log-prob error against the reference goldens 5-10x mode 1's (still inside the
  *                2e-3 tolerance there, identical predictions), more accurate than the TF32 convolutions PyTorch
  *                runs by default on the GPUs the reference targets.  Never the default, never the headline number.
+ *   3            every fp32 operand scaled by a power of two (exact) and split into TWO fp16 terms (22 significant
+ *                bits; the scale comes from the maximum |x| of the utterance, which the kernel that produced the tensor
+ *                publishes, so a row's result does not depend on the rest of its batch), the three largest cross
+ *                products on v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the matrix work of mode 1.  Its
+ *                per-product error is larger than mode 1's (<= 3 * 2^-22) but it rounds the accumulator half as often;
+ *                measured against fp64 it is not less accurate than modes 0 and 1 (tests/test_gpu_parity.py::
+ *                test_split_gemms_are_as_accurate_as_fp32_mfma) and all reference fixtures hold with the same
+ *                tolerances.  A GEMM whose input has no published maxima (port tensors of the per-module entry points,
+ *                the CTC head) runs as mode 1.
  * Layers whose shape the split kernel does not cover keep mode 0.
- * The environment variable VASR_GEMM=fp32 / bf16x3 / bf16x2 sets the initial mode of new handles. */
+ * The environment variable VASR_GEMM=fp32 / bf16x3 / bf16x2 / f16x2 sets the initial mode of new handles. */
 int vasr_set_gemm_mode(vasr_handle* h, int mode);
+int vasr_get_gemm_mode(const vasr_handle* h);
 
 /* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */
 /* int16 PCM -> float32 scaled by 2^-15 (AudioSegment._convert_samples_to_float32). n = total samples. */
@@ -252,6 +262,14 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
  * `steps` x 48 per wavefront; *flops = bf16 flops issued.  Timed by the caller; what it sustains is the rate the chip
  * holds under its power limit, against which bench.py also quotes the GEMM (roofline.sustained_peak). */
 int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
+
+/* 2 x fp16 scaled split variants (fragments: [m_pad/32][cin/16][2][64 lanes][8] fp16 bits; *inv_scale = 1 / the power
+ * of two the weights were scaled by).  d_amax: [2][batch][8] u32 scratch -- row 0 = max |x| per utterance (computed by
+ * the call itself when compute_amax != 0, else taken as given), row 1 receives max |y| per utterance. */
+int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out, float* inv_scale);
+int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
+                               const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
+                               uint32_t* d_amax, int compute_amax, vasr_stream stream);
 
 /* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
 int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);

@@ -229,3 +229,45 @@ def test_device_beam_search_randomised_cases(gpu):
     import fuzz_beam
     bad = [m for m in (fuzz_beam.run_case(c) for c in range(60)) if m]
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_beam_module_through_the_executor_with_a_batch(gpu):
+    """The reference's wiring (infer.py:146-160) through NeuralModuleFactory.infer with B = 3 ragged utterances: the
+    beam module's single output port carries ONE value per batch -- a list of B transcripts (round 1 zipped that list
+    against the port and kept row 0 only) -- and every row is searched over its own encoded length, not over the
+    padding frames of the batch (log_probs_length, which the reference ignores because it only ever runs B = 1)."""
+    from viet_asr_amd import asr as nemo_asr
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.beam import BeamSearchDecoder
+    from viet_asr_amd.core import DeviceType, NeuralModuleFactory
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 12), synth.decoder_state_dict(1024, 91, 12)
+    nf = NeuralModuleFactory(placement=DeviceType.GPU)
+    dl = nemo_asr.AudioDataLayer(sample_rate=16000)
+    pre = nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(cfg["AudioToMelSpectrogramPreprocessor"], dither=0, pad_to=0))
+    enc = nemo_asr.JasperEncoder(feat_in=64, **cfg["JasperEncoder"])
+    dec = nemo_asr.JasperDecoderForCTC(feat_in=1024, num_classes=len(cfg["labels"]))
+    beam = nemo_asr.BeamSearchDecoderWithLM(vocab=cfg["labels"], beam_width=16, alpha=0.5, beta=1.5, lm_path=None, num_cpus=1)
+    enc.load_state_dict({k: torch.as_tensor(v) for k, v in enc_sd.items()})
+    dec.load_state_dict({k: torch.as_tensor(v) for k, v in dec_sd.items()})
+    a, al = dl()
+    mel, ml = pre(input_signal=a, length=al)
+    e, el = enc(audio_signal=mel, length=ml)
+    lp = dec(encoder_output=e)
+    hyp = beam(log_probs=lp, log_probs_length=el)
+    sig, lens = synth.audio_batch(3, 32000, 12, ragged=True)
+    lens[:] = [32000, 9000, 20000]
+    dl.set_batch([sig[b, : lens[b]] for b in range(3)])
+    lp_v, el_v, hyp_v = [o[0] for o in nf.infer(tensors=[lp, el, hyp], verbose=False)]
+    assert isinstance(hyp_v, list) and len(hyp_v) == 3 and all(isinstance(t, str) for t in hyp_v)
+    direct = BeamSearchDecoder(cfg["labels"])
+    assert hyp_v == direct.decode_batch(lp_v.to(gpu), 16, frames=[int(v) for v in el_v.tolist()])
+    for b in range(3):                         # row b over its own frames == a batch-1 search of exactly those frames
+        assert hyp_v[b] == direct.decode_batch(lp_v[b:b + 1, : int(el_v[b])].to(gpu), 16)[0]
+    whole = direct.decode_batch(lp_v.to(gpu), 16)                    # all padded frames: what round 1 searched
+    assert whole[0] == hyp_v[0]                                      # the longest row has no padding
+    dl.set_signal(sig[1, : lens[1]])
+    single = nf.infer(tensors=[hyp], verbose=False)[0][0]
+    assert isinstance(single, str)                                   # what infer.py consumes: evaluated_tensors[0][0]

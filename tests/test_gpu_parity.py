@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 # Tolerances (fp32 path, stated per north_star): the HIP kernels accumulate in a different order
 # than MKL-DNN / pocketfft, so values agree to fp32 round-off amplified through <= 86 layers;
 # predictions and transcripts must be IDENTICAL (the smallest top-2 margin of a fixture is 9e-4; measured log-prob
-# errors are <= 1.7e-4 on those fixtures).
+# errors are <= 1.7e-4 on those fixtures: the bound is 3x that, it was 12x in round 1).
 MEL_TOL = 2e-4
-LOGP_TOL = 2e-3
+LOGP_TOL = 5e-4
 # ... for log-probs up to ~100 in magnitude.  The synthetic 15x5 model is far peakier on long clips (|log-prob| up to
 # 480 on the 10 s fixture, where one fp32 ulp is 3e-5): the bound follows the magnitude, 2e-5 relative.
 LOGP_REL = 2e-5
@@ -22,15 +22,26 @@ def logp_tol(ref):
     return max(LOGP_TOL, LOGP_REL * float(np.abs(np.asarray(ref)).max()))
 
 
+def _record(test, **kw):
+    """Measured errors go to gpurun_out/parity_errors.jsonl (when that scratch directory exists): the tolerances above
+    are set from these numbers, not guessed."""
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in kw.items()})) + "\n")
+
+
 def _engine(cfg, enc_sd, dec_sd, gemm=None):
     from viet_asr_amd.engine import QuartzNetCTC
     return QuartzNetCTC(cfg, enc_sd, dec_sd, gemm=gemm)
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_fused_path_matches_reference_goldens(gpu, name, gemm):
-    """Both GEMM arithmetics (3 x bf16 split operands = default, exact-fp32 MFMA) against the reference goldens."""
+    """The three fp32-equivalent GEMM arithmetics (2 x fp16 scaled split operands, 3 x bf16 split operands, exact-fp32
+    MFMA) against the reference goldens, same tolerance for all."""
     g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
     eng = _engine(cfg, enc_sd, dec_sd, gemm)
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
@@ -39,6 +50,7 @@ def test_fused_path_matches_reference_goldens(gpu, name, gemm):
     assert logp.shape == g["logp"].shape
     assert np.isfinite(logp).all()
     err = np.abs(logp - g["logp"]).max()
+    _record("goldens", name=name, gemm=gemm, err=err, scale=np.abs(g["logp"]).max(), min_margin=g["min_margin"])
     assert err <= logp_tol(g["logp"]), err
     assert (r["enc_len"].cpu().numpy() == g["enc_len"]).all()
     assert (r["pred"].cpu().numpy() == g["pred"]).all()
@@ -130,7 +142,7 @@ def test_edge_cases(gpu):
     # a row with seq_len == 1 has NaN statistics in the reference (unbiased std of one frame): same here
     assert torch.isnan(ref["logp"][2]).all() == torch.isnan(lp[2]).all()
     ok = ~torch.isnan(ref["logp"])
-    assert (lp[ok] - ref["logp"][ok]).abs().max() <= LOGP_TOL
+    assert (lp[ok] - ref["logp"][ok]).abs().max() <= logp_tol(ref["logp"][ok])
     assert (r["pred"].cpu()[:2] == ref["pred"][:2]).all()
     with pytest.raises(ValueError):          # torch.stft refuses reflect padding of <= n_fft/2 samples
         eng.forward(torch.zeros(1, 256, device=gpu), torch.tensor([256], device=gpu))
@@ -211,15 +223,26 @@ def test_vietasr_class_end_to_end(gpu, tmp_path):
         VietASR("quartznet12x1_vi", str(tmp_path / "missing.pt"), dec_p)
 
 
-def test_split_bf16_gemm_is_as_accurate_as_fp32_mfma(gpu):
-    """Isolated 1x1-conv GEMM (512 -> 512 channels) against an fp64 reference: the 3 x bf16 split must not be less
-    accurate than the exact-fp32 MFMA chain, and the two must agree to fp32 round-off."""
+@pytest.mark.parametrize("cin,kind", [(256, "randn"), (512, "randn"), (1024, "randn"), (512, "relu"), (512, "wide")])
+def test_split_gemms_are_as_accurate_as_fp32_mfma(gpu, cin, kind):
+    """Isolated 1x1-conv GEMM (cin -> 512 channels) against an fp64 reference: neither split arithmetic (3 x bf16, six
+    products; 2 x fp16 scaled, three products) may be less accurate than the exact-fp32 MFMA chain, and all three must
+    agree to fp32 round-off.  Inputs: Gaussian; ReLU'd Gaussian (what the layers actually see); and "wide" -- rows whose
+    magnitudes span 2^-24 ... 2^6 inside one utterance, far more than the 18 octaves the fp16 split carries at full
+    precision, where its error must stay below fp32 round-off of the LARGEST terms (absolute, not relative)."""
     from viet_asr_amd import _lib
+    import ctypes as C
     L = _lib.lib()
-    B, T, cin, cout = 2, 300, 512, 512
+    B, T, cout = 2, 300, 512
     ld = int(L.vasr_padded_frames(T))
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, cin, ld, generator=g).to(gpu)
+    g = torch.Generator().manual_seed(cin + len(kind))
+    x = torch.randn(B, cin, ld, generator=g)
+    if kind == "relu":
+        x = torch.relu(x)
+    if kind == "wide":
+        x = x * torch.exp2(torch.randint(-24, 7, (B, cin, ld), generator=g).float())
+    x[1] *= 37.5                                        # utterances of one batch at different scales
+    x = x.to(gpu)
     w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).contiguous()
     sc, sh = torch.ones(cout, device=gpu), torch.zeros(cout, device=gpu)
     st = torch.cuda.current_stream().cuda_stream
@@ -227,15 +250,27 @@ def test_split_bf16_gemm_is_as_accurate_as_fp32_mfma(gpu):
     _lib.check(L.vasr_pack_pointwise(w.data_ptr(), cout, cin, cout, pk.data_ptr()))
     pk3 = torch.empty(cout * cin * 3, dtype=torch.int16)
     _lib.check(L.vasr_pack_pointwise_bf16x3(w.data_ptr(), cout, cin, cout, pk3.data_ptr()))
-    y32, y3 = torch.empty(B, cout, ld, device=gpu), torch.empty(B, cout, ld, device=gpu)
-    w32, w3 = pk.to(gpu), pk3.to(gpu)
+    pk16 = torch.empty(cout * cin * 2, dtype=torch.int16)
+    inv = C.c_float()
+    _lib.check(L.vasr_pack_pointwise_f16x2(w.data_ptr(), cout, cin, cout, pk16.data_ptr(), C.byref(inv)))
+    y32, y3, y16 = (torch.empty(B, cout, ld, device=gpu) for _ in range(3))
+    amax = torch.zeros(2, B, 8, dtype=torch.int32, device=gpu)
+    w32, w3, w16 = pk.to(gpu), pk3.to(gpu), pk16.to(gpu)
     _lib.check(L.vasr_bench_pointwise(x.data_ptr(), w32.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y32.data_ptr(), st))
     _lib.check(L.vasr_bench_pointwise_bf16x3(x.data_ptr(), w3.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y3.data_ptr(), st))
+    _lib.check(L.vasr_bench_pointwise_f16x2(x.data_ptr(), w16.data_ptr(), inv.value, sc.data_ptr(), sh.data_ptr(), B, cin, cout, T,
+                                            y16.data_ptr(), amax.data_ptr(), 1, st))
     ref = torch.relu(torch.einsum("mk,bkt->bmt", w.double().to(gpu), x[:, :, :T].double()))
-    e32 = float((y32[:, :, :T].double() - ref).abs().max())
-    e3 = float((y3[:, :, :T].double() - ref).abs().max())
-    assert e32 < 1e-5 and e3 < 1e-5 and e3 <= 1.5 * e32 + 1e-7, (e32, e3)
-    assert float((y3[:, :, :T] - y32[:, :, :T]).abs().max()) < 1e-5
+    err = lambda y: [float((y[b, :, :T].double() - ref[b]).abs().max()) for b in range(B)]
+    e32, e3, e16 = err(y32), err(y3), err(y16)
+    for b in range(B):          # per utterance: each has its own scale
+        assert e3[b] <= 1.5 * e32[b] + 1e-7 * float(ref[b].max()), (cin, kind, b, e32, e3)
+        assert e16[b] <= 1.5 * e32[b] + 1e-7 * float(ref[b].max()), (cin, kind, b, e32, e16)
+        assert e32[b] <= 2e-6 * max(1.0, float(ref[b].max())), (e32, float(ref[b].max()))
+    # the maxima the kernels publish: row 0 = max |x| over the valid frames, row 1 = max |y| (what the next layer's split uses)
+    got = amax.view(torch.float32).amax(-1).cpu()
+    assert torch.equal(got[0], x[:, :, :T].abs().amax((1, 2)).cpu())
+    assert torch.equal(got[1], y16[:, :, :T].abs().amax((1, 2)).cpu())
 
 
 def test_long_clips_config5_shape(gpu):
@@ -251,11 +286,13 @@ def test_long_clips_config5_shape(gpu):
     assert r["logp"].shape == (2, 1501, 29)
     # logits span +-170 on this model (very peaky posteriors), so fp32 round-off is judged against that scale:
     # absolute tolerance + 5e-5 of the largest |log-prob| (measured: 4.7e-3 at scale 167 = 2.8e-5 relative)
+    _record("long_clips", err=(r["logp"].cpu() - ref["logp"]).abs().max(), scale=ref["logp"].abs().max())
     assert (r["logp"].cpu() - ref["logp"]).abs().max() <= LOGP_TOL + 5e-5 * float(ref["logp"].abs().max())
     top2 = torch.topk(ref["logp"], 2, dim=-1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 1e-3               # frames whose margin is far above fp32 round-off
+    # a flip needs the two leading classes inside twice the measured error (4.7e-3 at this scale): none elsewhere
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-2
     assert (r["pred"].cpu()[safe] == ref["pred"][safe]).all()
-    assert (r["pred"].cpu() != ref["pred"]).sum() <= 2
+    assert float(safe.float().mean()) > 0.995
 
 
 _ALT_PATH_SNIPPET = r"""
@@ -271,14 +308,17 @@ for name in ("vi12x1_b3_ragged", "en15x5_b2_ragged"):
     torch.cuda.synchronize()
     err = float(np.abs(r["logp"].cpu().numpy() - g["logp"]).max())
     same = bool((r["pred"].cpu().numpy() == g["pred"]).all()) and eng.texts(r["ids"], r["id_len"]) == [str(s) for s in g["hyp"]]
-    if err > 2e-3 or not same:
+    if err > 5e-4 or not same:
         bad.append((name, err, same))
 print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
 """
 
 
 @pytest.mark.parametrize("env", [{"VASR_DW_PAIR": "0"}, {"VASR_NO_FUSED_RESIDUAL": "1"}, {"VASR_PW3_TILE": "3"},
-                                 {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"}],
+                                 {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"},
+                                 {"VASR_GEMM": "f16x2", "VASR_DW_PAIR": "0"}, {"VASR_GEMM": "f16x2", "VASR_NO_FUSED_RESIDUAL": "1"},
+                                 {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "6"}, {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "3"},
+                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "6"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):
     """The kernels a default run does not pick (one-row depthwise, two-GEMM residual, latency GEMM tiles, batch slices
@@ -292,17 +332,20 @@ def test_alternate_kernel_paths_match_goldens(gpu, env):
     assert "ALT_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
-def test_results_do_not_depend_on_batch_size_or_tile_shape(gpu):
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3"])
+def test_results_do_not_depend_on_batch_size_or_tile_shape(gpu, gemm):
     """An utterance gives bit-identical log-probs alone (64x32 GEMM tiles, self-paired depthwise) and inside an odd
     batch of 67 equal-length clips (256x128 / 512x128 tiles, utterance pairs): every reduction runs in the same order
     whatever the launch shape.  This is what lets the serving queue merge requests without changing answers."""
     from viet_asr_amd import configs, synth
     cfg = configs.builtin("quartznet15x5")
     jas = cfg["JasperEncoder"]["jasper"]
-    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 9), synth.decoder_state_dict(1024, 29, 9))
+    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 9), synth.decoder_state_dict(1024, 29, 9), gemm)
     sig, lens = synth.audio_batch(67, 24000, 9)
+    sig[5] *= 1e-3                                     # rows at very different levels: the fp16 split scales per utterance
+    sig[66] *= 40.0
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
-    for b in (0, 33, 66):
+    for b in (0, 5, 33, 66):
         r1 = eng.forward(torch.from_numpy(sig[b:b + 1]).to(gpu), torch.from_numpy(lens[b:b + 1]).to(gpu), want_logp=True)
         assert torch.equal(r["logp"][b], r1["logp"][0])
         assert torch.equal(r["pred"][b], r1["pred"][0])
@@ -339,8 +382,9 @@ def _random_architecture(rng):
     return blocks
 
 
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("seed", range(8))
-def test_random_architectures_and_shapes_match_oracle(gpu, seed):
+def test_random_architectures_and_shapes_match_oracle(gpu, seed, gemm):
     import copy
     from viet_asr_amd import configs, synth
     rng = np.random.default_rng(1000 + seed)
@@ -348,7 +392,7 @@ def test_random_architectures_and_shapes_match_oracle(gpu, seed):
     jas = cfg["JasperEncoder"]["jasper"] = _random_architecture(rng)
     enc_sd = synth.encoder_state_dict(jas, 64, seed)
     dec_sd = synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, seed)
-    eng = _engine(cfg, enc_sd, dec_sd)
+    eng = _engine(cfg, enc_sd, dec_sd, gemm)
     B, L = int(rng.integers(1, 6)), int(rng.integers(1500, 30000))
     sig, lens = synth.audio_batch(B, L, seed, ragged=True)
     lens[int(rng.integers(0, B))] = L                        # the collate pads to the longest row
@@ -359,10 +403,11 @@ def test_random_architectures_and_shapes_match_oracle(gpu, seed):
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
     lp, want = r["logp"].cpu(), ref["logp"]
     assert lp.shape == want.shape, (jas, B, L)
-    assert (lp - want).abs().max() <= LOGP_TOL, (float((lp - want).abs().max()), jas, B, L)
+    _record("random_arch", seed=seed, gemm=gemm, err=(lp - want).abs().max(), scale=want.abs().max())
+    assert (lp - want).abs().max() <= logp_tol(want), (float((lp - want).abs().max()), jas, B, L)
     assert r["enc_len"].cpu().tolist() == ref["enc_len"].tolist()
     top2 = want.topk(2, -1).values
-    clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL    # random weights: near-ties may flip inside the tolerance
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * logp_tol(want)   # a flip needs both leading classes inside the tolerance
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
 
 
@@ -398,12 +443,13 @@ def test_strongly_ragged_batch_skipped_tiles_match_oracle(gpu):
         sig[b, lens[b]:] = 0
     ref = _oracle(cfg, sig, lens, enc_sd, dec_sd)
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
-    assert (r["logp"].cpu() - ref["logp"]).abs().max() <= LOGP_TOL
+    _record("strongly_ragged", err=(r["logp"].cpu() - ref["logp"]).abs().max(), scale=ref["logp"].abs().max())
+    assert (r["logp"].cpu() - ref["logp"]).abs().max() <= logp_tol(ref["logp"])
     assert r["enc_len"].cpu().tolist() == ref["enc_len"].tolist()
     top2 = ref["logp"].topk(2, -1).values
-    clear = (top2[..., 0] - top2[..., 1]) > 10 * LOGP_TOL
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * logp_tol(ref["logp"])
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
-    assert clear.float().mean() > 0.9
+    assert clear.float().mean() > 0.95
 
 
 @pytest.mark.parametrize("model,B,L", [("quartznet12x1_vi", 3, 20321), ("quartznet15x5", 2, 48000), ("quartznet12x1_vi", 1, 257)])

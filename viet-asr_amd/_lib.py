@@ -57,6 +57,10 @@ SIGNATURES = {
     "vasr_pcm16_to_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
     "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
     "vasr_set_gemm_mode": (C.c_int, [_P, C.c_int]),
+    "vasr_get_gemm_mode": (C.c_int, [_P]),
+    "vasr_pack_pointwise_f16x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
+    "vasr_bench_pointwise_f16x2": (C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P,
+                                             C.c_int, _P]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_set_row_independent": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
@@ -182,9 +186,16 @@ class Handle:
         return dict(pointwise_flops=out[0], depthwise_flops=out[1], depthwise_bytes=out[2],
                     decoder_flops=out[3], frontend_flops=out[4])
 
+    GEMM_MODES = {"fp32": 0, "bf16x3": 1, "bf16x2": 2, "f16x2": 3}
+
     def set_gemm_mode(self, mode):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (3 x bf16 split operands, fp32-equivalent accuracy)."""
-        check(lib().vasr_set_gemm_mode(self.h, {"fp32": 0, "bf16x3": 1, "bf16x2": 2}[mode] if isinstance(mode, str) else int(mode)))
+        """'fp32' (exact fp32 MFMA), 'bf16x3' (3 x bf16 split operands), 'f16x2' (2 x fp16 scaled split operands) --
+        all fp32-equivalent accuracy -- or the reduced-precision opt-in 'bf16x2'; see vasr_set_gemm_mode."""
+        check(lib().vasr_set_gemm_mode(self.h, self.GEMM_MODES[mode] if isinstance(mode, str) else int(mode)))
+
+    def gemm_mode_name(self):
+        m = int(lib().vasr_get_gemm_mode(self.h))
+        return {v: k for k, v in self.GEMM_MODES.items()}[m]
 
     def set_slices(self, n):
         check(lib().vasr_set_slices(self.h, int(n)))

@@ -43,6 +43,21 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)v, o, 64);
+    v = other > v ? other : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// One unreturned atomic per wavefront publishes the wavefront's max |y| of utterance b (vasr_internal.h, kAmaxSlots).
+__device__ __forceinline__ void publish_amax(unsigned* amax, int b, int slot, unsigned lane_max, int lane) {
+  const unsigned m = wave_max_u32(lane_max);
+  if (lane == 0 && m) atomicMax(amax + b * kAmaxSlots + (slot & (kAmaxSlots - 1)), m);
+}
+
 // One sub-group of 4 consecutive outputs, taps [K0, K1), on packed-fp32 FMAs.
 // v_pk_fma_f32 wants its two lanes in one even-aligned register pair, but output pair (r, r+1) at
 // tap k needs x[r+k], x[r+k+1], which is an aligned pair only when r+k is even.  So taps whose
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels,
-                                                      float* __restrict__ y, int64_t ldy) {
+                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax) {
   using G = DwGeom<K, DIL>;
   constexpr int NQE = (G::OFF + DIL * (K - 1) + 4 + 1 + 3) / 4;  // +1: the odd-tap pairing reads one sample further
   constexpr int NLD = ((256 + 252 + 4 * NQE) / 4 + 63) / 64;  // staging float4s per lane (3)
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     return v;
   };
 
+  unsigned row_max = 0;
   gload(c0);
 #pragma unroll 1
   for (int r = 0; r < ROWS; ++r) {
@@ -162,10 +178,12 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
         if (t + 2 >= len_out) o.z = 0.f;
         if (t + 3 >= len_out) o.w = 0.f;
         *reinterpret_cast<v4f*>(yr + t) = o;
+        if (amax) row_max = max(row_max, max(max(abs_bits(o.x), abs_bits(o.y)), max(abs_bits(o.z), abs_bits(o.w))));
       }
     }
     wave_sync();
   }
+  if (amax) publish_amax(amax, b, c0, row_max, lane);
 }
 
 // ---- utterance-pair variant ---------------------------------------------------------------------------------------
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels, int batch,
-                                                      float* __restrict__ y, int64_t ldy) {
+                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax) {
   using G = PairGeom<K, DIL>;
   constexpr int NLD = G::NLD;
   __shared__ v4f lds4[4 * G::PHYS];
@@ -336,6 +354,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
   const int n0 = lens_out[b0] - t, n1 = lens_out[b1] - t;
   float* y0 = y + ((int64_t)b0 * channels + c) * ldy + t;
   float* y1 = y + ((int64_t)b1 * channels + c) * ldy + t;
+  unsigned m0 = 0, m1 = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (t + 4 * h < ldy) {
@@ -347,16 +366,27 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
       }
       *reinterpret_cast<v4f*>(y0 + 4 * h) = o0;
       if (twin) *reinterpret_cast<v4f*>(y1 + 4 * h) = o1;
+      if (amax) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m0 = max(m0, abs_bits(o0[e]));
+          m1 = max(m1, abs_bits(o1[e]));
+        }
+      }
     }
+  }
+  if (amax) {   // masked outputs only (zeros past lens_out): the maximum over the utterance's valid frames
+    publish_amax(amax, b0, c, m0, lane);
+    if (twin) publish_amax(amax, b1, c, m1, lane);
   }
 }
 
 template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
-                    int channels, float* y, int64_t ldy, hipStream_t st) {
+                    int channels, float* y, int64_t ldy, hipStream_t st, unsigned* amax) {
   dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
   static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy);
+  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy, amax);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
@@ -366,7 +396,8 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
                                                               const int32_t* __restrict__ lens_in,
                                                               const int32_t* __restrict__ lens_out,
                                                               int channels, int K, int stride, int dil, int pad,
-                                                              float* __restrict__ y, int64_t ldy) {
+                                                              float* __restrict__ y, int64_t ldy,
+                                                              unsigned* __restrict__ amax) {
   constexpr int kSpan = 2048;
   __shared__ float xs[kSpan];
   const int c = blockIdx.y, b = blockIdx.z;
@@ -388,9 +419,8 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
     }
     __syncthreads();
   }
-  if (t >= ldy) return;
   float acc = 0.f;
-  if (t < lens_out[b]) {
+  if (t < ldy && t < lens_out[b]) {
     if (staged) {
       const float* xt = xs + threadIdx.x * stride;
       for (int k = 0; k < K; ++k) acc = fmaf(wc[k], xt[k * dil], acc);
@@ -402,7 +432,8 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
       }
     }
   }
-  y[row * ldy + t] = acc;
+  if (t < ldy) y[row * ldy + t] = acc;
+  if (amax) publish_amax(amax, b, c, abs_bits(acc), threadIdx.x & 63);   // whole wavefronts reach this point
 }
 
 // MaskedConv1d.get_seq_len chain (jasper.py:108-111): lens.to(long) for the mask, then
@@ -448,21 +479,21 @@ __global__ __launch_bounds__(256) void repad_kernel(const float* __restrict__ sr
 
 template <int K>
 void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
-                 int channels, float* y, int64_t ldy, hipStream_t st) {
+                 int channels, float* y, int64_t ldy, hipStream_t st, unsigned* amax) {
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
   static const int rows_env = getenv("VASR_DW_ROWS") ? atoi(getenv("VASR_DW_ROWS")) : 1;
   if (channels % 32 == 0 && rows_env == 8) {
     dim3 grid(channels / 32, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
   } else if (channels % 8 == 0 && rows_env == 2) {
     dim3 grid(channels / 8, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
   } else if (channels % 16 == 0 && rows_env != 1) {
     dim3 grid(channels / 16, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
   } else {
     dim3 grid(channels / 4, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy);
+    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
   }
 }
 
@@ -470,20 +501,20 @@ void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li,
 
 void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
                       const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
-                      int pad, float* y, int64_t ldy, hipStream_t st) {
+                      int pad, float* y, int64_t ldy, hipStream_t st, unsigned int* amax) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
   static const bool pair = !(getenv("VASR_DW_PAIR") && atoi(getenv("VASR_DW_PAIR")) == 0);
   if (pair && aligned && stride == 1) {
     if (dilation == 2 && kernel == 87 && pad == 86)
-      return launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+      return launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
     if (dilation == 1 && pad == kernel / 2) {
       switch (kernel) {
-        case 33: return launch_dw_pair<33, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-        case 39: return launch_dw_pair<39, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-        case 51: return launch_dw_pair<51, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-        case 63: return launch_dw_pair<63, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-        case 75: return launch_dw_pair<75, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+        case 33: return launch_dw_pair<33, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+        case 39: return launch_dw_pair<39, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+        case 51: return launch_dw_pair<51, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+        case 63: return launch_dw_pair<63, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+        case 75: return launch_dw_pair<75, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
         default: break;
       }
     }
@@ -491,23 +522,43 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
   if (aligned && stride == 1 && dilation == 2 && kernel == 87 && pad == 86) {
     dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
     VASR_LAUNCH((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
-                       y, ldy);
+                       y, ldy, amax);
     return;
   }
   const bool fast = aligned && stride == 1 && dilation == 1 && pad == kernel / 2;
   if (fast) {
     switch (kernel) {
-      case 33: return launch_dw_t<33>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-      case 39: return launch_dw_t<39>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-      case 51: return launch_dw_t<51>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-      case 63: return launch_dw_t<63>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
-      case 75: return launch_dw_t<75>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st);
+      case 33: return launch_dw_t<33>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      case 39: return launch_dw_t<39>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      case 51: return launch_dw_t<51>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      case 63: return launch_dw_t<63>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      case 75: return launch_dw_t<75>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
       default: break;
     }
   }
   dim3 grid((unsigned)((ldy + 255) / 256), channels, batch);
   VASR_LAUNCH(dw_conv_generic_kernel, grid, dim3(256), 0, st, x, ldx, frames_in, w, lens_in, lens_out,
-                     channels, kernel, stride, dilation, pad, y, ldy);
+                     channels, kernel, stride, dilation, pad, y, ldy, amax);
+}
+
+// max |x| per utterance over columns < lens[b] (or < frames) of x[b][rows][ld]: for tensors whose producer does not
+// publish its maxima (port tensors, the fp32 GEMM kernel)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t ld, int rows, int frames,
+                                                   const int32_t* __restrict__ lens, unsigned* __restrict__ amax) {
+  const int b = blockIdx.y;
+  int n = lens ? lens[b] : frames;
+  n = n < frames ? n : frames;
+  unsigned m = 0;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* xr = x + ((int64_t)b * rows + r) * ld;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) m = max(m, abs_bits(xr[t]));
+  }
+  publish_amax(amax, b, blockIdx.x + (threadIdx.x >> 6), m, threadIdx.x & 63);
+}
+
+void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, unsigned int* amax,
+                 hipStream_t st) {
+  hipLaunchKernelGGL(amax_kernel, dim3(rows < 64 ? rows : 64, batch), dim3(256), 0, st, x, ld, rows, frames, lens, amax);
 }
 
 void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,

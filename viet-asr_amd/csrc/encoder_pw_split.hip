@@ -1,21 +1,32 @@
-// Pointwise (1x1) convolution GEMM on the bf16 matrix pipe with fp32-equivalent accuracy ("3 x bf16" operands).
+// Pointwise (1x1) convolution GEMM on the 16-bit matrix pipe with fp32-equivalent accuracy ("split operand" GEMMs).
 //
 // Same operation, epilogue and dual-source K reduction as encoder_pw.hip (reference
-// nemo/collections/asr/parts/jasper.py:113-132, :374-392, :428-448), but every fp32 operand is split exactly into
-// three bf16 terms  x = x_hi + x_mid + x_lo  (round-to-nearest each: 8 + 8 + 8 significant bits = the 24 of fp32)
-// and the product is evaluated with the six largest cross terms
-//     a*b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi
-// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms are < 2^-25 |a b| (measured: max relative
-// product error 2.7e-8, below the 4e-8 of one fp32 rounding), so the result is as accurate as the fp32-MFMA path
-// -- 6 bf16 MFMAs (6 x 32 cycles per 32x32x16 block) replace 8 fp32 ones (8 x 64 cycles): 2.67x less matrix time.
+// nemo/collections/asr/parts/jasper.py:113-132, :374-392, :428-448).  Three arithmetics share the kernel (template ARITH):
 //
-//   * weights are split and packed at vasr_finalize() in A-fragment order [M/32][K/16][3 planes][64 lanes][8 bf16]:
+//   kBf16x3  every fp32 operand split exactly into three bf16 terms  x = x_hi + x_mid + x_lo  (round-to-nearest each:
+//            8 + 8 + 8 significant bits = the 24 of fp32), product from the six largest cross terms
+//                a*b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi
+//            on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped terms < 2^-25 |a b|.
+//   kF16x2   every operand scaled by a power of two (exact) and split into TWO fp16 terms  s x = x_hi + x_lo  (11 + 11
+//            significant bits; the scale puts the utterance's largest |x| -- and the layer's largest |w| -- in
+//            [2^14, 2^15), so that x_lo keeps all its bits down to |x| = 2^-17 max|x| and an absolute error of
+//            2^-40 max|x| below that), product from the three largest cross terms  a_hi b_hi + a_hi b_lo + a_lo b_hi  on
+//            v_mfma_f32_32x32x16_f16: HALF the matrix work of kBf16x3.  Per-product error <= 3 * 2^-22, but only three
+//            fp32 accumulator roundings per 16-deep k-step instead of six: measured against fp64 the result is not
+//            less accurate than kBf16x3's or the fp32-MFMA chain's (tests/test_gpu_parity.py::
+//            test_split_gemms_are_as_accurate_as_fp32_mfma).  The accumulators carry s_x s_w times the result; the
+//            epilogue multiplies by the (power-of-two, exact) inverse before the BN affine.  The per-utterance maxima
+//            come from the kernel that produced the tensor (depthwise kernels and this kernel's own epilogue publish
+//            max |y| per utterance with one atomic per wavefront: PwArgs::amax_*), so the scale of a row depends on
+//            that row alone and results stay independent of the batch an utterance sits in.
+//   kBf16x2  opt-in REDUCED precision: the two upper bf16 terms and three cross terms (16-bit significands).
+//
+//   * weights are split and packed at vasr_finalize() in A-fragment order [M/32][K/16][planes][64 lanes][8 x 16 bit]:
 //     one 16-byte load per lane, plane and 16-deep k-step, straight from L2, one step ahead of use;
-//   * activations are split ONCE per workgroup while they are staged into LDS (v_cvt_pk_bf16_f32), laid out
-//     [plane][k-step][k-half][column][8 bf16] so that every B fragment is one conflict-free ds_read_b128;
+//   * activations are split ONCE per workgroup while they are staged into LDS, laid out
+//     [plane][k-step][k-half][column][8 x 16 bit] so that every B fragment is one conflict-free ds_read_b128;
 //   * throughput tile 512 x 128 (8 wavefronts, two 32-row m-tiles each, every wave owning all 128 columns, 128
-//     accumulator registers, one workgroup per CU): a weight fragment is reused for 24 MFMAs, which keeps the weight
-//     stream from L2 at 8 TB/s instead of 17 TB/s at full MFMA rate;
+//     accumulator registers, one workgroup per CU): a weight fragment is reused for 12-24 MFMAs;
 //   * latency tile 64 x 32 (2 wavefronts) for small batches, where the throughput tile would leave most of the
 //     256 CUs idle (B = 1: 4 workgroups per layer instead of 128).
 #include <cstdlib>
@@ -33,6 +44,10 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 using v2f = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+enum { kBf16x3 = 0, kBf16x2 = 1, kF16x2 = 2 };
 
 constexpr int BKC = 64;   // K rows per LDS buffer
 #ifndef VASR_ABLATE
@@ -62,8 +77,29 @@ __device__ __forceinline__ void split3(const float (&x)[8], uint4& hi, uint4& mi
   lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// 8 consecutive-k values of one column, scaled by the power of two s -> two 16-byte fp16 fragments:
+// hi = rne16(s x), lo = rne16(s x - hi)  (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_fma_f32,
+// v_cvt_pk_f16_f32: six VALU instructions per pair)
+__device__ __forceinline__ void split2h(const float (&x)[8], float s, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const v2f v = {x[2 * p] * s, x[2 * p + 1] * s};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const v2f r = v - __builtin_convertvector(hh, v2f);   // exact: the residual of a round-to-nearest conversion
+    h[p] = __builtin_bit_cast(unsigned, hh);
+    l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int ARITH>
 __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  if constexpr (ARITH == kF16x2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // orders a wavefront's own LDS writes and reads for the compiler (the LDS pipeline itself keeps them in issue order)
@@ -73,28 +109,48 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)v, o, 64);
+    v = other > v ? other : v;
+  }
+  return v;
+}
+
+// power-of-two scale (and its inverse) that puts a maximum of magnitude `amax_bits` (fp32 bit pattern of |x|) into
+// [2^14, 2^15): the fp16 planes then have 18 octaves of full 22-bit precision below the maximum
+__device__ __forceinline__ void f16_scale(unsigned amax_bits, float* scale, float* inv) {
+  int e = (int)(amax_bits >> 23);
+  e = e < 16 ? 16 : (e > 254 ? 254 : e);
+  *scale = __uint_as_float((unsigned)(268 - e) << 23);   // 2^(141 - e)
+  *inv = __uint_as_float((unsigned)(e - 14) << 23);      // 2^(e - 141)
+}
+
 // NW wavefronts stacked along M, each TM m-tiles (32 rows) x all TN n-tiles (32 columns each):
 // workgroup tile (32*TM*NW) x (32*TN).
-template <int NW, int TM, int TN>
+template <int NW, int TM, int TN, int ARITH>
 struct Geom {
   static constexpr int BM = 32 * TM * NW;
   static constexpr int BN = 32 * TN;
   static constexpr int NT = 64 * NW;                   // threads
+  static constexpr int PL = ARITH == kBf16x3 ? 3 : 2;  // operand planes multiplied (and staged into LDS)
+  static constexpr int PLW = ARITH == kF16x2 ? 2 : 3;  // planes in the weight pack (bf16x2 reads the bf16x3 pack)
   static constexpr int PATCHES = BKC / 8 * BN;         // staging patches (8 k-rows x 1 column) per chunk
-  static constexpr int PPT = PATCHES / NT;             // patches per thread (2 for every instantiated shape)
-  static constexpr size_t LDS = (size_t)2 * 3 * STEPS * 2 * BN * sizeof(uint4);
+  static constexpr int PPT = PATCHES / NT;             // patches per thread
+  static constexpr size_t LDS_MAIN = (size_t)2 * PL * STEPS * 2 * BN * sizeof(uint4);
+  static constexpr size_t LDS_EPI = (size_t)NW * 2 * 8 * BN * sizeof(float);   // epilogue transposition buffers
+  static constexpr size_t LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static_assert(PATCHES % NT == 0 && PPT >= 1, "staging patches must divide evenly over the threads");
 };
 
-// LITE: only the hi/mid planes and the three largest cross terms (hi*hi, hi*mid, mid*hi): 16-bit operands,
-// opt-in "bf16x2" mode (vasr_set_gemm_mode(h, 2)); the default keeps all three planes and six terms.
-template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, bool LITE>
-__global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
-  using G = Geom<NW, TM, TN>;
-  constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT;
-  extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][3][STEPS][2][BN]
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, int ARITH>
+__global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+  using G = Geom<NW, TM, TN, ARITH>;
+  constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT, PL = G::PL, PLW = G::PLW;
+  extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][PL][STEPS][2][BN]
   auto bs = [&](int buf, int plane, int s, int kb, int n) -> uint4& {
-    return Bs[(((buf * 3 + plane) * STEPS + s) * 2 + kb) * BN + n];
+    return Bs[(((buf * PL + plane) * STEPS + s) * 2 + kb) * BN + n];
   };
 
   int bid = blockIdx.x;
@@ -115,13 +171,34 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
   const int len = MASK ? a.lens[b] : 0;
   const int len2 = DUAL ? a.lens2[b] : 0;
 
+  // kF16x2: one power-of-two scale per utterance from the maxima the producers of x (and x2) published
+  float xs = 1.f, out_scale = 1.f;
+  if constexpr (ARITH == kF16x2) {
+    unsigned mx = 0;
+#pragma unroll
+    for (int i = 0; i < kAmaxSlots; ++i) {
+      const unsigned v = a.amax_x[b * kAmaxSlots + i];
+      mx = v > mx ? v : mx;
+    }
+    if (DUAL) {
+#pragma unroll
+      for (int i = 0; i < kAmaxSlots; ++i) {
+        const unsigned v = a.amax_x2[b * kAmaxSlots + i];
+        mx = v > mx ? v : mx;
+      }
+    }
+    float inv;
+    f16_scale(mx, &xs, &inv);
+    out_scale = inv * a.w_inv_scale;
+  }
+
   const int K1 = DUAL ? a.K1 : a.K;
   const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0;
   const float* __restrict__ xb2 = DUAL ? a.x2 + (int64_t)b * (a.K - K1) * a.ldx2 + t0 : nullptr;
-  // A fragments [M/32][K/16][3][64] uint4
+  // A fragments [M/32][K/16][PLW][64] uint4
   const int ksteps = a.K / 16;
-  const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * ksteps) * 3 * 64 + lane;
-  const int64_t a_tile = (int64_t)ksteps * 3 * 64;   // uint4 stride between m-tiles
+  const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * ksteps) * PLW * 64 + lane;
+  const int64_t a_tile = (int64_t)ksteps * PLW * 64;   // uint4 stride between m-tiles
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -159,22 +236,29 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
         for (int e = 0; e < 8; ++e) rb[p][e] = keep ? rb[p][e] : 0.f;
       }
-      uint4 hi, mid, lo;
-      split3(rb[p], hi, mid, lo);
-      bs(buf, 0, g >> 1, g & 1, n) = hi;
-      bs(buf, 1, g >> 1, g & 1, n) = mid;
-      if (!LITE) bs(buf, 2, g >> 1, g & 1, n) = lo;
+      if constexpr (ARITH == kF16x2) {
+        uint4 hi, lo;
+        split2h(rb[p], xs, hi, lo);
+        bs(buf, 0, g >> 1, g & 1, n) = hi;
+        bs(buf, 1, g >> 1, g & 1, n) = lo;
+      } else {
+        uint4 hi, mid, lo;
+        split3(rb[p], hi, mid, lo);
+        bs(buf, 0, g >> 1, g & 1, n) = hi;
+        bs(buf, 1, g >> 1, g & 1, n) = mid;
+        if constexpr (PL == 3) bs(buf, 2, g >> 1, g & 1, n) = lo;
+      }
     }
   };
 
   // weights: the next k-step's fragments are in flight while the current ones are multiplied
-  uint4 af[TM][3], an[TM][3];
-  auto aload = [&](int s, uint4 (&dst)[TM][3]) {
+  uint4 af[TM][PL], an[TM][PL];
+  auto aload = [&](int s, uint4 (&dst)[TM][PL]) {
     const int sc = s < ksteps ? s : ksteps - 1;   // harmless re-read past the end
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < (LITE ? 2 : 3); ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * 3 + p) * 64];
+      for (int p = 0; p < PL; ++p) dst[i][p] = ap[i * a_tile + ((int64_t)sc * PLW + p) * 64];
   };
 
   // A time tile on which every input is zero (past the utterance's length in a ragged batch) has nothing to reduce:
@@ -198,9 +282,9 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
     const int cn = c + 1;
     // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
-    uint4 bf[2][3];
+    uint4 bf[2][PL];
 #pragma unroll
-    for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
+    for (int p = 0; p < PL; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
@@ -216,36 +300,35 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
         if (!(VASR_ABLATE & 2)) {
           if (j + 1 < TN) {
 #pragma unroll
-            for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+            for (int p = 0; p < PL; ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
           } else if (s + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < (LITE ? 2 : 3); ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
+            for (int p = 0; p < PL; ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
           }
         } else {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[nxt][p] = bf[cur][p];
+          for (int p = 0; p < PL; ++p) bf[nxt][p] = bf[cur][p];
         }
-        const uint4 bh = bf[cur][0], bm = bf[cur][1], bl = bf[cur][2];
-        // six cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
-        if constexpr (!LITE) {
+        // cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
+        if constexpr (ARITH == kBf16x3) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][2], bh, acc[i][j]);   // lo  * hi
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][2], bf[cur][0], acc[i][j]);   // lo  * hi
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bl, acc[i][j]);   // hi  * lo
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][2], acc[i][j]);   // hi  * lo
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bm, acc[i][j]);   // mid * mid
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur][1], acc[i][j]);   // mid * mid
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][1], bh, acc[i][j]);   // mid * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur][0], acc[i][j]);   // mid (lo) * hi
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bm, acc[i][j]);   // hi  * mid
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i][0], bh, acc[i][j]);   // hi  * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][0], acc[i][j]);   // hi  * hi
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int p = 0; p < (LITE ? 2 : 3); ++p) af[i][p] = an[i][p];
+        for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
     }
     if (!LAST && !(VASR_ABLATE & 4)) sstore((c + 1) & 1, cn * BKC);
     if (!(VASR_ABLATE & 8)) __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
@@ -255,6 +338,13 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
+  // max |y| over the utterance's VALID output frames, for the split of the next kF16x2 consumer of y
+  const int ylen = a.amax_y ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
+  unsigned ymax = 0;
+  auto track = [&](float v, int t) {
+    const unsigned u = __float_as_uint(v) & 0x7fffffffu;
+    ymax = (t < ylen && u > ymax) ? u : ymax;
+  };
   const bool full = (t0 + BN <= a.store_cols) && (m0 + BM <= a.m_store);
   const bool vec = full && ((a.ldy | a.ldr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
   if (vec) {
@@ -276,7 +366,11 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) buf[(4 * kh + rr) * BN + 32 * j + l31] = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][4 * q + rr];
+            if constexpr (ARITH == kF16x2) v *= out_scale;   // exact: a power of two
+            buf[(4 * kh + rr) * BN + 32 * j + l31] = fmaf(v, sc[rr], sh[rr]);
+          }
         wave_fence();
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
@@ -286,63 +380,78 @@ __global__ __launch_bounds__(64 * NW) void pw_gemm_bf16x3_kernel(PwArgs a, int b
           if (RES) v += *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m) * a.ldr + t);
           if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
           *reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t) = v;
+          if (a.amax_y) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) track(v[e], t + e);
+          }
         }
       }
     }
-    return;
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mq = m0 + wm + i * 32 + 8 * q + 4 * kh;
+        const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq);
+        const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int m = mq + rr;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int t = t0 + j * 32 + l31;
+            float v = acc[i][j][4 * q + rr];
+            if constexpr (ARITH == kF16x2) v *= out_scale;
+            v = fmaf(v, sc[rr], sh[rr]);
+            if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
+            if (a.relu & 1) v = fmaxf(v, 0.f);
+            if (full || (t < a.store_cols && m < a.m_store)) {
+              a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
+              if (a.amax_y) track(v, t);
+            }
+          }
+        }
+      }
+    }
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int mq = m0 + wm + i * 32 + 8 * q + 4 * kh;
-      const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq);
-      const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = mq + rr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int t = t0 + j * 32 + l31;
-          float v = fmaf(acc[i][j][4 * q + rr], sc[rr], sh[rr]);
-          if (RES) v += a.res[((int64_t)b * a.M + m) * a.ldr + t];
-          if (a.relu & 1) v = fmaxf(v, 0.f);
-          if (full || (t < a.store_cols && m < a.m_store)) a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
-        }
-      }
-    }
+  if (a.amax_y) {
+    ymax = wave_max_u32(ymax);
+    if (lane == 0 && ymax) atomicMax(a.amax_y + b * kAmaxSlots + ((mb * NW + wave) & (kAmaxSlots - 1)), ymax);
   }
 }
 
-template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, bool LITE>
-void launch_k(const PwArgs& a, hipStream_t st) {
-  using G = Geom<NW, TM, TN>;
+template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, int ARITH>
+int launch_k(const PwArgs& a, hipStream_t st) {
+  using G = Geom<NW, TM, TN, ARITH>;
   const int blocks_m = a.M / G::BM;
   const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
-  auto kern = pw_gemm_bf16x3_kernel<NW, TM, TN, MASK, RES, DUAL, LITE>;
-  static bool once = [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    return true;
-  }();
-  (void)once;
+  auto kern = pw_gemm_split_kernel<NW, TM, TN, MASK, RES, DUAL, ARITH>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  if (attr != hipSuccess) return (int)attr;
   VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
+  return 0;
 }
 
-template <int NW, int TM, int TN, bool LITE>
-void launch_l(const PwArgs& a, hipStream_t st) {
+template <int NW, int TM, int TN, int ARITH>
+int launch_l(const PwArgs& a, hipStream_t st) {
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) launch_k<NW, TM, TN, false, false, true, LITE>(a, st);
-  else if (mask && res) launch_k<NW, TM, TN, true, true, false, LITE>(a, st);
-  else if (mask) launch_k<NW, TM, TN, true, false, false, LITE>(a, st);
-  else if (res) launch_k<NW, TM, TN, false, true, false, LITE>(a, st);
-  else launch_k<NW, TM, TN, false, false, false, LITE>(a, st);
+  if (dual) return launch_k<NW, TM, TN, false, false, true, ARITH>(a, st);
+  if (mask && res) return launch_k<NW, TM, TN, true, true, false, ARITH>(a, st);
+  if (mask) return launch_k<NW, TM, TN, true, false, false, ARITH>(a, st);
+  if (res) return launch_k<NW, TM, TN, false, true, false, ARITH>(a, st);
+  return launch_k<NW, TM, TN, false, false, false, ARITH>(a, st);
 }
 
 template <int NW, int TM, int TN>
-void launch_t(const PwArgs& a, hipStream_t st) {
-  if (a.relu & 4) launch_l<NW, TM, TN, true>(a, st);   // bit 2 of `relu`: the 3-term "bf16x2" arithmetic
-  else launch_l<NW, TM, TN, false>(a, st);
+int launch_t(const PwArgs& a, int arith, hipStream_t st) {
+  switch (arith) {
+    case kF16x2: return launch_l<NW, TM, TN, kF16x2>(a, st);
+    case kBf16x2: return launch_l<NW, TM, TN, kBf16x2>(a, st);
+    default: return launch_l<NW, TM, TN, kBf16x3>(a, st);
+  }
 }
 
 inline unsigned short bf16_rne(float x, float* back) {
@@ -354,34 +463,37 @@ inline unsigned short bf16_rne(float x, float* back) {
 
 }  // namespace
 
-bool pointwise_bf16x3_supported(int M, int K, int K1) {
+bool pointwise_split_supported(int M, int K, int K1) {
   return M % 64 == 0 && K % BKC == 0 && (K1 == 0 || K1 % BKC == 0);
 }
 
-void launch_pointwise_bf16x3(const PwArgs& args, hipStream_t st) {
-  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..4 pins a tile shape
+// arith: 0 = 3 x bf16 (six products), 1 = 2 x bf16 (three products, reduced), 2 = 2 x fp16 scaled (three products; needs
+// a.amax_x (and a.amax_x2 for a dual source), a.w_inv_scale and the fp16 weight pack).  Returns 0 or a hipError_t.
+int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st) {
+  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..6 pins a tile shape
   static const bool no_skip = getenv("VASR_NO_TILE_SKIP") && atoi(getenv("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
   PwArgs a = args;
   if (no_skip) a.zero_from = nullptr;
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[5] = {0, 512, 256, 128, 64};
+  const int rows[7] = {0, 512, 256, 128, 64, 256, 256};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
   else if (a.M % 128 == 0 && blocks(128, 64) >= 192) tile = 3;
-  if (force >= 1 && force <= 4 && a.M % rows[force] == 0) tile = force;
   // 256-channel layers: 256 x 64 tiles put two or three workgroups on a CU (49 KB of LDS each), which hides more of
   // one workgroup's prologue / epilogue behind another's main loop: 30.0 -> 28.7 us at K = 256, 49.1 -> 48.1 at K = 512
-  if (tile == 2 && a.M == 256 && blocks(256, 64) >= 384 && (force == 0 || force == 5)) tile = 5;
+  if (tile == 2 && a.M == 256 && blocks(256, 64) >= 384) tile = 5;
   // (for the 512-channel layers both 256 x 64 and 512 x 64 measured slower than 512 x 128: 88-91 / 94-97 vs 86 us)
+  if (force >= 1 && force <= 6 && a.M % rows[force] == 0) tile = force;
   switch (tile) {
-    case 1: return launch_t<8, 2, 4>(a, st);
-    case 2: return launch_t<8, 1, 4>(a, st);
-    case 5: return launch_t<8, 1, 2>(a, st);
-    case 3: return launch_t<4, 1, 2>(a, st);
-    default: return launch_t<2, 1, 1>(a, st);
+    case 1: return launch_t<8, 2, 4>(a, arith, st);
+    case 2: return launch_t<8, 1, 4>(a, arith, st);
+    case 5: return launch_t<8, 1, 2>(a, arith, st);
+    case 6: return launch_t<4, 2, 4>(a, arith, st);   // 256 x 128 on four wavefronts: two workgroups per CU (kF16x2: 64 KB of LDS each)
+    case 3: return launch_t<4, 1, 2>(a, arith, st);
+    default: return launch_t<2, 1, 1>(a, arith, st);
   }
 }
 
@@ -404,6 +516,31 @@ void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad,
           out[base + 64 * 8] = mi;
           out[base + 2 * 64 * 8] = lo;
         }
+}
+
+// Same fragment order with two fp16 planes [m_pad/32][cin/16][2][64][8]: hi = rne16(s w), lo = rne16(s w - hi), s the
+// power of two that puts the layer's largest |w| into [2^14, 2^15).  Returns 1/s for the epilogue.
+float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad, unsigned short* out) {
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)cout * cin; ++i) mx = fabsf(w[i]) > mx ? fabsf(w[i]) : mx;
+  int e = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+  e = e < 16 ? 16 : (e > 254 ? 254 : e);
+  const float s = __builtin_bit_cast(float, (unsigned)(268 - e) << 23), inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
+  const int ksteps = cin / 16;
+  auto bits = [](_Float16 h) { return __builtin_bit_cast(unsigned short, h); };
+  for (int mt = 0; mt < m_pad / 32; ++mt)
+    for (int st = 0; st < ksteps; ++st)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int el = 0; el < 8; ++el) {
+          const int m = mt * 32 + (lane & 31), k = st * 16 + 8 * (lane >> 5) + el;
+          const float x = (m < cout ? w[(size_t)m * cin + k] : 0.f) * s;
+          const _Float16 h = (_Float16)x;              // round to nearest even
+          const _Float16 l = (_Float16)(x - (float)h);
+          const size_t base = (((size_t)mt * ksteps + st) * 2) * 64 * 8 + (size_t)lane * 8 + el;
+          out[base] = bits(h);
+          out[base + 64 * 8] = bits(l);
+        }
+  return inv;
 }
 
 }  // namespace vasr
@@ -454,17 +591,17 @@ __global__ __launch_bounds__(512) void mfma_bf16_sustained_kernel(int steps, flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][2], bf[j][0], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][2], bf[j][0], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][2], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][0], bf[j][2], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][1], bf[j][1], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][1], bf[j][1], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][1], bf[j][0], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][1], bf[j][0], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][1], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][0], bf[j][1], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mma(af[i][0], bf[j][0], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = mma<kBf16x3>(af[i][0], bf[j][0], acc[i][j]);
     }
   }
   float t = 0.f;

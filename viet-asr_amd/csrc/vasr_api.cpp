@@ -48,7 +48,9 @@ struct ConvLayer {
   int cin = 0, cout = 0, kernel = 1, stride = 1, dilation = 1, pad = 0;
   int m_pad = 0;             // pointwise: rows of the packed weight (multiple of 128)
   float* d_w = nullptr;      // depthwise [C][K]; pointwise: MFMA A-fragment order (fp32)
-  unsigned short* d_w3 = nullptr;  // pointwise: 3 x bf16 split fragments (encoder_pw_bf16x3.hip), when the shape allows
+  unsigned short* d_w3 = nullptr;  // pointwise: 3 x bf16 split fragments (encoder_pw_split.hip), when the shape allows
+  unsigned short* d_w16 = nullptr; // pointwise: 2 x fp16 scaled split fragments, same condition
+  float w16_inv = 1.f;             // 1 / (power-of-two scale of the fp16 pack)
   float* d_scale = nullptr;  // [m_pad]
   float* d_shift = nullptr;  // [m_pad]
   int step = -1;             // index in the MaskedConv1d length chain
@@ -71,6 +73,15 @@ struct Block {
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int kDefaultGemmMode = 1;
+int parse_gemm_mode(const char* s) {
+  if (!s) return kDefaultGemmMode;
+  if (!strcmp(s, "fp32")) return 0;
+  if (!strcmp(s, "bf16x3")) return 1;
+  if (!strcmp(s, "bf16x2")) return 2;
+  if (!strcmp(s, "f16x2")) return 3;
+  return kDefaultGemmMode;
+}
 constexpr int kMaxSlices = 4;
 
 }  // namespace
@@ -102,7 +113,8 @@ struct vasr_handle {
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16
   // Default 1: measured max error against fp64 is slightly LOWER than mode 0's (tools/kscan.py: 3.6e-6 vs 4.7e-6 at
   // K=512) and every parity test passes unchanged, at 1.6x the GEMM throughput.  VASR_GEMM=fp32 selects mode 0.
-  int gemm_mode = !getenv("VASR_GEMM") ? 1 : !strcmp(getenv("VASR_GEMM"), "fp32") ? 0 : !strcmp(getenv("VASR_GEMM"), "bf16x2") ? 2 : 1;
+  // 3 = 2 x fp16 scaled split operands on v_mfma_f32_32x32x16_f16 (half the matrix work of mode 1, see vasr.h)
+  int gemm_mode = parse_gemm_mode(getenv("VASR_GEMM"));
   bool profiling = false;
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;
@@ -209,10 +221,13 @@ int pack_fused_residual(vasr_handle* h, const std::string& w1_key, const std::st
   std::vector<float> wt((size_t)K * L->m_pad, 0.f), sc(L->m_pad, 1.f), sh(L->m_pad, 0.f);
   pack_pointwise_weights(w.data(), cout, K, L->m_pad, wt.data());
   for (int m = 0; m < cout; ++m) sh[m] = b1[m] + b2[m];
-  if (pointwise_bf16x3_supported(L->m_pad, K, k1)) {
+  if (pointwise_split_supported(L->m_pad, K, k1)) {
     std::vector<unsigned short> w3((size_t)K * L->m_pad * 3);
     pack_pointwise_weights_bf16x3(w.data(), cout, K, L->m_pad, w3.data());
     if ((rc = upload(h, w3, &L->d_w3))) return rc;
+    std::vector<unsigned short> w16((size_t)K * L->m_pad * 2);
+    L->w16_inv = pack_pointwise_weights_f16x2(w.data(), cout, K, L->m_pad, w16.data());
+    if ((rc = upload(h, w16, &L->d_w16))) return rc;
   }
   if ((rc = upload(h, wt, &L->d_w)) || (rc = upload(h, sc, &L->d_scale))) return rc;
   return upload(h, sh, &L->d_shift);
@@ -223,16 +238,20 @@ int pack_pointwise(vasr_handle* h, const std::string& key, int cout, int cin, Co
   const HostTensor* w;
   int rc;
   if ((rc = need(h, key, (size_t)cout * cin, &w))) return rc;
-  if (cin % 32) return fail(VASR_ERR_UNSUPPORTED, "%s: in_channels %d is not a multiple of 32", key.c_str(), cin);
+  // (a K depth of 32 would select the 128 x 256 tile of the fp32 kernel, whose last time tile assumes a 256-frame pitch)
+  if (cin % 64) return fail(VASR_ERR_UNSUPPORTED, "%s: in_channels %d is not a multiple of 64", key.c_str(), cin);
   L->cin = cin;
   L->cout = cout;
   L->m_pad = (int)align_up(cout, 128);
   std::vector<float> wt((size_t)cin * L->m_pad, 0.f);
   pack_pointwise_weights(w->data.data(), cout, cin, L->m_pad, wt.data());
-  if (pointwise_bf16x3_supported(L->m_pad, cin, 0)) {
+  if (pointwise_split_supported(L->m_pad, cin, 0)) {
     std::vector<unsigned short> w3((size_t)cin * L->m_pad * 3);
     pack_pointwise_weights_bf16x3(w->data.data(), cout, cin, L->m_pad, w3.data());
     if ((rc = upload(h, w3, &L->d_w3))) return rc;
+    std::vector<unsigned short> w16((size_t)cin * L->m_pad * 2);
+    L->w16_inv = pack_pointwise_weights_f16x2(w->data.data(), cout, cin, L->m_pad, w16.data());
+    if ((rc = upload(h, w16, &L->d_w16))) return rc;
   }
   return upload(h, wt, &L->d_w);
 }
@@ -368,7 +387,7 @@ int build_decoder(vasr_handle* h) {
 
 // ---------------- workspace plan ----------------
 struct WsPlan {
-  size_t lens_tab, seq, melp, bufP, bufQ, bufD, bufR, bufS, encp, logits, pred, total;
+  size_t lens_tab, amax, seq, melp, bufP, bufQ, bufD, bufR, bufS, encp, logits, pred, total;
   int64_t T, Tp0, T1, Tp1;
 };
 
@@ -393,6 +412,8 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
   p.lens_tab = take((h->steps.size() + 1) * (size_t)batch * 4);
+  // maxima table of the fp16-split GEMMs: one [B][kAmaxSlots] row per conv of the length chain (+ 1 spare)
+  p.amax = take((h->steps.size() + 2) * (size_t)batch * kAmaxSlots * 4);
   p.seq = take((size_t)batch * 8);
   p.melp = take((size_t)batch * (h->has_encoder ? h->feat_in : 64) * p.Tp0 * 4);
   const size_t mid = (size_t)batch * h->c_mid_max * std::max(tp_mid, p.Tp1) * 4;
@@ -415,7 +436,7 @@ struct ProfScope {
   static hipEvent_t get(vasr_handle* h) {
     hipEvent_t e;
     if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;   // a null event makes the record / elapsed calls fail loudly
     return e;
   }
   // Single-launch classes (depthwise, pointwise) hand the event pair to the launch itself (g_probe: the dispatch
@@ -449,15 +470,24 @@ int check_launch(const char* what) {
 }
 
 // GEMM dispatch: exact-fp32 MFMA kernel, or the 3 x bf16 split kernel when selected and the layer has that pack.
-static void run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStream_t st) {
+// Returns 1 when the launch published a.amax_y (only the split kernel does), 0 when not, < 0 on error.
+static int run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStream_t st) {
   if (h->gemm_mode >= 1 && W.d_w3) {
+    int arith = h->gemm_mode == 2 ? 1 : 0;
     a.wt = reinterpret_cast<const float*>(W.d_w3);
-    if (h->gemm_mode == 2) a.relu |= 4;   // 3-term "bf16x2" arithmetic (opt-in, 16-bit operands)
-    launch_pointwise_bf16x3(a, st);
-  } else {
-    a.wt = W.d_w;
-    launch_pointwise(a, st);
+    // fp16 split: needs the maxima of every source this GEMM reads; a source without them keeps the 3 x bf16 form
+    if (h->gemm_mode == 3 && W.d_w16 && a.amax_x && (!a.x2 || a.amax_x2)) {
+      arith = 2;
+      a.wt = reinterpret_cast<const float*>(W.d_w16);
+      a.w_inv_scale = W.w16_inv;
+    }
+    const int e = launch_pointwise_split(a, arith, st);
+    if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
+    return a.amax_y != nullptr ? 1 : 0;
   }
+  a.wt = W.d_w;
+  launch_pointwise(a, st);
+  return 0;
 }
 
 // Encoder over an input [B][feat_in][x_ld]; writes [B][c_last][out_ld] (T1 valid frames).
@@ -471,11 +501,21 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
   float* D = reinterpret_cast<float*>(ws + p.bufD);
   const float* cur = x;
   int64_t cur_ld = x_ld, cur_T = T;
+  // fp16-split GEMMs: maxima rows, indexed by the length-chain step of the conv that produced the tensor
+  const bool want_amax = h->gemm_mode == 3;
+  unsigned int* amax_tab = reinterpret_cast<unsigned int*>(ws + p.amax);
+  auto amax_row = [&](int step) { return amax_tab + (size_t)step * batch * kAmaxSlots; };
+  if (want_amax) {
+    hipError_t e = hipMemsetAsync(amax_tab, 0, (h->steps.size() + 2) * (size_t)batch * kAmaxSlots * 4, st);
+    if (e != hipSuccess) return fail(VASR_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  const unsigned int* cur_amax = nullptr;   // maxima of `cur` over each utterance's valid frames (nullptr: not known)
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     Block& B = h->blocks[i];
     const bool last_block = i + 1 == h->blocks.size();
     const float* blk_in = cur;
     const int64_t blk_ld = cur_ld;
+    const unsigned int* blk_amax = cur_amax;
     // scratch buffers that are not the block input (the fused residual reads it until the block's last GEMM):
     // sub-block outputs ping-pong between the first two, an unfused residual result takes the third
     float* free3[3];
@@ -489,8 +529,9 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.res = nullptr; a.y = R; a.M = B.res.m_pad; a.K = B.res.cin; a.batch = batch;
       a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
       a.m_store = B.res.m_pad; a.relu = 0;
+      a.amax_x = blk_amax;
       ProfScope ps(h, kProfPointwise, st);
-      run_pointwise(h, a, B.res, st);
+      if (run_pointwise(h, a, B.res, st) < 0) return VASR_ERR_HIP;
     }
     int flip = 0;
     for (size_t r = 0; r < B.subs.size(); ++r) {
@@ -499,13 +540,15 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       const float* gx = cur;
       int64_t gx_ld = cur_ld, g_T = cur_T;
       const int32_t* g_lens = nullptr;
+      const unsigned int* gx_amax = cur_amax;
       if (S.separable) {
         const int64_t t_out = conv_out_frames(cur_T, S.dw);
         const int64_t ld_out = pad_frames(t_out);
         ProfScope ps(h, kProfDepthwise, st);
+        unsigned int* am = want_amax ? amax_row(S.dw.step) : nullptr;
         launch_depthwise(cur, cur_ld, (int)cur_T, S.dw.d_w, lens(S.dw.step), lens(S.dw.step + 1), batch, S.dw.cin,
-                         S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st);
-        gx = D; gx_ld = ld_out; g_T = t_out;
+                         S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st, am);
+        gx = D; gx_ld = ld_out; g_T = t_out; gx_amax = am;
       } else {
         g_lens = lens(S.pw.step);  // block input is unmasked: predicate inside the GEMM
       }
@@ -526,11 +569,18 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       if (fuse) { a.x2 = blk_in; a.lens2 = lens(B.first_step); a.K1 = B.fused_k1; a.ldx2 = blk_ld; }
       if ((a.res || fuse) && blk_ld != gx_ld)
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
+      a.amax_x = gx_amax;
+      a.amax_x2 = fuse ? blk_amax : nullptr;
+      // this GEMM's output is masked at lens(S.pw.step + 1) by whatever reads it next
+      if (want_amax && !(last_block && last_sub)) { a.amax_y = amax_row(S.pw.step); a.lens_y = lens(S.pw.step + 1); }
+      int published;
       {
         ProfScope ps(h, kProfPointwise, st);
-        run_pointwise(h, a, W, st);
+        published = run_pointwise(h, a, W, st);
       }
+      if (published < 0) return VASR_ERR_HIP;
       cur = dst; cur_ld = dst_ld; cur_T = g_T;
+      cur_amax = published ? a.amax_y : nullptr;
     }
   }
   return check_launch("encoder");
@@ -544,7 +594,8 @@ int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int b
   a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
   a.relu = 0;
   ProfScope ps(h, kProfHead, st);
-  run_pointwise(h, a, h->dec, st);   // split-bf16 GEMM unless fp32 mode is selected (the head is HBM-bound either way)
+  // 3 x bf16 split GEMM unless fp32 mode is selected (no maxima are passed: the head, HBM-bound, never takes the fp16 form)
+  if (run_pointwise(h, a, h->dec, st) < 0) return VASR_ERR_HIP;
   launch_logsoftmax_argmax(logits, ld, (int64_t)h->num_classes * ld, batch, (int)T1, h->num_classes, logp, pred, st);
   return check_launch("decoder");
 }
@@ -856,11 +907,14 @@ int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in,
 }
 
 int vasr_set_gemm_mode(vasr_handle* h, int mode) {
-  if (!h || mode < 0 || mode > 2)
-    return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA), 1 (3 x bf16 split) or 2 (2 x bf16 split, reduced)");
+  if (!h || mode < 0 || mode > 3)
+    return fail(VASR_ERR_INVALID, "gemm mode must be 0 (fp32 MFMA), 1 (3 x bf16 split), 2 (2 x bf16 split, reduced) or "
+                                  "3 (2 x fp16 scaled split)");
   h->gemm_mode = mode;
   return 0;
 }
+
+int vasr_get_gemm_mode(const vasr_handle* h) { return h ? h->gemm_mode : -1; }
 
 int vasr_set_row_independent(vasr_handle* h, int on) {
   if (!h) return fail(VASR_ERR_INVALID, "null handle");
@@ -1051,16 +1105,46 @@ int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, u
   return 0;
 }
 
+int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out, float* inv_scale) {
+  if (!h_w || !h_out || !inv_scale || cout <= 0 || cin % 16 || m_pad % 32 || m_pad < cout)
+    return fail(VASR_ERR_INVALID, "bad argument");
+  *inv_scale = pack_pointwise_weights_f16x2(h_w, cout, cin, m_pad, h_out);
+  return 0;
+}
+
+int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
+                               const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
+                               uint32_t* d_amax, int compute_amax, vasr_stream stream) {
+  if (!d_x || !d_w16 || !d_scale || !d_shift || !d_y || !d_amax || !pointwise_split_supported(cout, cin, 0))
+    return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(frames);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (compute_amax) {
+    HIP_TRY(hipMemsetAsync(d_amax, 0, (size_t)2 * batch * kAmaxSlots * 4, st));
+    launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, d_amax, st);
+  }
+  PwArgs a{};
+  a.wt = reinterpret_cast<const float*>(d_w16); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
+  a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.amax_x = d_amax; a.w_inv_scale = w_inv_scale;
+  a.amax_y = d_amax + (size_t)batch * kAmaxSlots;   // second row: maxima of y (what the next layer would read)
+  const int e = launch_pointwise_split(a, 2, st);
+  if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
+  return check_launch("bench_pointwise_f16x2");
+}
+
 int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
                                 int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
-  if (!d_x || !d_w3 || !d_scale || !d_shift || !d_y || !pointwise_bf16x3_supported(cout, cin, 0))
+  if (!d_x || !d_w3 || !d_scale || !d_shift || !d_y || !pointwise_split_supported(cout, cin, 0))
     return fail(VASR_ERR_INVALID, "bad argument");
   const int64_t ld = pad_frames(frames);
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
   a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
-  launch_pointwise_bf16x3(a, static_cast<hipStream_t>(stream));
+  const int e = launch_pointwise_split(a, getenv("VASR_BENCH_BF16X2") ? 1 : 0, static_cast<hipStream_t>(stream));
+  if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
   return check_launch("bench_pointwise_bf16x3");
 }
 

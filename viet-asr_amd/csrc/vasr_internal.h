@@ -24,10 +24,18 @@ extern thread_local LaunchProbe g_probe;
   } while (0)
 
 // Activations live in HBM as [B][C][ld] fp32 with the time axis contiguous and
-// ld = pad_frames(T): every row starts 1-KB aligned and every (64..256)-frame GEMM tile stays
+// ld = pad_frames(T): every row starts 512-byte aligned and every (32..128)-frame GEMM tile stays
 // inside one utterance.  Columns t >= T are padding (never consumed unmasked).
-constexpr int kTimeTile = 256;
+// (Round 1 padded to 256 frames: T' = 516 -- a 10.3 s clip -- then cost 768 columns, +50 % depthwise tiles and GEMM
+// epilogues over T' = 512; at 128 it costs 640.)
+constexpr int kTimeTile = 128;
 static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
+
+// Per-utterance maxima for the fp16-split GEMM (encoder_pw_split.hip, kF16x2): every kernel that produces a tensor a
+// 1x1 convolution will read publishes max |y| over the utterance's valid frames as an fp32 bit pattern, spread over
+// kAmaxSlots words per utterance (one unreturned atomicMax per wavefront; the slots keep same-address atomics apart).
+// The table [tensor][B][kAmaxSlots] lives in the workspace and is zeroed once per encoder pass.
+constexpr int kAmaxSlots = 8;
 
 // ---- front end (frontend.hip) ----
 struct FrontendTables {
@@ -60,9 +68,10 @@ void launch_repad(const float* src, int64_t src_ld, int rows, int frames, float*
 
 // depthwise masked conv: y[b][c][t] = sum_k w[c][k] * xm[b][c][t*stride + k*dil - pad],
 // xm = x where t < lens_in[b] else 0; y forced to 0 for t >= lens_out[b]; all columns < ldy written.
+// amax_y: [batch][kAmaxSlots] maxima table of the output (nullptr = not wanted)
 void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
                       const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
-                      int pad, float* y, int64_t ldy, hipStream_t st);
+                      int pad, float* y, int64_t ldy, hipStream_t st, unsigned int* amax_y = nullptr);
 
 struct PwArgs {
   const float* wt;        // weights in MFMA fragment order (pack_pointwise_weights), M % 128 == 0, K % 32 == 0
@@ -86,16 +95,29 @@ struct PwArgs {
   // the masks guarantee it), so a time tile that starts there skips its K loop: its outputs are relu(shift (+ res)).
   // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
   const int32_t* zero_from;
+  // kF16x2 only: maxima tables of x / x2 (inputs, [B][kAmaxSlots]) and 1 / (weight scale) of the fp16 pack
+  const unsigned int* amax_x;
+  const unsigned int* amax_x2;
+  float w_inv_scale;
+  // any split arithmetic: publish max |y| over columns < lens_y[b] (nullptr: < frames) into amax_y (nullptr = off)
+  unsigned int* amax_y;
+  const int32_t* lens_y;
 };
 void launch_pointwise(const PwArgs& a, hipStream_t st);
 // host: [cout][cin] row-major -> fragment order [m_pad/32][cin/8][64][4] (zero rows past cout)
 void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float* out);
 
-// 3 x bf16 split variant (encoder_pw_bf16x3.hip): same PwArgs, a.wt points at the bf16 fragment pack
-bool pointwise_bf16x3_supported(int M, int K, int K1);
+// split-operand variants (encoder_pw_split.hip): same PwArgs, a.wt points at the 16-bit fragment pack of the arithmetic
+// arith: 0 = 3 x bf16 (six MFMA products per multiply), 1 = 2 x bf16 (three, reduced precision), 2 = 2 x fp16 scaled
+// (three; needs amax_x / w_inv_scale and the fp16 pack).  Returns 0 or a hipError_t.
+bool pointwise_split_supported(int M, int K, int K1);
 double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st);
-void launch_pointwise_bf16x3(const PwArgs& a, hipStream_t st);
+int launch_pointwise_split(const PwArgs& a, int arith, hipStream_t st);
 void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out);
+float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad, unsigned short* out);   // returns 1 / scale
+// [batch][kAmaxSlots] maxima of a contiguous-per-utterance tensor x[b][rows][ld] over columns < lens[b] (or < frames)
+void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, unsigned int* amax,
+                 hipStream_t st);
 
 // ---- CTC head / decode (decode.hip) ----
 // logits [B][ldm rows][ld] (row v, column t) -> logp [B][T][V] (optional), pred [B][T] (optional)

@@ -66,6 +66,7 @@ class QuartzNetCTC:
         self._ws = None
         self._slots, self._copy_stream, self._launched = None, None, 0
         self._row_independent = False
+        self._beam_stream = None
 
     # -- shapes
     def frames(self, samples):
@@ -139,6 +140,31 @@ class QuartzNetCTC:
                          want_logp=True, want_pred=False, row_independent=row_independent)
         own = [self.frames(n)[1] for n in lens] if row_independent else None
         return beam_decoder.decode_batch(r["logp"], beam_width, frames=own)
+
+    def forward_beam(self, wav, length, beam_decoder, beam_width, frames=None, overlap=True):
+        """Acoustic pass + beam search (+ LM) of one device-resident batch: the batched form of infer.py:146-160.
+
+        overlap=True runs the search on a side stream: it occupies one workgroup per utterance (64 of the 256 CUs at
+        B = 64) for about as long as the acoustic pass of the NEXT batch takes on the whole chip, so queued behind the
+        log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
+        score, done): ``done`` is an event on the side stream (None when overlap is off); wait for it -- or
+        synchronise the device -- before reading the results from another stream."""
+        r = self.forward(wav, length, want_logp=True, want_pred=False)
+        if not overlap:
+            ids, n, score = beam_decoder.decode_ids(r["logp"], beam_width, frames)
+            return dict(ids=ids, id_len=n, score=score, done=None, enc_len=r["enc_len"])
+        if self._beam_stream is None:
+            self._beam_stream = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._beam_stream):
+            self._beam_stream.wait_event(ready)
+            ids, n, score = beam_decoder.decode_ids(r["logp"], beam_width, frames)
+            done = torch.cuda.Event()
+            done.record(self._beam_stream)
+        r["logp"].record_stream(self._beam_stream)     # allocated on the main stream, last read on the side stream
+        return dict(ids=ids, id_len=n, score=score, done=done, enc_len=r["enc_len"])
 
     # -- pipelined host path: pinned staging, copies on their own stream, two batches in flight
     def launch(self, signals, row_independent=False):

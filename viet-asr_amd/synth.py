@@ -120,3 +120,87 @@ def audio_batch(batch, samples, seed=0, ragged=False, amp=0.1):
     for b in range(batch):
         x[b, lens[b]:] = 0.0
     return x, lens
+
+
+def synthetic_arpa(path, labels, n_words=20000, n_bigrams=50000, n_trigrams=50000, seed=0):
+    """Write a deterministic back-off 3-gram model in ARPA text at a REALISTIC table size (defaults: 120 003 n-grams;
+    the reference's own LMs -- .MISSING_LARGE_BLOBS:4-7, 3/4/5-gram binaries -- are absent) and return
+    {tuple(words): (log10 p, log10 backoff)}.  Words are random strings over the letters of ``labels`` (2-8
+    characters, Zipf-like unigram scores), bigrams / trigrams random tuples of them with back-off weights on every
+    context that has an extension -- not a normalised model, but every table lookup, back-off step and <unk> path of
+    a real one is exercised at a real hash-table load."""
+    r = np.random.RandomState(0x5EED + seed)
+    letters = [c for c in labels if c.strip() and c.isalpha()]
+    words = set()
+    while len(words) < n_words:
+        for n in r.randint(2, 9, size=n_words):
+            words.add("".join(letters[i] for i in r.randint(0, len(letters), size=n)))
+            if len(words) == n_words:
+                break
+    words = sorted(words)
+    rank = r.permutation(n_words)
+    ng = {("<s>",): (-99.0, -0.35), ("</s>",): (-1.6, 0.0), ("<unk>",): (-4.5, 0.0)}
+    uni_p = -1.5 - 0.9 * np.log10(1.0 + rank)                      # Zipf-like
+    uni_bo = -0.6 * r.rand(n_words)
+    for w, p, bo in zip(words, uni_p, uni_bo):
+        ng[(w,)] = (round(float(p), 6), round(float(bo), 6))
+    pop = np.argsort(rank)                                          # frequent words first
+    def pick(n):                                                    # frequent words appear in more n-grams
+        return pop[np.minimum((r.rand(n) ** 2.5 * n_words).astype(np.int64), n_words - 1)]
+    a, b = pick(n_bigrams), pick(n_bigrams)
+    for i in range(n_bigrams):
+        ng[(words[a[i]], words[b[i]])] = (round(float(-0.3 - 2.5 * r.rand()), 6), round(float(-0.5 * r.rand()), 6))
+    big = [k for k in ng if len(k) == 2]
+    pre = r.randint(0, len(big), size=n_trigrams)
+    c = pick(n_trigrams)
+    for i in range(n_trigrams):
+        ng[big[pre[i]] + (words[c[i]],)] = (round(float(-0.2 - 2.0 * r.rand()), 6), 0.0)
+    for i in range(min(2000, n_bigrams)):                           # sentence starts and ends
+        ng[("<s>", words[a[i]])] = (round(float(-1.0 - 2.0 * r.rand()), 6), round(float(-0.4 * r.rand()), 6))
+        ng[(words[b[i]], "</s>")] = (round(float(-0.8 - 1.5 * r.rand()), 6), 0.0)
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\\data\\\n")
+        by_n = {n: sorted(k for k in ng if len(k) == n) for n in (1, 2, 3)}
+        for n in (1, 2, 3):
+            f.write(f"ngram {n}={len(by_n[n])}\n")
+        for n in (1, 2, 3):
+            f.write(f"\n\\{n}-grams:\n")
+            for k in by_n[n]:
+                p, bo = ng[k]
+                f.write(f"{p:.6f}\t{' '.join(k)}" + (f"\t{bo:.6f}" if n < 3 else "") + "\n")
+        f.write("\n\\end\\\n")
+    return ng
+
+
+def ctc_like_log_probs(batch, frames, labels, words, seed=0, blank_frac=0.55, noise=1.3):
+    """[batch, frames, len(labels)+1] float32 log-probabilities shaped like the output of a CONVERGED CTC model (the
+    random-weight models here emit near-deterministic posteriors, ~1.1 classes per frame above pyctcdecode's
+    token_min_logp, which leave a beam search nothing to do): each row spells a sequence of ``words`` (separated by
+    ' '), every character held for 1-3 frames between runs of blank frames; frames carry Gaussian logit noise and now
+    and then a competing character, so a handful of classes clear token_min_logp = -5 and beams genuinely branch,
+    merge and get re-ranked by the language model at word boundaries.  Blank is the last class."""
+    r = np.random.RandomState(0xC7C + seed)
+    V = len(labels)
+    lab = {c: i for i, c in enumerate(labels)}
+    out = np.empty((batch, frames, V + 1), dtype=np.float32)
+    for b in range(batch):
+        z = noise * r.randn(frames, V + 1).astype(np.float32)
+        t = 0
+        prev = None
+        while t < frames:
+            w = words[r.randint(0, len(words))] + " "
+            for ch in w:
+                if t >= frames:
+                    break
+                gap = r.geometric(1.0 - blank_frac) - 1 + (1 if ch == prev else 0)     # a repeat needs a blank between
+                z[t:t + gap, V] += 9.0
+                t += gap
+                hold = r.randint(1, 4)
+                z[t:t + hold, lab[ch]] += 7.0 + 2.0 * r.rand()
+                if r.rand() < 0.25 and t < frames:                                      # a competitor on the first frame
+                    z[t, r.randint(0, V)] += 6.0
+                t += hold
+                prev = ch
+        z = z.astype(np.float64)
+        out[b] = (z - np.log(np.exp(z).sum(-1, keepdims=True))).astype(np.float32)
+    return out
