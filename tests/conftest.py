@@ -35,6 +35,23 @@ def load_golden(name):
     return g, cfg, sig, lens, enc_sd, dec_sd
 
 
+REAL_AUDIO_CASES = ["real16k_thoisu_5", "real8k_external_2"]
+
+
+def load_real_audio_golden(name):
+    """-> (golden npz, model definition, int16 PCM, sample rate, synthetic encoder sd, REAL Vietnamese head sd, seeded head sd).
+    A recording of the reference's audio_samples/ with the outputs of the imported reference (make_golden.py)."""
+    from viet_asr_amd import configs, synth
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    head = np.load(os.path.join(GOLDEN_DIR, "vi12x1_b2_q2_realdec.npz"), allow_pickle=False)   # the same shipped checkpoint
+    cfg = configs.builtin(str(g["cfg_file"]))
+    jas = cfg["JasperEncoder"]["jasper"]
+    seed = int(g["seed"])
+    real = {"decoder_layers.0.weight": head["dec_weight"], "decoder_layers.0.bias": head["dec_bias"]}
+    return (g, cfg, g["pcm"], int(g["sample_rate"]), synth.encoder_state_dict(jas, 64, seed), real,
+            synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, seed))
+
+
 @pytest.fixture(scope="session")
 def gpu():
     import torch

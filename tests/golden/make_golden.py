@@ -192,6 +192,61 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None):
     print("   hyp[0][:60] =", repr(hyp[0][:60]))
 
 
+def run_real_audio_case(name, wav_name, seed):
+    """One file of the reference's audio_samples/ through the imported reference, the way infer.py:194-206 feeds it:
+    decode to float32 in [-1, 1) at 16 kHz (librosa.load(sr=16000), infer.py:200 -- third-party: int16 / 2^15 is what it
+    returns for PCM, and its 8 kHz -> 16 kHz conversion is resampy's kaiser_best, restated in oracle/audio_oracle.py,
+    parity unpinned), one utterance per call, synthetic encoder weights (the trained encoder is not in the mount) and
+    the REAL Vietnamese CTC head.  The fixture stores the file's int16 samples (data) and the reference's outputs."""
+    import wave
+    pkg = _load_pkg()
+    synth = pkg.synth
+    from nemo.collections.asr.helpers import post_process_predictions
+    from oracle import audio_oracle as AO
+    with wave.open(os.path.join(REF, "audio_samples", wav_name)) as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2
+        sr = w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()
+    x = pcm.astype(np.float32) / 32768.0
+    if sr != 16000:
+        x = AO.resample(x, sr, 16000)
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "quartznet12x1_vi.yaml"), encoding="utf-8"))
+    labels = cfg["labels"]
+    nf, pre, enc, dec, greedy = build_reference(cfg, labels)
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd = synth.encoder_state_dict(jas, 64, seed)
+    dec_sd = {k: v.numpy() for k, v in torch.load(os.path.join(REF, "models/acoustic_model/vietnamese/JasperDecoderForCTC-STEP-289936.pt"),
+                                                  map_location="cpu").items()}
+    enc.load_state_dict({k: torch.as_tensor(v) for k, v in enc_sd.items()})
+    dec.load_state_dict({k: torch.as_tensor(v) for k, v in dec_sd.items()})
+    enc.eval(); dec.eval(); greedy.eval()
+    with torch.no_grad():
+        mel, seq = pre(force_pt=True, input_signal=torch.as_tensor(x)[None], length=torch.tensor([len(x)]))
+        e, elen = enc(force_pt=True, audio_signal=mel, length=seq)
+        logp = dec(force_pt=True, encoder_output=e)
+        pred = greedy(force_pt=True, log_probs=logp)
+        # On untrained encoder features the real head answers blank on every frame (empty transcript): the same encoder
+        # output also goes through a seeded head, whose non-trivial transcript makes the comparison bite.
+        dec.load_state_dict({k: torch.as_tensor(v) for k, v in synth.decoder_state_dict(1024, len(labels) + 1, seed).items()})
+        logp_syn = dec(force_pt=True, encoder_output=e)
+        pred_syn = greedy(force_pt=True, log_probs=logp_syn)
+    hyp = post_process_predictions([pred], labels)
+    hyp_syn = post_process_predictions([pred_syn], labels)
+    margin = lambda lp: np.float32((torch.topk(lp, 2, dim=-1).values[..., 0] - torch.topk(lp, 2, dim=-1).values[..., 1]).min().item())
+    # the real head's weights are in vi12x1_b2_q2_realdec.npz (same checkpoint): not stored twice
+    out = dict(cfg_file="quartznet12x1_vi.yaml", wav_name=wav_name, sample_rate=sr, pcm=pcm, seed=seed, samples16=len(x),
+               seq=seq.numpy(), enc_len=elen.numpy(), logp=logp.numpy(), pred=pred.numpy(),
+               hyp=np.array(hyp, dtype=object).astype("U"), min_margin=margin(logp),
+               logp_syn=logp_syn.numpy(), pred_syn=pred_syn.numpy(), hyp_syn=np.array(hyp_syn, dtype=object).astype("U"),
+               min_margin_syn=margin(logp_syn),
+               mel_sum=np.float64(mel.double().sum().item()), mel_slice=mel[:, ::7, ::11].numpy().copy())
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {wav_name} sr={sr} pcm={len(pcm)} -> mel{tuple(mel.shape)} enc_len={elen.tolist()} "
+          f"min_margin={out['min_margin']:.3e} bytes={os.path.getsize(path)}")
+    print("   hyp =", repr(hyp[0][:80]), " hyp_syn =", repr(hyp_syn[0][:60]), f" min_margin_syn={out['min_margin_syn']:.3e}")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout required (dev container only)"
     install_shims()
@@ -204,3 +259,6 @@ if __name__ == "__main__":
     run_case("vi12x1_b1_tiny", "quartznet12x1_vi.yaml", 1, 4000, 4, False)
     run_case("en12x1_b4_hopmult", "quartznet12x1.yaml", 4, 160 * 150, 5, True)     # third shipped config; L % hop == 0
     run_case("en15x5_b1_10s", "quartznet15x5.yaml", 1, 160000, 6, False)           # one full BASELINE-length clip
+    # BASELINE config 1 plumbing: real recordings of the reference's audio_samples/ (16 kHz broadcast, 8 kHz call centre)
+    run_real_audio_case("real16k_thoisu_5", "V1 1 11 12H00 THOI SU 2019_5.wav", 7)
+    run_real_audio_case("real8k_external_2", "external_1202_771_20191118_093137_1574044304_22681_2.wav", 8)

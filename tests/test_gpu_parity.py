@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -487,3 +487,30 @@ def test_no_writes_outside_the_workspace_and_the_outputs(gpu, model, B, L):
     ref = eng.forward(wav, ln, want_logp=True)             # and the guarded call computed the same thing
     assert torch.equal(bufs["ids"][1].view(torch.int32).view(B, t1)[0, : int(ref["id_len"][0])], ref["ids"][0, : int(ref["id_len"][0])])
     assert torch.equal(bufs["logp"][1].view(torch.float32).view(B, t1, V1), ref["logp"])
+
+
+@pytest.mark.parametrize("name", REAL_AUDIO_CASES)
+def test_real_recordings_through_vietasr(gpu, tmp_path, name):
+    """BASELINE config 1 plumbing on the GPU: the int16 samples of a recording from the reference's audio_samples/ go
+    through ``VietASR.transcribe`` (infer.py:167-171; the 8 kHz file resampled on the device as librosa.load(sr=16000)
+    does on the host, infer.py:200) with checkpoints written in the reference's state_dict format, and come out as the
+    imported reference produced them: the real Vietnamese head (blank on every frame of an untrained encoder's features:
+    empty transcript, log-probs compared) and a seeded head (non-trivial transcript)."""
+    from viet_asr_amd.infer import VietASR
+    g, cfg, pcm, sr, enc_sd, real_head, syn_head = load_real_audio_golden(name)
+    enc_p = str(tmp_path / "JasperEncoder-STEP-1.pt")
+    torch.save({k: torch.as_tensor(v) for k, v in enc_sd.items()}, enc_p)
+    for tag, head, logp_key, hyp_key in (("real", real_head, "logp", "hyp"), ("seeded", syn_head, "logp_syn", "hyp_syn")):
+        dec_p = str(tmp_path / f"JasperDecoderForCTC-{tag}.pt")
+        torch.save({k: torch.as_tensor(v) for k, v in head.items()}, dec_p)
+        asr = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="greedy")
+        assert asr.transcribe(pcm, sample_rate=sr) == str(g[hyp_key][0])
+        # log-probs of the same call through the fused engine
+        x = asr._to_model_rate(pcm, sr)
+        assert len(x) == int(g["samples16"])
+        r = asr._fused_engine().forward(torch.from_numpy(x)[None].to(gpu), torch.tensor([len(x)], device=gpu), want_logp=True)
+        err = float(np.abs(r["logp"].cpu().numpy() - g[logp_key]).max())
+        _record("real_audio", name=name, head=tag, err=err, scale=np.abs(g[logp_key]).max())
+        assert err <= logp_tol(g[logp_key]), (tag, err)
+        assert (r["pred"].cpu().numpy() == g["pred" if tag == "real" else "pred_syn"]).all()
+        assert r["enc_len"].cpu().tolist() == g["enc_len"].tolist()

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden
+from oracle import audio_oracle as AO
 from oracle import quartznet_oracle as O
 
 
@@ -22,6 +23,28 @@ def test_oracle_matches_reference_outputs(name):
     assert np.abs(r["logp"].numpy() - g["logp"]).max() <= 2e-4
     assert (r["pred"].numpy() == g["pred"]).all()
     assert O.ctc_decode_strings(r["pred"], cfg["labels"]) == [str(s) for s in g["hyp"]]
+
+
+@pytest.mark.parametrize("name", REAL_AUDIO_CASES)
+def test_oracle_matches_reference_on_real_recordings(name):
+    """BASELINE config 1 plumbing: a 16 kHz and an 8 kHz recording of the reference's audio_samples/, decoded the way
+    infer.py:200 does (PCM / 2^15; 8 kHz -> 16 kHz by the resampy restatement), one utterance per call."""
+    g, cfg, pcm, sr, enc_sd, real_head, syn_head = load_real_audio_golden(name)
+    x = pcm.astype(np.float32) / 32768.0
+    if sr != 16000:
+        x = AO.resample(x, sr, 16000)
+    assert len(x) == int(g["samples16"])
+    jas = cfg["JasperEncoder"]["jasper"]
+    r = O.forward_all(x[None], np.array([len(x)]), enc_sd, real_head, jas)
+    assert (r["seq"].numpy() == g["seq"]).all() and (r["enc_len"].numpy() == g["enc_len"]).all()
+    assert abs(float(r["mel"].double().sum()) - float(g["mel_sum"])) <= 1e-3
+    assert np.abs(r["mel"][:, ::7, ::11].numpy() - g["mel_slice"]).max() <= 2e-5
+    assert np.abs(r["logp"].numpy() - g["logp"]).max() <= 2e-4
+    assert (r["pred"].numpy() == g["pred"]).all()
+    assert O.ctc_decode_strings(r["pred"], cfg["labels"]) == [str(s) for s in g["hyp"]]
+    r2 = O.forward_all(x[None], np.array([len(x)]), enc_sd, syn_head, jas)
+    assert np.abs(r2["logp"].numpy() - g["logp_syn"]).max() <= 2e-4
+    assert O.ctc_decode_strings(r2["pred"], cfg["labels"]) == [str(s) for s in g["hyp_syn"]] and len(str(g["hyp_syn"][0])) > 20
 
 
 def test_quirks_are_in_the_goldens():
