@@ -143,7 +143,7 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
 
 /* GEMM arithmetic of the 1x1 convolutions of the encoder:
  *   0            v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;
- *   1 (default)  every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
+ *   1            every fp32 operand split exactly into three bf16 terms, six cross products per multiply on
  *                v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error < one fp32 rounding, measured
  *                error against fp64 not larger than mode 0's; 2.67x less matrix time);
  *   2 (opt-in)   REDUCED precision: only the two upper bf16 terms of each operand (16 significant bits) and the
@@ -151,7 +151,7 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
  *                7.4 ms per batch), log-prob error against the reference goldens 5-10x mode 1's (still inside the
  *                2e-3 tolerance there, identical predictions), more accurate than the TF32 convolutions PyTorch
  *                runs by default on the GPUs the reference targets.  Never the default, never the headline number.
- *   3            every fp32 operand scaled by a power of two (exact) and split into TWO fp16 terms (22 significant
+ *   3 (default)  every fp32 operand scaled by a power of two (exact) and split into TWO fp16 terms (22 significant
  *                bits; the scale comes from the maximum |x| of the utterance, which the kernel that produced the tensor
  *                publishes, so a row's result does not depend on the rest of its batch), the three largest cross
  *                products on v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the matrix work of mode 1.  Its
@@ -251,6 +251,16 @@ int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us);
 int64_t vasr_padded_frames(int64_t frames);
 int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
                          int64_t frames, int kernel, float* d_y, vasr_stream stream);
+/* Depthwise convolution on the matrix pipe (Toeplitz form, fp16-split arithmetic; stride 1, the (kernel, dilation) pairs
+ * of the shipped models): vasr_depthwise_mfma_table_size = dwords per channel of the tap table (0 = shape not covered),
+ * vasr_pack_depthwise_taps fills [channels][size] tables and [channels] inverse scales on the host; the bench call runs
+ * one layer on [B][C][vasr_padded_frames(T)] buffers (dilation > 1: "same" padding as jasper.py:60-65).  d_amax as in
+ * vasr_bench_pointwise_f16x2. */
+int vasr_depthwise_mfma_table_size(int kernel, int dilation);
+int vasr_pack_depthwise_taps(const float* h_w, int channels, int kernel, int dilation, uint32_t* h_table, float* h_inv);
+int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const float* d_tap_inv, const int32_t* d_lens,
+                              int batch, int channels, int64_t frames, int kernel, int dilation, float* d_y,
+                              uint32_t* d_amax, int compute_amax, vasr_stream stream);
 /* Host helper: [cout][cin] row-major weights -> the MFMA fragment order the pointwise kernel streams
  * ([m_pad/32][cin/8][64 lanes][4], rows past cout zero); h_out holds m_pad*cin floats. */
 int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out);

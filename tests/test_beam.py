@@ -257,8 +257,10 @@ def test_beam_module_through_the_executor_with_a_batch(gpu):
     e, el = enc(audio_signal=mel, length=ml)
     lp = dec(encoder_output=e)
     hyp = beam(log_probs=lp, log_probs_length=el)
-    sig, lens = synth.audio_batch(3, 32000, 12, ragged=True)
-    lens[:] = [32000, 9000, 20000]
+    sig, lens = synth.audio_batch(3, 31990, 12, ragged=True)      # not a multiple of the hop: T' == enc_len of the longest row
+    lens[:] = [31990, 9000, 20000]
+    for b in range(3):
+        sig[b, lens[b]:] = 0
     dl.set_batch([sig[b, : lens[b]] for b in range(3)])
     lp_v, el_v, hyp_v = [o[0] for o in nf.infer(tensors=[lp, el, hyp], verbose=False)]
     assert isinstance(hyp_v, list) and len(hyp_v) == 3 and all(isinstance(t, str) for t in hyp_v)

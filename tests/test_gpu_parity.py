@@ -318,7 +318,7 @@ print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
                                  {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"},
                                  {"VASR_GEMM": "f16x2", "VASR_DW_PAIR": "0"}, {"VASR_GEMM": "f16x2", "VASR_NO_FUSED_RESIDUAL": "1"},
                                  {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "6"}, {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "3"},
-                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "6"}],
+                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "6"}, {"VASR_GEMM": "f16x2", "VASR_DW_MFMA": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):
     """The kernels a default run does not pick (one-row depthwise, two-GEMM residual, latency GEMM tiles, batch slices
@@ -505,12 +505,76 @@ def test_real_recordings_through_vietasr(gpu, tmp_path, name):
         torch.save({k: torch.as_tensor(v) for k, v in head.items()}, dec_p)
         asr = VietASR("quartznet12x1_vi", enc_p, dec_p, device="gpu", decoder="greedy")
         assert asr.transcribe(pcm, sample_rate=sr) == str(g[hyp_key][0])
-        # log-probs of the same call through the fused engine
+        # log-probs through the fused engine, fed with the signal the fixture's reference run saw: for the 8 kHz file that
+        # is the ORACLE resampler's output (the device resampler agrees with it to 2e-6, checked here; through ~60 layers
+        # that input difference alone moves log-probs of magnitude 120 by several 1e-3, which is not the model's error)
         x = asr._to_model_rate(pcm, sr)
         assert len(x) == int(g["samples16"])
+        if sr != 16000:
+            from oracle import audio_oracle as AO
+            x_ref = AO.resample(pcm.astype(np.float32) / 32768.0, sr, 16000)
+            assert float(np.abs(x - x_ref).max()) <= 2e-6
+            x = x_ref
         r = asr._fused_engine().forward(torch.from_numpy(x)[None].to(gpu), torch.tensor([len(x)], device=gpu), want_logp=True)
         err = float(np.abs(r["logp"].cpu().numpy() - g[logp_key]).max())
         _record("real_audio", name=name, head=tag, err=err, scale=np.abs(g[logp_key]).max())
         assert err <= logp_tol(g[logp_key]), (tag, err)
         assert (r["pred"].cpu().numpy() == g["pred" if tag == "real" else "pred_syn"]).all()
         assert r["enc_len"].cpu().tolist() == g["enc_len"].tolist()
+
+
+@pytest.mark.parametrize("K,dil,C,B,T,ragged", [(33, 1, 256, 5, 501, True), (39, 1, 256, 2, 130, False), (51, 1, 512, 4, 1300, True),
+                                                (63, 1, 512, 3, 516, True), (75, 1, 512, 6, 501, False), (87, 2, 512, 3, 777, True)])
+def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B, T, ragged):
+    """encoder_dw_mfma.hip (Toeplitz form, fp16-split operands) on one isolated layer against a float64 depthwise
+    convolution of the masked input: odd batches (the last utterance pairs with itself), several 512-frame tiles,
+    ragged lengths (input mask, output zeroed past the length), dilation 2; error bounded like the packed-FMA kernel's
+    (2e-6 of the largest output), which is run beside it where it exists (dilation 1); published maxima exact."""
+    import ctypes as C_
+    from viet_asr_amd import _lib
+    L = _lib.lib()
+    ld = int(L.vasr_padded_frames(T))
+    g = torch.Generator().manual_seed(K * 1000 + T)
+    x = torch.randn(B, C, ld, generator=g)
+    x[1 % B] *= 300.0                                          # utterances at different levels
+    x[:, :, T:] = float("nan")                                 # the padding columns must never be consumed
+    x = x.to(gpu)
+    w = (torch.randn(C, K, generator=g) / K ** 0.5).contiguous()
+    w[3] *= 1e-3
+    lens = torch.full((B,), T, dtype=torch.int32)
+    if ragged:
+        lens = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+        lens[0] = T
+    tsz = int(L.vasr_depthwise_mfma_table_size(K, dil))
+    assert tsz > 0
+    tab, inv = torch.empty(C, tsz, dtype=torch.int32), torch.empty(C)
+    _lib.check(L.vasr_pack_depthwise_taps(w.data_ptr(), C, K, dil, tab.data_ptr(), inv.data_ptr()))
+    y = torch.full((B, C, ld), float("nan"), device=gpu)
+    amax = torch.zeros(2, B, 8, dtype=torch.int32, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    lens_d, tab_d, inv_d = lens.to(gpu), tab.to(gpu), inv.to(gpu)
+    _lib.check(L.vasr_bench_depthwise_mfma(x.data_ptr(), tab_d.data_ptr(), inv_d.data_ptr(), lens_d.data_ptr(), B, C, T, K, dil,
+                                           y.data_ptr(), amax.data_ptr(), 1, st))
+    torch.cuda.synchronize()
+    pad = (dil * K) // 2 - 1 if dil > 1 else K // 2
+    t = torch.arange(ld, device=gpu)
+    valid = (t[None, :] < lens_d[:, None].long())[:, None, :]
+    xm = torch.where(valid, torch.nan_to_num(x, nan=0.0), torch.zeros((), device=gpu)).double()
+    ref = torch.nn.functional.conv1d(xm, w.double().to(gpu)[:, None, :], padding=pad, dilation=dil, groups=C)
+    t_out = ref.shape[-1]
+    ref = torch.where(valid[..., :t_out], ref, torch.zeros((), device=gpu, dtype=torch.float64))
+    assert bool(torch.isfinite(y).all()), "a column below the row pitch was not written (or padding was consumed)"
+    for b in range(B):
+        scale = float(ref[b].abs().max())
+        err = float((y[b, :, :t_out].double() - ref[b]).abs().max())
+        _record("dw_mfma", K=K, dil=dil, b=b, err=err, scale=scale)
+        assert err <= 2e-6 * max(scale, 1e-30), (K, dil, b, err, scale)
+        assert float(y[b, :, int(lens[b]):].abs().max() if int(lens[b]) < ld else 0.0) == 0.0        # zero past the length
+    got = amax.view(torch.float32).amax(-1).cpu()
+    assert torch.equal(got[0], xm.abs().amax((1, 2)).float().cpu())
+    assert torch.equal(got[1], y.abs().amax((1, 2)).cpu())
+    if dil == 1:                                              # the packed-FMA kernel on the same layer, for the record
+        y2 = torch.empty(B, C, ld, device=gpu)
+        _lib.check(L.vasr_bench_depthwise(torch.nan_to_num(x, nan=0.0).data_ptr(), w.to(gpu).data_ptr(), lens_d.data_ptr(), B, C, T, K,
+                                          y2.data_ptr(), st))
+        assert float((y2[:, :, :t_out].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())

@@ -1,0 +1,327 @@
+// Depthwise masked 1-D convolution on the MATRIX pipe (gfx950): the Toeplitz form.
+//
+// Same contract as encoder_dw.hip (reference nemo/collections/asr/parts/jasper.py:113-132 mask + conv, :360-373 layer
+// order): masked input, output zeroed past lens_out, every column < ldy written.  The packed-FMA kernels there are
+// VALU-issue bound from K = 51 up (600 v_pk_fma_f32 per wavefront-pass at K = 75: 23 us of pure issue per 512-channel
+// layer against 17-20 us of copy-speed traffic).  Here the taps of ONE channel are laid out as a banded matrix
+//
+//     A[m][j] = w[(j - m - OFF) / DIL]     (0 where that is not a tap)        m = 0..31 output offset inside a window
+//
+// and 32 windows of 32 consecutive outputs -- 16 windows = 512 frames of each of TWO utterances -- are its right-hand
+// sides: B[j][n] = x_n[t_n - PADL + j], eight consecutive samples per lane and k-step, so every B fragment is one
+// aligned 16-byte LDS read.  One v_mfma_f32_32x32x16 then produces 32 x 32 outputs from a 16-sample slice of the windows:
+// a K = 75 kernel spans 31 + 74 + OFF + 1 = 109 window samples = 7 k-steps.  Arithmetic as in the fp16-split GEMM
+// (encoder_pw_split.hip, kF16x2): operands scaled by a power of two (taps per channel, samples per utterance -- from the
+// maxima the producing GEMM published) and split into two fp16 terms, three products per k-step, fp32 accumulation:
+// 21 MFMAs for 1024 outputs x 75 taps instead of 600 packed FMAs, 5 us of matrix time per 512-channel layer.  What is
+// left is the HBM traffic: each sample is read once (16-byte coalesced loads), converted once, and every store
+// instruction writes 1 KB of one row (the accumulators are transposed through LDS).
+//
+//   grid (C / 4, ceil(pairs / kPairsPerWave), ceil(ldy / 512)), block 256 = 4 wavefronts = 4 channels; a wavefront builds
+//   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks kPairsPerWave
+//   utterance pairs with them, the next pair's rows in flight while the current pair is multiplied.
+#include <cstdlib>
+
+#include "vasr_internal.h"
+
+namespace vasr {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+using v2f = __attribute__((ext_vector_type(2))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+constexpr int kTile = 512;          // output frames per utterance and task: 16 windows of 32
+constexpr int kPairsPerWave = 2;
+
+template <int K, int DIL>
+struct TzGeom {
+  static constexpr int PAD = DIL > 1 ? (DIL * K) / 2 - 1 : K / 2;   // get_same_padding (jasper.py:60-65)
+  static constexpr int PADL = (PAD + 7) & ~7;                       // window origin: 8-sample aligned
+  static constexpr int OFF = PADL - PAD;
+  static constexpr int SPAN = 31 + DIL * (K - 1) + OFF + 1;         // window samples one 32-output window touches
+  static constexpr int NS = (SPAN + 15) / 16;                       // k-steps
+  static constexpr int TSZ = (16 * NS + 31 + 3) & ~3;               // tap-table entries: entry i = dense tap i - (31 + OFF)
+  static constexpr int NBLK = 15 + (NS + 1) / 2;                    // 32-sample blocks of one staged row
+  static constexpr int ROWS = 32 * NBLK;                            // samples staged per utterance
+  static constexpr int NLD = (ROWS / 4 + 63) / 64;                  // float4 loads per lane and utterance
+  static constexpr int UROW = (80 * NBLK + 255) & ~255;             // bytes of one plane of one utterance (80 B per block)
+  static constexpr int LDS_DATA = 2 * 2 * UROW;                     // [utterance][plane]
+  static constexpr int LDS_TAB = 4 * TSZ;
+  static constexpr int ORS = 144;                                   // output transposition: bytes per 32-float row
+  static constexpr int LDS_OUT = 32 * ORS;
+  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_OUT;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  // butterfly inside each 16-lane row on DPP (VALU only: a ds_bpermute chain costs six dependent LDS round trips at the
+  // tail of every wavefront -- measured: it DOUBLED the depthwise kernels' time), then the four row maxima through SGPRs
+#define VASR_DPP(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, false))
+  v = max(v, VASR_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
+  v = max(v, VASR_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
+  v = max(v, VASR_DPP(v, 0x141));   // row_half_mirror
+  v = max(v, VASR_DPP(v, 0x140));   // row_mirror: every lane of a row now holds the row's maximum
+#undef VASR_DPP
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ void f16_scale(unsigned amax_bits, float* scale, float* inv) {
+  int e = (int)(amax_bits >> 23);
+  e = e < 16 ? 16 : (e > 254 ? 254 : e);
+  *scale = __uint_as_float((unsigned)(268 - e) << 23);   // 2^(141 - e): the maximum lands in [2^14, 2^15)
+  *inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+__device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int K, int DIL>
+__global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const unsigned* __restrict__ taps,     // [C][TSZ] (hi | lo << 16)
+                                                          const float* __restrict__ tap_inv,     // [C] 1 / tap scale
+                                                          const int32_t* __restrict__ lens_in,
+                                                          const int32_t* __restrict__ lens_out,
+                                                          const unsigned* __restrict__ amax_x,   // [B][kAmaxSlots]
+                                                          int channels, int batch, float* __restrict__ y, int64_t ldy,
+                                                          unsigned* __restrict__ amax_y) {
+  using G = TzGeom<K, DIL>;
+  constexpr int NS = G::NS, NLD = G::NLD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* base = lds_raw + wave * G::LDS_WAVE;
+  unsigned char* dat = base;                                               // [u][plane][UROW]
+  unsigned* tab = reinterpret_cast<unsigned*>(base + G::LDS_DATA);
+  unsigned char* outb = base + G::LDS_DATA + G::LDS_TAB;
+  const int c = blockIdx.x * 4 + wave;
+  const int t_tile = blockIdx.z * kTile;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int n_pairs = (batch + 1) / 2;
+  const int p_lo = blockIdx.y * kPairsPerWave;
+  const int p_hi = min(p_lo + kPairsPerWave, n_pairs);
+
+  // ---- A fragments of this channel: lane (m = l31, kh), step s, element e <- table[31 - m + 16 s + 8 kh + e] ----
+  for (int i = lane; i < G::TSZ; i += 64) tab[i] = taps[(int64_t)c * G::TSZ + i];
+  const float w_inv = tap_inv[c];
+  wave_sync();
+  uint4 ah[NS], al[NS];
+  {
+    const unsigned* tp = tab + 31 - l31 + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      unsigned v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tp[16 * s + e];
+      // (hi | lo << 16) pairs -> four dwords of hi halves, four of lo halves (v_perm_b32 each)
+      ah[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u),
+                         __builtin_amdgcn_perm(v[5], v[4], 0x05040100u), __builtin_amdgcn_perm(v[7], v[6], 0x05040100u));
+      al[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u),
+                         __builtin_amdgcn_perm(v[5], v[4], 0x07060302u), __builtin_amdgcn_perm(v[7], v[6], 0x07060302u));
+    }
+  }
+
+  // ---- staging of one utterance pair: both rows, branch-free, all loads in flight together ----
+  v4f s0[NLD], s1[NLD];
+  auto gload = [&](int p) {
+    const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
+    const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
+    const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int t = t_tile - G::PADL + 4 * (lane + 64 * j);
+      int tc = t < 0 ? 0 : t;
+      tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
+      s0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
+      s1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+    }
+  };
+  // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding (t, PADL multiples of 4)
+  // scale by the utterance's power of two, split into fp16 hi / lo, 8 + 8 bytes into the two planes
+  auto sstore = [&](const v4f (&sv)[NLD], int u, int len, float sx) {
+    unsigned char* ph = dat + (u * 2 + 0) * G::UROW;
+    unsigned char* pl = dat + (u * 2 + 1) * G::UROW;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int tau = 4 * (lane + 64 * j);
+      if (tau < G::ROWS) {
+        const int t = t_tile - G::PADL + tau;
+        const int n = t < 0 ? 0 : len - t;
+        v4f v = sv[j];
+        v.x = n > 0 ? v.x : 0.f;
+        v.y = n > 1 ? v.y : 0.f;
+        v.z = n > 2 ? v.z : 0.f;
+        v.w = n > 3 ? v.w : 0.f;
+        const v2f a = {v.x * sx, v.y * sx}, b = {v.z * sx, v.w * sx};
+        const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+        const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, v2f), f16x2);
+        const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, v2f), f16x2);
+        const int off = 80 * (tau >> 5) + 2 * (tau & 31);
+        *reinterpret_cast<uint2*>(ph + off) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+        *reinterpret_cast<uint2*>(pl + off) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+      }
+    }
+  };
+
+  // B fragments: lane (n' = l31, kh): utterance u = n' / 16, window n = n' % 16 -> samples 32 n + 16 s + 8 kh + e
+  const unsigned char* bb = dat + (l31 >> 4) * 2 * G::UROW + 80 * (l31 & 15) + 16 * kh;
+  unsigned char* orow = outb + l31 * G::ORS + 16 * kh;   // transposition: lane writes row n', floats 8 q + 4 kh .. + 3
+
+  if (p_lo < p_hi) gload(p_lo);
+  for (int p = p_lo; p < p_hi; ++p) {
+    const int b0 = 2 * p;
+    const bool twin = b0 + 1 < batch;
+    const int b1 = twin ? b0 + 1 : b0;
+    unsigned mx0 = 0, mx1 = 0;
+#pragma unroll
+    for (int i = 0; i < kAmaxSlots; ++i) {
+      mx0 = max(mx0, amax_x[b0 * kAmaxSlots + i]);
+      mx1 = max(mx1, amax_x[b1 * kAmaxSlots + i]);
+    }
+    float sx0, sx1, ix0, ix1;
+    f16_scale(mx0, &sx0, &ix0);
+    f16_scale(mx1, &sx1, &ix1);
+    sstore(s0, 0, lens_in[b0], sx0);
+    sstore(s1, 1, lens_in[b1], sx1);
+    if (p + 1 < p_hi) gload(p + 1);   // in flight while this pair is multiplied and stored
+    wave_sync();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int off = 80 * (s >> 1) + 32 * (s & 1);
+      const uint4 bh = *reinterpret_cast<const uint4*>(bb + off);
+      const uint4 bl = *reinterpret_cast<const uint4*>(bb + G::UROW + off);
+      acc = mma(al[s], bh, acc);
+      acc = mma(ah[s], bl, acc);
+      acc = mma(ah[s], bh, acc);
+    }
+
+    // ---- epilogue: unscale, transpose through LDS, zero past lens_out, 1 KB of one row per store instruction ----
+    const float os = w_inv * (l31 < 16 ? ix0 : ix1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f o = {acc[4 * q] * os, acc[4 * q + 1] * os, acc[4 * q + 2] * os, acc[4 * q + 3] * os};
+      *reinterpret_cast<v4f*>(orow + 32 * q) = o;
+    }
+    wave_sync();
+    const int lo0 = lens_out[b0], lo1 = lens_out[b1];
+    unsigned m0 = 0, m1 = 0;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      // flat float index 4 lane + 256 ps -> row (window) lane / 8 + 8 ps, column 4 (lane % 8)
+      const int row = (lane >> 3) + 8 * ps;
+      v4f v = *reinterpret_cast<const v4f*>(outb + row * G::ORS + 16 * (lane & 7));
+      const int u = ps >> 1;
+      const int t = t_tile + 32 * (row & 15) + 4 * (lane & 7);
+      const int nv = (u ? lo1 : lo0) - t;
+      v.x = nv > 0 ? v.x : 0.f;
+      v.y = nv > 1 ? v.y : 0.f;
+      v.z = nv > 2 ? v.z : 0.f;
+      v.w = nv > 3 ? v.w : 0.f;
+      if (t < ldy && (u == 0 || twin)) {
+        *reinterpret_cast<v4f*>(y + ((int64_t)(u ? b1 : b0) * channels + c) * ldy + t) = v;
+        const unsigned m = max(max(abs_bits(v.x), abs_bits(v.y)), max(abs_bits(v.z), abs_bits(v.w)));
+        if (u) m1 = max(m1, m); else m0 = max(m0, m);
+      }
+    }
+    if (amax_y) {
+      m0 = wave_max_u32(m0);
+      m1 = wave_max_u32(m1);
+      if (lane == 0 && m0) atomicMax(amax_y + b0 * kAmaxSlots + (c & (kAmaxSlots - 1)), m0);
+      if (lane == 0 && twin && m1) atomicMax(amax_y + b1 * kAmaxSlots + (c & (kAmaxSlots - 1)), m1);
+    }
+    wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
+  }
+}
+
+template <int K, int DIL>
+int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* tap_inv, const int32_t* li, const int32_t* lo,
+              const unsigned* amax_x, int batch, int channels, float* y, int64_t ldy, unsigned* amax_y, hipStream_t st) {
+  using G = TzGeom<K, DIL>;
+  auto kern = dw_toeplitz_kernel<K, DIL>;
+  constexpr int lds = 4 * G::LDS_WAVE;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) return (int)attr;
+  const int n_pairs = (batch + 1) / 2;
+  dim3 grid(channels / 4, (n_pairs + kPairsPerWave - 1) / kPairsPerWave, (unsigned)((ldy + kTile - 1) / kTile));
+  VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x, channels, batch, y, ldy, amax_y);
+  return 0;
+}
+
+template <int K, int DIL>
+int table_size() { return TzGeom<K, DIL>::TSZ; }
+
+}  // namespace
+
+// (kernel, dilation) pairs with a Toeplitz instantiation; 0 = none
+int depthwise_mfma_table_size(int kernel, int dilation) {
+  if (dilation == 2 && kernel == 87) return table_size<87, 2>();
+  if (dilation != 1) return 0;
+  switch (kernel) {
+    case 33: return table_size<33, 1>();
+    case 39: return table_size<39, 1>();
+    case 51: return table_size<51, 1>();
+    case 63: return table_size<63, 1>();
+    case 75: return table_size<75, 1>();
+    default: return 0;
+  }
+}
+
+// Host: one channel's taps w[K] -> table[tsz] of (hi | lo << 16) fp16 pairs of the scaled DENSE tap sequence
+// (entry i = dense tap i - (31 + OFF), dense tap k * DIL = w[k]); returns 1 / scale.
+float pack_depthwise_taps_f16x2(const float* w, int kernel, int dilation, int tsz, unsigned* table) {
+  const int pad = dilation > 1 ? (dilation * kernel) / 2 - 1 : kernel / 2;
+  const int off = ((pad + 7) & ~7) - pad;
+  float mx = 0.f;
+  for (int k = 0; k < kernel; ++k) mx = fabsf(w[k]) > mx ? fabsf(w[k]) : mx;
+  int e = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+  e = e < 16 ? 16 : (e > 254 ? 254 : e);
+  const float s = __builtin_bit_cast(float, (unsigned)(268 - e) << 23), inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
+  for (int i = 0; i < tsz; ++i) {
+    const int d = i - (31 + off);
+    float v = 0.f;
+    if (d >= 0 && d % dilation == 0 && d / dilation < kernel) v = w[d / dilation] * s;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    table[i] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  }
+  return inv;
+}
+
+// Returns 0, a hipError_t, or -1 when the shape has no Toeplitz instantiation (caller falls back to encoder_dw.hip).
+int launch_depthwise_mfma(const float* x, int64_t ldx, const unsigned* taps, const float* tap_inv, const int32_t* lens_in,
+                          const int32_t* lens_out, const unsigned* amax_x, int batch, int channels, int kernel, int dilation,
+                          float* y, int64_t ldy, unsigned* amax_y, hipStream_t st) {
+  const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= 4 &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  if (!aligned || !taps || !amax_x) return -1;
+#define TZ(KK, DD) return launch_tz<KK, DD>(x, ldx, taps, tap_inv, lens_in, lens_out, amax_x, batch, channels, y, ldy, amax_y, st)
+  if (dilation == 2 && kernel == 87) TZ(87, 2);
+  if (dilation == 1) {
+    switch (kernel) {
+      case 33: TZ(33, 1);
+      case 39: TZ(39, 1);
+      case 51: TZ(51, 1);
+      case 63: TZ(63, 1);
+      case 75: TZ(75, 1);
+      default: break;
+    }
+  }
+#undef TZ
+  return -1;
+}
+
+}  // namespace vasr

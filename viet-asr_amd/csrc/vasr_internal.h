@@ -73,6 +73,16 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
                       const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
                       int pad, float* y, int64_t ldy, hipStream_t st, unsigned int* amax_y = nullptr);
 
+// Toeplitz / MFMA form (encoder_dw_mfma.hip): fp16-split arithmetic, needs the input's maxima table and the per-channel
+// tap tables packed by pack_depthwise_taps_f16x2.  stride 1 only.  Returns 0, a hipError_t, or -1 when the shape has
+// no instantiation (the caller then uses launch_depthwise).
+int depthwise_mfma_table_size(int kernel, int dilation);   // dwords per channel; 0 = shape not covered
+float pack_depthwise_taps_f16x2(const float* w, int kernel, int dilation, int tsz, unsigned int* table);   // returns 1 / scale
+int launch_depthwise_mfma(const float* x, int64_t ldx, const unsigned int* taps, const float* tap_inv,
+                          const int32_t* lens_in, const int32_t* lens_out, const unsigned int* amax_x, int batch,
+                          int channels, int kernel, int dilation, float* y, int64_t ldy, unsigned int* amax_y,
+                          hipStream_t st);
+
 struct PwArgs {
   const float* wt;        // weights in MFMA fragment order (pack_pointwise_weights), M % 128 == 0, K % 32 == 0
   const float* x;         // [B][K][ldx]  (dual source: [B][K1][ldx])

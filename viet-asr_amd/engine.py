@@ -42,7 +42,7 @@ def blocks_from_config(jasper_cfg):
 
 class QuartzNetCTC:
     def __init__(self, model_definition, encoder_state, decoder_state, device="cuda:0", gemm=None):
-        """gemm: None (library default: "bf16x3"), "bf16x3", "fp32" or the reduced-precision opt-in "bf16x2" --
+        """gemm: None (library default: "f16x2"), "f16x2", "bf16x3", "fp32" or the reduced-precision opt-in "bf16x2" --
         see vasr_set_gemm_mode in include/vasr.h."""
         _require_gpu()
         self.device = torch.device(device)
