@@ -255,12 +255,12 @@ int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_le
  * of the shipped models): vasr_depthwise_mfma_table_size = dwords per channel of the tap table (0 = shape not covered),
  * vasr_pack_depthwise_taps fills [channels][size] tables and [channels] inverse scales on the host; the bench call runs
  * one layer on [B][C][vasr_padded_frames(T)] buffers (dilation > 1: "same" padding as jasper.py:60-65).  d_amax as in
- * vasr_bench_pointwise_f16x2. */
+ * vasr_bench_pointwise_f16x2, amax_stride >= 256 and >= channels * ceil(padded frames / 256) * 4. */
 int vasr_depthwise_mfma_table_size(int kernel, int dilation);
 int vasr_pack_depthwise_taps(const float* h_w, int channels, int kernel, int dilation, uint32_t* h_table, float* h_inv);
 int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const float* d_tap_inv, const int32_t* d_lens,
                               int batch, int channels, int64_t frames, int kernel, int dilation, float* d_y,
-                              uint32_t* d_amax, int compute_amax, vasr_stream stream);
+                              uint32_t* d_amax, int amax_stride, vasr_stream stream);
 /* Host helper: [cout][cin] row-major weights -> the MFMA fragment order the pointwise kernel streams
  * ([m_pad/32][cin/8][64 lanes][4], rows past cout zero); h_out holds m_pad*cin floats. */
 int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out);
@@ -274,12 +274,13 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
 int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
 
 /* 2 x fp16 scaled split variants (fragments: [m_pad/32][cin/16][2][64 lanes][8] fp16 bits; *inv_scale = 1 / the power
- * of two the weights were scaled by).  d_amax: [2][batch][8] u32 scratch -- row 0 = max |x| per utterance (computed by
- * the call itself when compute_amax != 0, else taken as given), row 1 receives max |y| per utterance. */
+ * of two the weights were scaled by).  d_amax: [2][batch][amax_stride] u32 scratch (amax_stride >= 256 and >= cout *
+ * frames / 1024) -- table 0 receives per-wavefront maxima of |x| per utterance (the call computes them), table 1 those of
+ * |y|; unused slots are zeroed, so max over the last axis is the utterance's maximum. */
 int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out, float* inv_scale);
 int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
                                const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
-                               uint32_t* d_amax, int compute_amax, vasr_stream stream);
+                               uint32_t* d_amax, int amax_stride, vasr_stream stream);
 
 /* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
 int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);

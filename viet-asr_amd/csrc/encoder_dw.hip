@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "vasr_internal.h"
+#include "vasr_device.h"
 
 namespace vasr {
 
@@ -41,26 +42,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  // butterfly inside each 16-lane row on DPP (VALU only: a ds_bpermute chain costs six dependent LDS round trips at the
-  // tail of every wavefront -- measured: it DOUBLED the depthwise kernels' time), then the four row maxima through SGPRs
-#define VASR_DPP(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, false))
-  v = max(v, VASR_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
-  v = max(v, VASR_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
-  v = max(v, VASR_DPP(v, 0x141));   // row_half_mirror
-  v = max(v, VASR_DPP(v, 0x140));   // row_mirror: every lane of a row now holds the row's maximum
-#undef VASR_DPP
-  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-// One unreturned atomic per wavefront publishes the wavefront's max |y| of utterance b (vasr_internal.h, kAmaxSlots).
-__device__ __forceinline__ void publish_amax(unsigned* amax, int b, int slot, unsigned lane_max, int lane) {
-  const unsigned m = wave_max_u32(lane_max);
-  if (lane == 0 && m) atomicMax(amax + b * kAmaxSlots + (slot & (kAmaxSlots - 1)), m);
 }
 
 // One sub-group of 4 consecutive outputs, taps [K0, K1), on packed-fp32 FMAs.
@@ -105,7 +86,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels,
-                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax) {
+                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
+                                                      int amax_stride) {
   using G = DwGeom<K, DIL>;
   constexpr int NQE = (G::OFF + DIL * (K - 1) + 4 + 1 + 3) / 4;  // +1: the odd-tap pairing reads one sample further
   constexpr int NLD = ((256 + 252 + 4 * NQE) / 4 + 63) / 64;  // staging float4s per lane (3)
@@ -188,7 +170,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
     }
     wave_sync();
   }
-  if (amax) publish_amax(amax, b, c0, row_max, lane);
+  if (amax) amax_publish(amax, amax_stride, b, (blockIdx.x * 4 + wave) * gridDim.z + blockIdx.z, row_max, lane);
 }
 
 // ---- utterance-pair variant ---------------------------------------------------------------------------------------
@@ -235,7 +217,8 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels, int batch,
-                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax) {
+                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
+                                                      int amax_stride) {
   using G = PairGeom<K, DIL>;
   constexpr int NLD = G::NLD;
   __shared__ v4f lds4[4 * G::PHYS];
@@ -381,17 +364,20 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     }
   }
   if (amax) {   // masked outputs only (zeros past lens_out): the maximum over the utterance's valid frames
-    publish_amax(amax, b0, c, m0, lane);
-    if (twin) publish_amax(amax, b1, c, m1, lane);
+    const int slot = c * gridDim.z + blockIdx.z;
+    amax_publish(amax, amax_stride, b0, slot, m0, lane);
+    if (twin) amax_publish(amax, amax_stride, b1, slot, m1, lane);
   }
 }
 
 template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
-                    int channels, float* y, int64_t ldy, hipStream_t st, unsigned* amax) {
+                    int channels, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
   dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
+  if (amax) amax->n = channels * grid.z;
   static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy, amax);
+  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy,
+              amax ? amax->p : nullptr, amax ? amax->stride : 0);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
@@ -402,7 +388,7 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
                                                               const int32_t* __restrict__ lens_out,
                                                               int channels, int K, int stride, int dil, int pad,
                                                               float* __restrict__ y, int64_t ldy,
-                                                              unsigned* __restrict__ amax) {
+                                                              unsigned* __restrict__ amax, int amax_stride) {
   constexpr int kSpan = 2048;
   __shared__ float xs[kSpan];
   const int c = blockIdx.y, b = blockIdx.z;
@@ -438,7 +424,8 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
     }
   }
   if (t < ldy) y[row * ldy + t] = acc;
-  if (amax) publish_amax(amax, b, c, abs_bits(acc), threadIdx.x & 63);   // whole wavefronts reach this point
+  if (amax)   // whole wavefronts reach this point
+    amax_publish(amax, amax_stride, b, (c * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), abs_bits(acc), threadIdx.x & 63);
 }
 
 // MaskedConv1d.get_seq_len chain (jasper.py:108-111): lens.to(long) for the mask, then
@@ -484,72 +471,99 @@ __global__ __launch_bounds__(256) void repad_kernel(const float* __restrict__ sr
 
 template <int K>
 void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
-                 int channels, float* y, int64_t ldy, hipStream_t st, unsigned* amax) {
+                 int channels, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
+  unsigned* ap = amax ? amax->p : nullptr;
+  const int as = amax ? amax->stride : 0;
   static const int rows_env = getenv("VASR_DW_ROWS") ? atoi(getenv("VASR_DW_ROWS")) : 1;
   if (channels % 32 == 0 && rows_env == 8) {
     dim3 grid(channels / 32, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
+    if (amax) amax->n = grid.x * 4 * tiles;
+    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
   } else if (channels % 8 == 0 && rows_env == 2) {
     dim3 grid(channels / 8, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
+    if (amax) amax->n = grid.x * 4 * tiles;
+    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
   } else if (channels % 16 == 0 && rows_env != 1) {
     dim3 grid(channels / 16, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
+    if (amax) amax->n = grid.x * 4 * tiles;
+    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
   } else {
     dim3 grid(channels / 4, batch, tiles);
-    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, amax);
+    if (amax) amax->n = grid.x * 4 * tiles;
+    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
   }
 }
 
 }  // namespace
 
-void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
-                      const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
-                      int pad, float* y, int64_t ldy, hipStream_t st, unsigned int* amax) {
+int depthwise_amax_slots(int channels, int64_t ldy) {
+  // the generic kernel (any shape) uses channels * ceil(ldy / 256) * 4 slots, the tiled ones channels * ceil(ldy / 512)
+  return channels * (int)((ldy + 255) / 256) * 4;
+}
+
+static int launch_depthwise_impl(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
+                                 const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
+                                 int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax);
+
+int launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
+                     const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
+                     int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
+  if (amax && amax->stride < depthwise_amax_slots(channels, ldy)) return -1;   // table too small for this shape
+  return launch_depthwise_impl(x, ldx, frames_in, w, lens_in, lens_out, batch, channels, kernel, stride, dilation, pad, y,
+                               ldy, st, amax);
+}
+
+static int launch_depthwise_impl(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
+                                 const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
+                                 int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
   static const bool pair = !(getenv("VASR_DW_PAIR") && atoi(getenv("VASR_DW_PAIR")) == 0);
   if (pair && aligned && stride == 1) {
     if (dilation == 2 && kernel == 87 && pad == 86)
-      return launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      { launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
     if (dilation == 1 && pad == kernel / 2) {
       switch (kernel) {
-        case 33: return launch_dw_pair<33, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-        case 39: return launch_dw_pair<39, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-        case 51: return launch_dw_pair<51, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-        case 63: return launch_dw_pair<63, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-        case 75: return launch_dw_pair<75, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+        case 33: { launch_dw_pair<33, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+        case 39: { launch_dw_pair<39, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+        case 51: { launch_dw_pair<51, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+        case 63: { launch_dw_pair<63, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+        case 75: { launch_dw_pair<75, 1>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
         default: break;
       }
     }
   }
   if (aligned && stride == 1 && dilation == 2 && kernel == 87 && pad == 86) {
     dim3 grid(channels / 4, batch, (unsigned)((ldy + kTile - 1) / kTile));
+    if (amax) amax->n = grid.x * 4 * grid.z;
     VASR_LAUNCH((dw_conv_kernel<87, 1, 2>), grid, dim3(256), 0, st, x, ldx, w, lens_in, lens_out, channels,
-                       y, ldy, amax);
-    return;
+                       y, ldy, amax ? amax->p : nullptr, amax ? amax->stride : 0);
+    return 0;
   }
   const bool fast = aligned && stride == 1 && dilation == 1 && pad == kernel / 2;
   if (fast) {
     switch (kernel) {
-      case 33: return launch_dw_t<33>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-      case 39: return launch_dw_t<39>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-      case 51: return launch_dw_t<51>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-      case 63: return launch_dw_t<63>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
-      case 75: return launch_dw_t<75>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax);
+      case 33: { launch_dw_t<33>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+      case 39: { launch_dw_t<39>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+      case 51: { launch_dw_t<51>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+      case 63: { launch_dw_t<63>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
+      case 75: { launch_dw_t<75>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }
       default: break;
     }
   }
   dim3 grid((unsigned)((ldy + 255) / 256), channels, batch);
+  if (amax) amax->n = channels * grid.x * 4;
   VASR_LAUNCH(dw_conv_generic_kernel, grid, dim3(256), 0, st, x, ldx, frames_in, w, lens_in, lens_out,
-                     channels, kernel, stride, dilation, pad, y, ldy, amax);
+                     channels, kernel, stride, dilation, pad, y, ldy, amax ? amax->p : nullptr, amax ? amax->stride : 0);
+  return 0;
 }
 
 // max |x| per utterance over columns < lens[b] (or < frames) of x[b][rows][ld]: for tensors whose producer does not
 // publish its maxima (port tensors, the fp32 GEMM kernel)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t ld, int rows, int frames,
-                                                   const int32_t* __restrict__ lens, unsigned* __restrict__ amax) {
+                                                   const int32_t* __restrict__ lens, unsigned* __restrict__ amax,
+                                                   int amax_stride) {
   const int b = blockIdx.y;
   int n = lens ? lens[b] : frames;
   n = n < frames ? n : frames;
@@ -558,12 +572,14 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     const float* xr = x + ((int64_t)b * rows + r) * ld;
     for (int t = threadIdx.x; t < n; t += blockDim.x) m = max(m, abs_bits(xr[t]));
   }
-  publish_amax(amax, b, blockIdx.x + (threadIdx.x >> 6), m, threadIdx.x & 63);
+  amax_publish(amax, amax_stride, b, blockIdx.x * 4 + (threadIdx.x >> 6), m, threadIdx.x & 63);
 }
 
-void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, unsigned int* amax,
+void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, AmaxTab* amax,
                  hipStream_t st) {
-  hipLaunchKernelGGL(amax_kernel, dim3(rows < 64 ? rows : 64, batch), dim3(256), 0, st, x, ld, rows, frames, lens, amax);
+  const int gx = rows < 64 ? rows : 64;
+  amax->n = gx * 4;
+  hipLaunchKernelGGL(amax_kernel, dim3(gx, batch), dim3(256), 0, st, x, ld, rows, frames, lens, amax->p, amax->stride);
 }
 
 void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,

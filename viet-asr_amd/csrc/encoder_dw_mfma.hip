@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "vasr_internal.h"
+#include "vasr_device.h"
 
 namespace vasr {
 
@@ -61,26 +62,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  // butterfly inside each 16-lane row on DPP (VALU only: a ds_bpermute chain costs six dependent LDS round trips at the
-  // tail of every wavefront -- measured: it DOUBLED the depthwise kernels' time), then the four row maxima through SGPRs
-#define VASR_DPP(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, false))
-  v = max(v, VASR_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
-  v = max(v, VASR_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
-  v = max(v, VASR_DPP(v, 0x141));   // row_half_mirror
-  v = max(v, VASR_DPP(v, 0x140));   // row_mirror: every lane of a row now holds the row's maximum
-#undef VASR_DPP
-  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-__device__ __forceinline__ void f16_scale(unsigned amax_bits, float* scale, float* inv) {
-  int e = (int)(amax_bits >> 23);
-  e = e < 16 ? 16 : (e > 254 ? 254 : e);
-  *scale = __uint_as_float((unsigned)(268 - e) << 23);   // 2^(141 - e): the maximum lands in [2^14, 2^15)
-  *inv = __uint_as_float((unsigned)(e - 14) << 23);
-}
 __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -91,9 +72,10 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
                                                           const float* __restrict__ tap_inv,     // [C] 1 / tap scale
                                                           const int32_t* __restrict__ lens_in,
                                                           const int32_t* __restrict__ lens_out,
-                                                          const unsigned* __restrict__ amax_x,   // [B][kAmaxSlots]
-                                                          int channels, int batch, float* __restrict__ y, int64_t ldy,
-                                                          unsigned* __restrict__ amax_y) {
+                                                          const unsigned* __restrict__ amax_x, int amax_x_stride,
+                                                          int amax_x_n, int channels, int batch,
+                                                          float* __restrict__ y, int64_t ldy,
+                                                          unsigned* __restrict__ amax_y, int amax_y_stride) {
   using G = TzGeom<K, DIL>;
   constexpr int NS = G::NS, NLD = G::NLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -181,12 +163,8 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const int b0 = 2 * p;
     const bool twin = b0 + 1 < batch;
     const int b1 = twin ? b0 + 1 : b0;
-    unsigned mx0 = 0, mx1 = 0;
-#pragma unroll
-    for (int i = 0; i < kAmaxSlots; ++i) {
-      mx0 = max(mx0, amax_x[b0 * kAmaxSlots + i]);
-      mx1 = max(mx1, amax_x[b1 * kAmaxSlots + i]);
-    }
+    const unsigned mx0 = amax_read(amax_x, amax_x_stride, amax_x_n, b0, lane);
+    const unsigned mx1 = amax_read(amax_x, amax_x_stride, amax_x_n, b1, lane);
     float sx0, sx1, ix0, ix1;
     f16_scale(mx0, &sx0, &ix0);
     f16_scale(mx1, &sx1, &ix1);
@@ -237,10 +215,9 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       }
     }
     if (amax_y) {
-      m0 = wave_max_u32(m0);
-      m1 = wave_max_u32(m1);
-      if (lane == 0 && m0) atomicMax(amax_y + b0 * kAmaxSlots + (c & (kAmaxSlots - 1)), m0);
-      if (lane == 0 && twin && m1) atomicMax(amax_y + b1 * kAmaxSlots + (c & (kAmaxSlots - 1)), m1);
+      const int slot = c * gridDim.z + blockIdx.z;
+      amax_publish(amax_y, amax_y_stride, b0, slot, m0, lane);
+      if (twin) amax_publish(amax_y, amax_y_stride, b1, slot, m1, lane);
     }
     wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
   }
@@ -248,7 +225,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
 
 template <int K, int DIL>
 int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* tap_inv, const int32_t* li, const int32_t* lo,
-              const unsigned* amax_x, int batch, int channels, float* y, int64_t ldy, unsigned* amax_y, hipStream_t st) {
+              AmaxTab amax_x, int batch, int channels, float* y, int64_t ldy, AmaxTab* amax_y, hipStream_t st) {
   using G = TzGeom<K, DIL>;
   auto kern = dw_toeplitz_kernel<K, DIL>;
   constexpr int lds = 4 * G::LDS_WAVE;
@@ -257,7 +234,12 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
   if (attr != hipSuccess) return (int)attr;
   const int n_pairs = (batch + 1) / 2;
   dim3 grid(channels / 4, (n_pairs + kPairsPerWave - 1) / kPairsPerWave, (unsigned)((ldy + kTile - 1) / kTile));
-  VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x, channels, batch, y, ldy, amax_y);
+  if (amax_y) {
+    amax_y->n = channels * grid.z;
+    if (amax_y->n > amax_y->stride) return -1;
+  }
+  VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x.p, amax_x.stride, amax_x.n, channels, batch,
+              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0);
   return 0;
 }
 
@@ -303,11 +285,11 @@ float pack_depthwise_taps_f16x2(const float* w, int kernel, int dilation, int ts
 
 // Returns 0, a hipError_t, or -1 when the shape has no Toeplitz instantiation (caller falls back to encoder_dw.hip).
 int launch_depthwise_mfma(const float* x, int64_t ldx, const unsigned* taps, const float* tap_inv, const int32_t* lens_in,
-                          const int32_t* lens_out, const unsigned* amax_x, int batch, int channels, int kernel, int dilation,
-                          float* y, int64_t ldy, unsigned* amax_y, hipStream_t st) {
+                          const int32_t* lens_out, AmaxTab amax_x, int batch, int channels, int kernel, int dilation,
+                          float* y, int64_t ldy, AmaxTab* amax_y, hipStream_t st) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= 4 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-  if (!aligned || !taps || !amax_x) return -1;
+  if (!aligned || !taps || !amax_x.p || amax_x.n <= 0) return -1;
 #define TZ(KK, DD) return launch_tz<KK, DD>(x, ldx, taps, tap_inv, lens_in, lens_out, amax_x, batch, channels, y, ldy, amax_y, st)
   if (dilation == 2 && kernel == 87) TZ(87, 2);
   if (dilation == 1) {

@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include "vasr_internal.h"
+#include "vasr_device.h"
 #include <type_traits>
 
 namespace vasr {
@@ -109,29 +110,6 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  // butterfly inside each 16-lane row on DPP (VALU only: a ds_bpermute chain costs six dependent LDS round trips at the
-  // tail of every wavefront -- measured: it DOUBLED the depthwise kernels' time), then the four row maxima through SGPRs
-#define VASR_DPP(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, false))
-  v = max(v, VASR_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
-  v = max(v, VASR_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
-  v = max(v, VASR_DPP(v, 0x141));   // row_half_mirror
-  v = max(v, VASR_DPP(v, 0x140));   // row_mirror: every lane of a row now holds the row's maximum
-#undef VASR_DPP
-  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, d));
-}
-
-// power-of-two scale (and its inverse) that puts a maximum of magnitude `amax_bits` (fp32 bit pattern of |x|) into
-// [2^14, 2^15): the fp16 planes then have 18 octaves of full 22-bit precision below the maximum
-__device__ __forceinline__ void f16_scale(unsigned amax_bits, float* scale, float* inv) {
-  int e = (int)(amax_bits >> 23);
-  e = e < 16 ? 16 : (e > 254 ? 254 : e);
-  *scale = __uint_as_float((unsigned)(268 - e) << 23);   // 2^(141 - e)
-  *inv = __uint_as_float((unsigned)(e - 14) << 23);      // 2^(e - 141)
-}
-
 // NW wavefronts stacked along M, each TM m-tiles (32 rows) x all TN n-tiles (32 columns each):
 // workgroup tile (32*TM*NW) x (32*TN).
 template <int NW, int TM, int TN, int ARITH>
@@ -179,19 +157,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   // kF16x2: one power-of-two scale per utterance from the maxima the producers of x (and x2) published
   float xs = 1.f, out_scale = 1.f;
   if constexpr (ARITH == kF16x2) {
-    unsigned mx = 0;
-#pragma unroll
-    for (int i = 0; i < kAmaxSlots; ++i) {
-      const unsigned v = a.amax_x[b * kAmaxSlots + i];
-      mx = v > mx ? v : mx;
-    }
-    if (DUAL) {
-#pragma unroll
-      for (int i = 0; i < kAmaxSlots; ++i) {
-        const unsigned v = a.amax_x2[b * kAmaxSlots + i];
-        mx = v > mx ? v : mx;
-      }
-    }
+    // every wavefront reduces the producers' per-wavefront maxima of its utterance itself (a few KB from L2, no barrier)
+    unsigned mx = amax_read(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane);
+    if (DUAL) mx = max(mx, amax_read(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane));
     float inv;
     f16_scale(mx, &xs, &inv);
     out_scale = inv * a.w_inv_scale;
@@ -344,7 +312,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
   // max |y| over the utterance's VALID output frames, for the split of the next kF16x2 consumer of y
-  const int ylen = a.amax_y ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
+  const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
   unsigned ymax = 0;
   auto track = [&](float v, int t) {
     const unsigned u = __float_as_uint(v) & 0x7fffffffu;
@@ -385,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
           if (RES) v += *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m) * a.ldr + t);
           if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
           *reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t) = v;
-          if (a.amax_y) {
+          if (a.amax_y.p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) track(v[e], t + e);
           }
@@ -413,25 +381,27 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
             if (a.relu & 1) v = fmaxf(v, 0.f);
             if (full || (t < a.store_cols && m < a.m_store)) {
               a.y[((int64_t)b * a.m_store + m) * a.ldy + t] = v;
-              if (a.amax_y) track(v, t);
+              if (a.amax_y.p) track(v, t);
             }
           }
         }
       }
     }
   }
-  if (a.amax_y) {
-    ymax = wave_max_u32(ymax);
-    if (lane == 0 && ymax) atomicMax(a.amax_y + b * kAmaxSlots + ((mb * NW + wave) & (kAmaxSlots - 1)), ymax);
-  }
+  if (a.amax_y.p) amax_publish(a.amax_y.p, a.amax_y.stride, b, (mb * tiles_t + nt % tiles_t) * NW + wave, ymax, lane);
 }
 
 template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, int ARITH>
-int launch_k(const PwArgs& a, hipStream_t st) {
+int launch_k(const PwArgs& a, hipStream_t st, int* amax_n) {
   using G = Geom<NW, TM, TN, ARITH>;
   const int blocks_m = a.M / G::BM;
   const int tiles_t = (int)((a.ldx + G::BN - 1) / G::BN);
   const int n_blocks = blocks_m * tiles_t * a.batch;
+  if (a.amax_y.p) {
+    const int n = blocks_m * tiles_t * NW;
+    if (n > a.amax_y.stride) return (int)hipErrorInvalidValue;
+    if (amax_n) *amax_n = n;
+  }
   auto kern = pw_gemm_split_kernel<NW, TM, TN, MASK, RES, DUAL, ARITH>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
@@ -441,21 +411,21 @@ int launch_k(const PwArgs& a, hipStream_t st) {
 }
 
 template <int NW, int TM, int TN, int ARITH>
-int launch_l(const PwArgs& a, hipStream_t st) {
+int launch_l(const PwArgs& a, hipStream_t st, int* amax_n) {
   const bool mask = a.lens != nullptr, res = a.res != nullptr, dual = a.x2 != nullptr;
-  if (dual) return launch_k<NW, TM, TN, false, false, true, ARITH>(a, st);
-  if (mask && res) return launch_k<NW, TM, TN, true, true, false, ARITH>(a, st);
-  if (mask) return launch_k<NW, TM, TN, true, false, false, ARITH>(a, st);
-  if (res) return launch_k<NW, TM, TN, false, true, false, ARITH>(a, st);
-  return launch_k<NW, TM, TN, false, false, false, ARITH>(a, st);
+  if (dual) return launch_k<NW, TM, TN, false, false, true, ARITH>(a, st, amax_n);
+  if (mask && res) return launch_k<NW, TM, TN, true, true, false, ARITH>(a, st, amax_n);
+  if (mask) return launch_k<NW, TM, TN, true, false, false, ARITH>(a, st, amax_n);
+  if (res) return launch_k<NW, TM, TN, false, true, false, ARITH>(a, st, amax_n);
+  return launch_k<NW, TM, TN, false, false, false, ARITH>(a, st, amax_n);
 }
 
 template <int NW, int TM, int TN>
-int launch_t(const PwArgs& a, int arith, hipStream_t st) {
+int launch_t(const PwArgs& a, int arith, hipStream_t st, int* amax_n) {
   switch (arith) {
-    case kF16x2: return launch_l<NW, TM, TN, kF16x2>(a, st);
-    case kBf16x2: return launch_l<NW, TM, TN, kBf16x2>(a, st);
-    default: return launch_l<NW, TM, TN, kBf16x3>(a, st);
+    case kF16x2: return launch_l<NW, TM, TN, kF16x2>(a, st, amax_n);
+    case kBf16x2: return launch_l<NW, TM, TN, kBf16x2>(a, st, amax_n);
+    default: return launch_l<NW, TM, TN, kBf16x3>(a, st, amax_n);
   }
 }
 
@@ -474,7 +444,10 @@ bool pointwise_split_supported(int M, int K, int K1) {
 
 // arith: 0 = 3 x bf16 (six products), 1 = 2 x bf16 (three products, reduced), 2 = 2 x fp16 scaled (three products; needs
 // a.amax_x (and a.amax_x2 for a dual source), a.w_inv_scale and the fp16 weight pack).  Returns 0 or a hipError_t.
-int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st) {
+// the smallest tile (64 x 32 on two wavefronts) uses the most slots: (M / 64) * (ld / 32) * 2
+int pointwise_amax_slots(int M, int64_t ld) { return (int)((int64_t)(M / 64) * ((ld + 31) / 32) * 2); }
+
+int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* amax_n) {
   static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..6 pins a tile shape
   static const bool no_skip = getenv("VASR_NO_TILE_SKIP") && atoi(getenv("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
   PwArgs a = args;
@@ -493,12 +466,12 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st) {
   // (for the 512-channel layers both 256 x 64 and 512 x 64 measured slower than 512 x 128: 88-91 / 94-97 vs 86 us)
   if (force >= 1 && force <= 6 && a.M % rows[force] == 0) tile = force;
   switch (tile) {
-    case 1: return launch_t<8, 2, 4>(a, arith, st);
-    case 2: return launch_t<8, 1, 4>(a, arith, st);
-    case 5: return launch_t<8, 1, 2>(a, arith, st);
-    case 6: return launch_t<4, 2, 4>(a, arith, st);   // 256 x 128 on four wavefronts: two workgroups per CU (kF16x2: 64 KB of LDS each)
-    case 3: return launch_t<4, 1, 2>(a, arith, st);
-    default: return launch_t<2, 1, 1>(a, arith, st);
+    case 1: return launch_t<8, 2, 4>(a, arith, st, amax_n);
+    case 2: return launch_t<8, 1, 4>(a, arith, st, amax_n);
+    case 5: return launch_t<8, 1, 2>(a, arith, st, amax_n);
+    case 6: return launch_t<4, 2, 4>(a, arith, st, amax_n);   // 256 x 128 on four wavefronts: two workgroups per CU (kF16x2: 64 KB of LDS each)
+    case 3: return launch_t<4, 1, 2>(a, arith, st, amax_n);
+    default: return launch_t<2, 1, 1>(a, arith, st, amax_n);
   }
 }
 

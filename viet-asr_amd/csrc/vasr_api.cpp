@@ -89,6 +89,7 @@ int parse_gemm_mode(const char* s) {
   return kDefaultGemmMode;
 }
 constexpr int kMaxSlices = 4;
+constexpr int kAmaxTabs = 4;
 
 }  // namespace
 
@@ -402,6 +403,7 @@ int build_decoder(vasr_handle* h) {
 struct WsPlan {
   size_t lens_tab, amax, seq, melp, bufP, bufQ, bufD, bufR, bufS, encp, logits, pred, total;
   int64_t T, Tp0, T1, Tp1;
+  int amax_stride;   // slots per utterance of one maxima table (kAmaxTabs tables: [tab][B][amax_stride] u32)
 };
 
 int64_t enc_frames(const vasr_handle* h, int64_t t) {
@@ -425,8 +427,21 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
   p.lens_tab = take((h->steps.size() + 1) * (size_t)batch * 4);
-  // maxima table of the fp16-split GEMMs: one [B][kAmaxSlots] row per conv of the length chain (+ 1 spare)
-  p.amax = take((h->steps.size() + 2) * (size_t)batch * kAmaxSlots * 4);
+  // maxima tables of the fp16-split arithmetic (AmaxTab): in flight at any time are the block input's, the current
+  // kernel's input's and its output's -- kAmaxTabs = 4 rotate.  Capacity: the most slots any producer may use.
+  p.amax_stride = 64;
+  if (h->has_encoder) {
+    int64_t t = T;
+    for (const Block& B : h->blocks)
+      for (const SubBlock& S : B.subs) {
+        if (S.separable) {
+          t = conv_out_frames(t, S.dw);
+          p.amax_stride = std::max(p.amax_stride, depthwise_amax_slots(S.dw.cin, pad_frames(t)));
+        }
+        p.amax_stride = std::max(p.amax_stride, pointwise_amax_slots(S.pw.m_pad, pad_frames(t)));
+      }
+  }
+  p.amax = take((size_t)kAmaxTabs * batch * p.amax_stride * 4);
   p.seq = take((size_t)batch * 8);
   p.melp = take((size_t)batch * (h->has_encoder ? h->feat_in : 64) * p.Tp0 * 4);
   const size_t mid = (size_t)batch * h->c_mid_max * std::max(tp_mid, p.Tp1) * 4;
@@ -489,14 +504,14 @@ static int run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStrea
     int arith = h->gemm_mode == 2 ? 1 : 0;
     a.wt = reinterpret_cast<const float*>(W.d_w3);
     // fp16 split: needs the maxima of every source this GEMM reads; a source without them keeps the 3 x bf16 form
-    if (h->gemm_mode == 3 && W.d_w16 && a.amax_x && (!a.x2 || a.amax_x2)) {
+    if (h->gemm_mode == 3 && W.d_w16 && a.amax_x.p && (!a.x2 || a.amax_x2.p)) {
       arith = 2;
       a.wt = reinterpret_cast<const float*>(W.d_w16);
       a.w_inv_scale = W.w16_inv;
     }
-    const int e = launch_pointwise_split(a, arith, st);
+    const int e = launch_pointwise_split(a, arith, st, &a.amax_y.n);
     if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
-    return a.amax_y != nullptr ? 1 : 0;
+    return a.amax_y.p != nullptr ? 1 : 0;
   }
   a.wt = W.d_w;
   launch_pointwise(a, st);
@@ -516,19 +531,22 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
   int64_t cur_ld = x_ld, cur_T = T;
   // fp16-split GEMMs: maxima rows, indexed by the length-chain step of the conv that produced the tensor
   const bool want_amax = h->gemm_mode == 3;
-  unsigned int* amax_tab = reinterpret_cast<unsigned int*>(ws + p.amax);
-  auto amax_row = [&](int step) { return amax_tab + (size_t)step * batch * kAmaxSlots; };
-  if (want_amax) {
-    hipError_t e = hipMemsetAsync(amax_tab, 0, (h->steps.size() + 2) * (size_t)batch * kAmaxSlots * 4, st);
-    if (e != hipSuccess) return fail(VASR_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-  }
-  const unsigned int* cur_amax = nullptr;   // maxima of `cur` over each utterance's valid frames (nullptr: not known)
+  unsigned int* amax_base = reinterpret_cast<unsigned int*>(ws + p.amax);
+  AmaxTab cur_amax{}, blk_amax{};   // maxima of `cur` / of the block input over each utterance's valid frames (p == nullptr: not known)
+  // a table that neither the block input's nor the current tensor's maxima live in (the third candidate is always free)
+  auto free_tab = [&](const AmaxTab& also_busy) {
+    for (int i = 0; i < kAmaxTabs; ++i) {
+      unsigned int* q = amax_base + (size_t)i * batch * p.amax_stride;
+      if (q != cur_amax.p && q != blk_amax.p && q != also_busy.p) return AmaxTab{q, p.amax_stride, 0};
+    }
+    return AmaxTab{};
+  };
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     Block& B = h->blocks[i];
     const bool last_block = i + 1 == h->blocks.size();
     const float* blk_in = cur;
     const int64_t blk_ld = cur_ld;
-    const unsigned int* blk_amax = cur_amax;
+    blk_amax = cur_amax;
     // scratch buffers that are not the block input (the fused residual reads it until the block's last GEMM):
     // sub-block outputs ping-pong between the first two, an unfused residual result takes the third
     float* free3[3];
@@ -553,22 +571,22 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       const float* gx = cur;
       int64_t gx_ld = cur_ld, g_T = cur_T;
       const int32_t* g_lens = nullptr;
-      const unsigned int* gx_amax = cur_amax;
+      AmaxTab gx_amax = cur_amax;
       if (S.separable) {
         const int64_t t_out = conv_out_frames(cur_T, S.dw);
         const int64_t ld_out = pad_frames(t_out);
         ProfScope ps(h, kProfDepthwise, st);
-        unsigned int* am = want_amax ? amax_row(S.dw.step) : nullptr;
+        AmaxTab am = want_amax ? free_tab(AmaxTab{}) : AmaxTab{};
         // fp16-split mode with the input's maxima at hand: the Toeplitz form on the matrix pipe; else packed FMAs
         static const bool dw_mfma = !(getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) == 0);
         int e = -1;
-        if (want_amax && dw_mfma && cur_amax && S.dw.d_taps)
+        if (want_amax && dw_mfma && cur_amax.p && S.dw.d_taps)
           e = launch_depthwise_mfma(cur, cur_ld, S.dw.d_taps, S.dw.d_tap_inv, lens(S.dw.step), lens(S.dw.step + 1), cur_amax,
-                                    batch, S.dw.cin, S.dw.kernel, S.dw.dilation, D, ld_out, am, st);
+                                    batch, S.dw.cin, S.dw.kernel, S.dw.dilation, D, ld_out, am.p ? &am : nullptr, st);
         if (e > 0) return fail(VASR_ERR_HIP, "depthwise (MFMA): %s", hipGetErrorString((hipError_t)e));
-        if (e < 0)
-          launch_depthwise(cur, cur_ld, (int)cur_T, S.dw.d_w, lens(S.dw.step), lens(S.dw.step + 1), batch, S.dw.cin,
-                           S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st, am);
+        if (e < 0 && launch_depthwise(cur, cur_ld, (int)cur_T, S.dw.d_w, lens(S.dw.step), lens(S.dw.step + 1), batch, S.dw.cin,
+                                      S.dw.kernel, S.dw.stride, S.dw.dilation, S.dw.pad, D, ld_out, st, am.p ? &am : nullptr))
+          return fail(VASR_ERR_WORKSPACE, "maxima table too small for depthwise layer of block %zu", i);
         gx = D; gx_ld = ld_out; g_T = t_out; gx_amax = am;
       } else {
         g_lens = lens(S.pw.step);  // block input is unmasked: predicate inside the GEMM
@@ -591,9 +609,9 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       if ((a.res || fuse) && blk_ld != gx_ld)
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
       a.amax_x = gx_amax;
-      a.amax_x2 = fuse ? blk_amax : nullptr;
+      a.amax_x2 = fuse ? blk_amax : AmaxTab{};
       // this GEMM's output is masked at lens(S.pw.step + 1) by whatever reads it next
-      if (want_amax && !(last_block && last_sub)) { a.amax_y = amax_row(S.pw.step); a.lens_y = lens(S.pw.step + 1); }
+      if (want_amax && !(last_block && last_sub)) { a.amax_y = free_tab(gx_amax); a.lens_y = lens(S.pw.step + 1); }
       int published;
       {
         ProfScope ps(h, kProfPointwise, st);
@@ -601,7 +619,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       }
       if (published < 0) return VASR_ERR_HIP;
       cur = dst; cur_ld = dst_ld; cur_T = g_T;
-      cur_amax = published ? a.amax_y : nullptr;
+      cur_amax = published ? a.amax_y : AmaxTab{};
     }
   }
   return check_launch("encoder");
@@ -1090,8 +1108,8 @@ int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_le
                          int64_t frames, int kernel, float* d_y, vasr_stream stream) {
   if (!d_x || !d_w || !d_lens || !d_y) return fail(VASR_ERR_INVALID, "bad argument");
   const int64_t ld = pad_frames(frames);
-  launch_depthwise(d_x, ld, (int)frames, d_w, d_lens, d_lens, batch, channels, kernel, 1, 1, kernel / 2, d_y, ld,
-                   static_cast<hipStream_t>(stream));
+  (void)launch_depthwise(d_x, ld, (int)frames, d_w, d_lens, d_lens, batch, channels, kernel, 1, 1, kernel / 2, d_y, ld,
+                         static_cast<hipStream_t>(stream));
   return check_launch("bench_depthwise");
 }
 
@@ -1107,18 +1125,22 @@ int vasr_pack_depthwise_taps(const float* h_w, int channels, int kernel, int dil
 
 int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const float* d_tap_inv, const int32_t* d_lens,
                               int batch, int channels, int64_t frames, int kernel, int dilation, float* d_y,
-                              uint32_t* d_amax, int compute_amax, vasr_stream stream) {
+                              uint32_t* d_amax, int amax_stride, vasr_stream stream) {
   if (!d_x || !d_taps || !d_tap_inv || !d_lens || !d_y || !d_amax) return fail(VASR_ERR_INVALID, "bad argument");
   const int64_t ld = pad_frames(frames);
+  if (amax_stride < 256 || amax_stride < depthwise_amax_slots(channels, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (compute_amax) {
-    HIP_TRY(hipMemsetAsync(d_amax, 0, (size_t)2 * batch * kAmaxSlots * 4, st));
-    launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, d_amax, st);
-  }
-  const int e = launch_depthwise_mfma(d_x, ld, d_taps, d_tap_inv, d_lens, d_lens, d_amax, batch, channels, kernel, dilation,
-                                      d_y, ld, d_amax + (size_t)batch * kAmaxSlots, st);
+  AmaxTab ax{d_amax, amax_stride, 0}, ay{d_amax + (size_t)batch * amax_stride, amax_stride, 0};
+  launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
+  const int e = launch_depthwise_mfma(d_x, ld, d_taps, d_tap_inv, d_lens, d_lens, ax, batch, channels, kernel, dilation,
+                                      d_y, ld, &ay, st);
   if (e > 0) return fail(VASR_ERR_HIP, "depthwise (MFMA): %s", hipGetErrorString((hipError_t)e));
   if (e < 0) return fail(VASR_ERR_UNSUPPORTED, "no Toeplitz instantiation for kernel %d dilation %d", kernel, dilation);
+  if (ay.n < amax_stride)
+    HIP_TRY(hipMemset2DAsync(d_amax + (size_t)batch * amax_stride + ay.n, (size_t)amax_stride * 4, 0,
+                             (size_t)(amax_stride - ay.n) * 4, batch, st));
+  if (ax.n < amax_stride)
+    HIP_TRY(hipMemset2DAsync(d_amax + ax.n, (size_t)amax_stride * 4, 0, (size_t)(amax_stride - ax.n) * 4, batch, st));
   return check_launch("bench_depthwise_mfma");
 }
 
@@ -1162,23 +1184,29 @@ int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, ui
 
 int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
                                const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
-                               uint32_t* d_amax, int compute_amax, vasr_stream stream) {
+                               uint32_t* d_amax, int amax_stride, vasr_stream stream) {
   if (!d_x || !d_w16 || !d_scale || !d_shift || !d_y || !d_amax || !pointwise_split_supported(cout, cin, 0))
     return fail(VASR_ERR_INVALID, "bad argument");
   const int64_t ld = pad_frames(frames);
+  if (amax_stride < 256 || amax_stride < pointwise_amax_slots(cout, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (compute_amax) {
-    HIP_TRY(hipMemsetAsync(d_amax, 0, (size_t)2 * batch * kAmaxSlots * 4, st));
-    launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, d_amax, st);
-  }
+  AmaxTab ax{d_amax, amax_stride, 0};
+  launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, &ax, st);
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w16); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
   a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
-  a.amax_x = d_amax; a.w_inv_scale = w_inv_scale;
-  a.amax_y = d_amax + (size_t)batch * kAmaxSlots;   // second row: maxima of y (what the next layer would read)
-  const int e = launch_pointwise_split(a, 2, st);
+  a.amax_x = ax; a.w_inv_scale = w_inv_scale;
+  a.amax_y = AmaxTab{d_amax + (size_t)batch * amax_stride, amax_stride, 0};   // second table: maxima of y
+  int n_y = 0;
+  const int e = launch_pointwise_split(a, 2, st, &n_y);
   if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
+  // slots past the ones the launch used read as zero for the caller
+  if (n_y < amax_stride)
+    HIP_TRY(hipMemset2DAsync(d_amax + (size_t)batch * amax_stride + n_y, (size_t)amax_stride * 4, 0,
+                             (size_t)(amax_stride - n_y) * 4, batch, st));
+  if (ax.n < amax_stride)
+    HIP_TRY(hipMemset2DAsync(d_amax + ax.n, (size_t)amax_stride * 4, 0, (size_t)(amax_stride - ax.n) * 4, batch, st));
   return check_launch("bench_pointwise_f16x2");
 }
 

@@ -31,11 +31,16 @@ extern thread_local LaunchProbe g_probe;
 constexpr int kTimeTile = 128;
 static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
 
-// Per-utterance maxima for the fp16-split GEMM (encoder_pw_split.hip, kF16x2): every kernel that produces a tensor a
-// 1x1 convolution will read publishes max |y| over the utterance's valid frames as an fp32 bit pattern, spread over
-// kAmaxSlots words per utterance (one unreturned atomicMax per wavefront; the slots keep same-address atomics apart).
-// The table [tensor][B][kAmaxSlots] lives in the workspace and is zeroed once per encoder pass.
-constexpr int kAmaxSlots = 8;
+// Per-utterance maxima for the fp16-split arithmetic (encoder_pw_split.hip kF16x2, encoder_dw_mfma.hip): every kernel
+// that produces a tensor such a kernel will read publishes max |y| over each utterance's valid frames, one plain store
+// per wavefront into its own slot: p[b * stride + slot], slot < n (n = what the producing launch used, set by its
+// launcher; stride = capacity per utterance).  The consumer's wavefronts reduce the n slots themselves (vasr_device.h).
+// No atomics, no memset: every slot below n is written by exactly one wavefront of the producing launch.
+struct AmaxTab {
+  unsigned int* p = nullptr;
+  int stride = 0;
+  int n = 0;
+};
 
 // ---- front end (frontend.hip) ----
 struct FrontendTables {
@@ -68,10 +73,12 @@ void launch_repad(const float* src, int64_t src_ld, int rows, int frames, float*
 
 // depthwise masked conv: y[b][c][t] = sum_k w[c][k] * xm[b][c][t*stride + k*dil - pad],
 // xm = x where t < lens_in[b] else 0; y forced to 0 for t >= lens_out[b]; all columns < ldy written.
-// amax_y: [batch][kAmaxSlots] maxima table of the output (nullptr = not wanted)
-void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
-                      const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
-                      int pad, float* y, int64_t ldy, hipStream_t st, unsigned int* amax_y = nullptr);
+// amax_y: maxima table of the output (nullptr = not wanted); the call sets amax_y->n (and fails if that exceeds the stride)
+int launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w, const int32_t* lens_in,
+                     const int32_t* lens_out, int batch, int channels, int kernel, int stride, int dilation,
+                     int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax_y = nullptr);
+// slots launch_depthwise may use per utterance for that shape, whatever kernel it picks
+int depthwise_amax_slots(int channels, int64_t ldy);
 
 // Toeplitz / MFMA form (encoder_dw_mfma.hip): fp16-split arithmetic, needs the input's maxima table and the per-channel
 // tap tables packed by pack_depthwise_taps_f16x2.  stride 1 only.  Returns 0, a hipError_t, or -1 when the shape has
@@ -79,8 +86,8 @@ void launch_depthwise(const float* x, int64_t ldx, int frames_in, const float* w
 int depthwise_mfma_table_size(int kernel, int dilation);   // dwords per channel; 0 = shape not covered
 float pack_depthwise_taps_f16x2(const float* w, int kernel, int dilation, int tsz, unsigned int* table);   // returns 1 / scale
 int launch_depthwise_mfma(const float* x, int64_t ldx, const unsigned int* taps, const float* tap_inv,
-                          const int32_t* lens_in, const int32_t* lens_out, const unsigned int* amax_x, int batch,
-                          int channels, int kernel, int dilation, float* y, int64_t ldy, unsigned int* amax_y,
+                          const int32_t* lens_in, const int32_t* lens_out, AmaxTab amax_x, int batch,
+                          int channels, int kernel, int dilation, float* y, int64_t ldy, AmaxTab* amax_y,
                           hipStream_t st);
 
 struct PwArgs {
@@ -105,12 +112,13 @@ struct PwArgs {
   // the masks guarantee it), so a time tile that starts there skips its K loop: its outputs are relu(shift (+ res)).
   // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
   const int32_t* zero_from;
-  // kF16x2 only: maxima tables of x / x2 (inputs, [B][kAmaxSlots]) and 1 / (weight scale) of the fp16 pack
-  const unsigned int* amax_x;
-  const unsigned int* amax_x2;
+  // kF16x2 only: maxima tables of x / x2 (inputs) and 1 / (weight scale) of the fp16 pack
+  AmaxTab amax_x;
+  AmaxTab amax_x2;
   float w_inv_scale;
-  // any split arithmetic: publish max |y| over columns < lens_y[b] (nullptr: < frames) into amax_y (nullptr = off)
-  unsigned int* amax_y;
+  // any split arithmetic: publish max |y| over columns < lens_y[b] (nullptr: < frames) into amax_y (p == nullptr: off);
+  // launch_pointwise_split reports the slots it used through its amax_n argument
+  AmaxTab amax_y;
   const int32_t* lens_y;
 };
 void launch_pointwise(const PwArgs& a, hipStream_t st);
@@ -122,11 +130,12 @@ void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float*
 // (three; needs amax_x / w_inv_scale and the fp16 pack).  Returns 0 or a hipError_t.
 bool pointwise_split_supported(int M, int K, int K1);
 double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st);
-int launch_pointwise_split(const PwArgs& a, int arith, hipStream_t st);
+int launch_pointwise_split(const PwArgs& a, int arith, hipStream_t st, int* amax_n = nullptr);
+int pointwise_amax_slots(int M, int64_t ld);   // slots per utterance the split kernel may use for that shape
 void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out);
 float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad, unsigned short* out);   // returns 1 / scale
-// [batch][kAmaxSlots] maxima of a contiguous-per-utterance tensor x[b][rows][ld] over columns < lens[b] (or < frames)
-void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, unsigned int* amax,
+// maxima of a contiguous-per-utterance tensor x[b][rows][ld] over columns < lens[b] (or < frames); sets amax->n (<= 256)
+void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, AmaxTab* amax,
                  hipStream_t st);
 
 // ---- CTC head / decode (decode.hip) ----
