@@ -36,7 +36,11 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int kTile = 512;          // output frames per utterance and task: 16 windows of 32
-constexpr int kPairsPerWave = 2;
+// Utterance pairs one wavefront walks with its channel's A fragments.  8: a 64-utterance batch gives 2048 wavefronts per
+// 512-channel layer, all resident at once (8 per CU), each streaming its pairs with the next TWO pairs' rows in flight --
+// with 2 (and one pair ahead) the kernel took 30 us per layer whatever K: every wavefront paid the fragment set-up and an
+// exposed HBM round trip per pair.
+constexpr int kPairsPerWave = 8;   // upper bound; the launch passes the count in use (VASR_DW_PPW, default below)
 
 template <int K, int DIL>
 struct TzGeom {
@@ -54,7 +58,8 @@ struct TzGeom {
   static constexpr int LDS_TAB = 4 * TSZ;
   static constexpr int ORS = 144;                                   // output transposition: bytes per 32-float row
   static constexpr int LDS_OUT = 32 * ORS;
-  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_OUT;
+  static constexpr int LDS_SCL = 16 * kPairsPerWave;                // (scale, 1 / scale) of the 2 * kPairsPerWave utterances
+  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_OUT + LDS_SCL;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
                                                           const unsigned* __restrict__ amax_x, int amax_x_stride,
                                                           int amax_x_n, int channels, int batch,
                                                           float* __restrict__ y, int64_t ldy,
-                                                          unsigned* __restrict__ amax_y, int amax_y_stride) {
+                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int ppw) {
   using G = TzGeom<K, DIL>;
   constexpr int NS = G::NS, NLD = G::NLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -85,36 +90,21 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   unsigned char* dat = base;                                               // [u][plane][UROW]
   unsigned* tab = reinterpret_cast<unsigned*>(base + G::LDS_DATA);
   unsigned char* outb = base + G::LDS_DATA + G::LDS_TAB;
+  float4* scl = reinterpret_cast<float4*>(base + G::LDS_DATA + G::LDS_TAB + G::LDS_OUT);
   const int c = blockIdx.x * 4 + wave;
   const int t_tile = blockIdx.z * kTile;
   const int l31 = lane & 31, kh = lane >> 5;
   const int n_pairs = (batch + 1) / 2;
-  const int p_lo = blockIdx.y * kPairsPerWave;
-  const int p_hi = min(p_lo + kPairsPerWave, n_pairs);
+  const int p_lo = blockIdx.y * ppw;
+  const int p_hi = min(p_lo + ppw, n_pairs);
 
-  // ---- A fragments of this channel: lane (m = l31, kh), step s, element e <- table[31 - m + 16 s + 8 kh + e] ----
-  for (int i = lane; i < G::TSZ; i += 64) tab[i] = taps[(int64_t)c * G::TSZ + i];
+  uint4 ah[NS], al[NS];   // A fragments of this channel (built below, after the first rows have been requested)
   const float w_inv = tap_inv[c];
-  wave_sync();
-  uint4 ah[NS], al[NS];
-  {
-    const unsigned* tp = tab + 31 - l31 + 8 * kh;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      unsigned v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tp[16 * s + e];
-      // (hi | lo << 16) pairs -> four dwords of hi halves, four of lo halves (v_perm_b32 each)
-      ah[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u),
-                         __builtin_amdgcn_perm(v[5], v[4], 0x05040100u), __builtin_amdgcn_perm(v[7], v[6], 0x05040100u));
-      al[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u),
-                         __builtin_amdgcn_perm(v[5], v[4], 0x07060302u), __builtin_amdgcn_perm(v[7], v[6], 0x07060302u));
-    }
-  }
 
-  // ---- staging of one utterance pair: both rows, branch-free, all loads in flight together ----
-  v4f s0[NLD], s1[NLD];
-  auto gload = [&](int p) {
+  // ---- staging of one utterance pair: both rows, branch-free, all loads in flight together; the producers' maxima of
+  //      the two utterances ride along (one word per lane and 64 slots) ----
+  struct Stage { v4f r0[NLD], r1[NLD]; };
+  auto gload = [&](int p, Stage& sg) {
     const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
     const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
     const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
@@ -123,8 +113,8 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       const int t = t_tile - G::PADL + 4 * (lane + 64 * j);
       int tc = t < 0 ? 0 : t;
       tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
-      s0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
-      s1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+      sg.r0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
+      sg.r1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
     }
   };
   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding (t, PADL multiples of 4)
@@ -158,19 +148,16 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   const unsigned char* bb = dat + (l31 >> 4) * 2 * G::UROW + 80 * (l31 & 15) + 16 * kh;
   unsigned char* orow = outb + l31 * G::ORS + 16 * kh;   // transposition: lane writes row n', floats 8 q + 4 kh .. + 3
 
-  if (p_lo < p_hi) gload(p_lo);
-  for (int p = p_lo; p < p_hi; ++p) {
+  // One pair: convert the staged rows, refill the stage with the pair two ahead, multiply, store.
+  auto do_pair = [&](int p, Stage& sg) {
     const int b0 = 2 * p;
     const bool twin = b0 + 1 < batch;
     const int b1 = twin ? b0 + 1 : b0;
-    const unsigned mx0 = amax_read(amax_x, amax_x_stride, amax_x_n, b0, lane);
-    const unsigned mx1 = amax_read(amax_x, amax_x_stride, amax_x_n, b1, lane);
-    float sx0, sx1, ix0, ix1;
-    f16_scale(mx0, &sx0, &ix0);
-    f16_scale(mx1, &sx1, &ix1);
-    sstore(s0, 0, lens_in[b0], sx0);
-    sstore(s1, 1, lens_in[b1], sx1);
-    if (p + 1 < p_hi) gload(p + 1);   // in flight while this pair is multiplied and stored
+    const float4 sc = scl[p - p_lo];   // (scale, 1 / scale) of both utterances: LDS broadcast, no vector-memory wait
+    const float sx0 = sc.x, ix0 = sc.y, sx1 = sc.z, ix1 = sc.w;
+    sstore(sg.r0, 0, lens_in[b0], sx0);
+    sstore(sg.r1, 1, lens_in[b1], sx1);
+    if (p + 2 < p_hi) gload(p + 2, sg);   // in flight while this pair and the next are multiplied and stored
     wave_sync();
 
     f32x16 acc;
@@ -220,6 +207,52 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       if (twin) amax_publish(amax_y, amax_y_stride, b1, slot, m1, lane);
     }
     wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
+  };
+
+  Stage sa, sb;
+  if (p_lo < p_hi) gload(p_lo, sa);
+  if (p_lo + 1 < p_hi) gload(p_lo + 1, sb);
+
+  // tap table of this channel: requested now, so that it shares the flight of the rows and of the maxima below
+  constexpr int NTL = (G::TSZ + 63) / 64;
+  unsigned tapv[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) tapv[j] = lane + 64 * j < G::TSZ ? taps[(int64_t)c * G::TSZ + lane + 64 * j] : 0u;
+
+  // ---- scales of every utterance this wavefront will touch, once: the reduction of the producers' slots is a loop of
+  //      dependent loads (a wait for ALL outstanding vector-memory operations -- inside the pair loop it would also wait
+  //      for the rows just requested two pairs ahead); here it overlaps the first rows' flight ----
+  for (int p = p_lo; p < p_hi; ++p) {
+    const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
+    float4 sc;
+    f16_scale(amax_read(amax_x, amax_x_stride, amax_x_n, b0, lane), &sc.x, &sc.y);
+    f16_scale(amax_read(amax_x, amax_x_stride, amax_x_n, b1, lane), &sc.z, &sc.w);
+    if (lane == 0) scl[p - p_lo] = sc;
+  }
+
+  // ---- A fragments of this channel: lane (m = l31, kh), step s, element e <- table[31 - m + 16 s + 8 kh + e] ----
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+    if (lane + 64 * j < G::TSZ) tab[lane + 64 * j] = tapv[j];
+  wave_sync();
+  {
+    const unsigned* tp = tab + 31 - l31 + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      unsigned v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tp[16 * s + e];
+      // (hi | lo << 16) pairs -> four dwords of hi halves, four of lo halves (v_perm_b32 each)
+      ah[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u),
+                         __builtin_amdgcn_perm(v[5], v[4], 0x05040100u), __builtin_amdgcn_perm(v[7], v[6], 0x05040100u));
+      al[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u),
+                         __builtin_amdgcn_perm(v[5], v[4], 0x07060302u), __builtin_amdgcn_perm(v[7], v[6], 0x07060302u));
+    }
+  }
+
+  for (int p = p_lo; p < p_hi; p += 2) {
+    do_pair(p, sa);
+    if (p + 1 < p_hi) do_pair(p + 1, sb);
   }
 }
 
@@ -233,13 +266,15 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
   const int n_pairs = (batch + 1) / 2;
-  dim3 grid(channels / 4, (n_pairs + kPairsPerWave - 1) / kPairsPerWave, (unsigned)((ldy + kTile - 1) / kTile));
+  static const int ppw_env = getenv("VASR_DW_PPW") ? atoi(getenv("VASR_DW_PPW")) : 0;
+  const int ppw = ppw_env >= 1 && ppw_env <= kPairsPerWave ? ppw_env : 8;
+  dim3 grid(channels / 4, (n_pairs + ppw - 1) / ppw, (unsigned)((ldy + kTile - 1) / kTile));
   if (amax_y) {
     amax_y->n = channels * grid.z;
     if (amax_y->n > amax_y->stride) return -1;
   }
   VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x.p, amax_x.stride, amax_x.n, channels, batch,
-              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0);
+              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0, ppw);
   return 0;
 }
 
