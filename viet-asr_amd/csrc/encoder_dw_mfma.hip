@@ -122,10 +122,15 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   auto sstore = [&](const v4f (&sv)[NLD], int u, int len, float sx) {
     unsigned char* ph = dat + (u * 2 + 0) * G::UROW;
     unsigned char* pl = dat + (u * 2 + 1) * G::UROW;
+    // Branch-free: a lane past the staged row (last slab only) writes into the 16 spare bytes behind it.  With a
+    // lane-dependent branch here the compiler cannot tell, where the paths merge, whether the skipped lanes' loads have
+    // been waited for, and drains the vector-memory counter (vmcnt(0)) before the next prefetch overwrites the stage
+    // registers -- which also waits for the OTHER stage's rows and for the previous pair's stores: no prefetch at all.
+    static_assert(G::UROW - 80 * G::NBLK >= 16, "no spare bytes behind the staged row");
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int tau = 4 * (lane + 64 * j);
-      if (tau < G::ROWS) {
+      {
         const int t = t_tile - G::PADL + tau;
         const int n = t < 0 ? 0 : len - t;
         v4f v = sv[j];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
         const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
         const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, v2f), f16x2);
         const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, v2f), f16x2);
-        const int off = 80 * (tau >> 5) + 2 * (tau & 31);
+        const int off = tau < G::ROWS ? 80 * (tau >> 5) + 2 * (tau & 31) : 80 * G::NBLK + 8 * (lane & 1);
         *reinterpret_cast<uint2*>(ph + off) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
         *reinterpret_cast<uint2*>(pl + off) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
       }
@@ -157,7 +162,10 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const float sx0 = sc.x, ix0 = sc.y, sx1 = sc.z, ix1 = sc.w;
     sstore(sg.r0, 0, lens_in[b0], sx0);
     sstore(sg.r1, 1, lens_in[b1], sx1);
-    if (p + 2 < p_hi) gload(p + 2, sg);   // in flight while this pair and the next are multiplied and stored
+    // The pair two ahead, in flight while this pair and the next are multiplied and stored.  UNCONDITIONAL (past the end
+    // the last pair is requested again): s_waitcnt vmcnt counts outstanding operations, so the compiler can only leave
+    // the other stage's rows in flight if it knows how many younger loads there are on every path.
+    gload(min(p + 2, p_hi - 1), sg);
     wave_sync();
 
     f32x16 acc;
@@ -209,9 +217,10 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
   };
 
+  if (p_lo >= p_hi) return;
   Stage sa, sb;
-  if (p_lo < p_hi) gload(p_lo, sa);
-  if (p_lo + 1 < p_hi) gload(p_lo + 1, sb);
+  gload(p_lo, sa);
+  gload(min(p_lo + 1, p_hi - 1), sb);
 
   // tap table of this channel: requested now, so that it shares the flight of the rows and of the maxima below
   constexpr int NTL = (G::TSZ + 63) / 64;
@@ -250,9 +259,11 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     }
   }
 
+  // two pairs per trip, both always executed (same reason as above); with an odd count the last pair is simply computed
+  // and stored twice
   for (int p = p_lo; p < p_hi; p += 2) {
     do_pair(p, sa);
-    if (p + 1 < p_hi) do_pair(p + 1, sb);
+    do_pair(min(p + 1, p_hi - 1), sb);
   }
 }
 
