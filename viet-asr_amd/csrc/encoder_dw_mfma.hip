@@ -35,6 +35,9 @@ using v2f = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
+#ifndef VASR_TZ_ABLATE
+#define VASR_TZ_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no MFMAs, 2 no global stores, 4 no conversion /
+#endif                     // LDS staging, 8 no row loads, 16 no transposition epilogue at all, 32 no maxima publishing
 constexpr int kTile = 512;          // output frames per utterance and task: 16 windows of 32
 // Utterance pairs one wavefront walks with its channel's A fragments.  8: a 64-utterance batch gives 2048 wavefronts per
 // 512-channel layer, all resident at once (8 per CU), each streaming its pairs with the next TWO pairs' rows in flight --
@@ -113,8 +116,13 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       const int t = t_tile - G::PADL + 4 * (lane + 64 * j);
       int tc = t < 0 ? 0 : t;
       tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
-      sg.r0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
-      sg.r1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+      if (!(VASR_TZ_ABLATE & 8)) {
+        sg.r0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
+        sg.r1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+      } else {
+        sg.r0[j] = v4f{(float)tc, 1.f, 2.f, 3.f};
+        sg.r1[j] = v4f{(float)tc, 3.f, 2.f, 1.f};
+      }
     }
   };
   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding (t, PADL multiples of 4)
@@ -160,8 +168,12 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const int b1 = twin ? b0 + 1 : b0;
     const float4 sc = scl[p - p_lo];   // (scale, 1 / scale) of both utterances: LDS broadcast, no vector-memory wait
     const float sx0 = sc.x, ix0 = sc.y, sx1 = sc.z, ix1 = sc.w;
-    sstore(sg.r0, 0, lens_in[b0], sx0);
-    sstore(sg.r1, 1, lens_in[b1], sx1);
+    if (!(VASR_TZ_ABLATE & 4)) {
+      sstore(sg.r0, 0, lens_in[b0], sx0);
+      sstore(sg.r1, 1, lens_in[b1], sx1);
+    } else {
+      asm volatile("" :: "v"(sg.r0[0]), "v"(sg.r1[NLD - 1]));
+    }
     // The pair two ahead, in flight while this pair and the next are multiplied and stored.  UNCONDITIONAL (past the end
     // the last pair is requested again): s_waitcnt vmcnt counts outstanding operations, so the compiler can only leave
     // the other stage's rows in flight if it knows how many younger loads there are on every path.
@@ -176,9 +188,13 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       const int off = 80 * (s >> 1) + 32 * (s & 1);
       const uint4 bh = *reinterpret_cast<const uint4*>(bb + off);
       const uint4 bl = *reinterpret_cast<const uint4*>(bb + G::UROW + off);
-      acc = mma(al[s], bh, acc);
-      acc = mma(ah[s], bl, acc);
-      acc = mma(ah[s], bh, acc);
+      if (!(VASR_TZ_ABLATE & 1)) {
+        acc = mma(al[s], bh, acc);
+        acc = mma(ah[s], bl, acc);
+        acc = mma(ah[s], bh, acc);
+      } else {
+        acc[s & 15] += __uint_as_float(bh.x ^ bl.y ^ al[s].x ^ ah[s].y);
+      }
     }
 
     // ---- epilogue: unscale, transpose through LDS, zero past lens_out, 1 KB of one row per store instruction ----
@@ -203,13 +219,13 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       v.y = nv > 1 ? v.y : 0.f;
       v.z = nv > 2 ? v.z : 0.f;
       v.w = nv > 3 ? v.w : 0.f;
-      if (t < ldy && (u == 0 || twin)) {
+      if (t < ldy && (u == 0 || twin) && (!(VASR_TZ_ABLATE & 2) || v.x == 12345.678f)) {
         *reinterpret_cast<v4f*>(y + ((int64_t)(u ? b1 : b0) * channels + c) * ldy + t) = v;
         const unsigned m = max(max(abs_bits(v.x), abs_bits(v.y)), max(abs_bits(v.z), abs_bits(v.w)));
         if (u) m1 = max(m1, m); else m0 = max(m0, m);
       }
     }
-    if (amax_y) {
+    if (amax_y && !(VASR_TZ_ABLATE & 32)) {
       const int slot = c * gridDim.z + blockIdx.z;
       amax_publish(amax_y, amax_y_stride, b0, slot, m0, lane);
       if (twin) amax_publish(amax_y, amax_y_stride, b1, slot, m1, lane);

@@ -578,7 +578,9 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         ProfScope ps(h, kProfDepthwise, st);
         AmaxTab am = want_amax ? free_tab(AmaxTab{}) : AmaxTab{};
         // fp16-split mode with the input's maxima at hand: the Toeplitz form on the matrix pipe; else packed FMAs
-        static const bool dw_mfma = !(getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) == 0);
+        // (opt-in while it is slower than the packed-FMA kernels: 33 vs 30 us per K = 75 layer, 25 vs 13 at K = 33 -- it
+        // issues ~500 instructions per utterance pair and is instruction-issue bound)
+        static const bool dw_mfma = getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) != 0;
         int e = -1;
         if (want_amax && dw_mfma && cur_amax.p && S.dw.d_taps)
           e = launch_depthwise_mfma(cur, cur_ld, S.dw.d_taps, S.dw.d_tap_inv, lens(S.dw.step), lens(S.dw.step + 1), cur_amax,
@@ -1131,11 +1133,17 @@ int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const fl
   if (amax_stride < 256 || amax_stride < depthwise_amax_slots(channels, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   AmaxTab ax{d_amax, amax_stride, 0}, ay{d_amax + (size_t)batch * amax_stride, amax_stride, 0};
-  launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
+  // timing runs (tools/bench_dw.py): VASR_BENCH_KEEP_AMAX=1 reuses the input maxima a previous call left in d_amax
+  static const bool keep = getenv("VASR_BENCH_KEEP_AMAX") != nullptr;
+  static int kept_n = 0;
+  if (keep && kept_n) ax.n = kept_n;
+  else launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
+  kept_n = ax.n;
   const int e = launch_depthwise_mfma(d_x, ld, d_taps, d_tap_inv, d_lens, d_lens, ax, batch, channels, kernel, dilation,
                                       d_y, ld, &ay, st);
   if (e > 0) return fail(VASR_ERR_HIP, "depthwise (MFMA): %s", hipGetErrorString((hipError_t)e));
   if (e < 0) return fail(VASR_ERR_UNSUPPORTED, "no Toeplitz instantiation for kernel %d dilation %d", kernel, dilation);
+  if (keep) return check_launch("bench_depthwise_mfma");
   if (ay.n < amax_stride)
     HIP_TRY(hipMemset2DAsync(d_amax + (size_t)batch * amax_stride + ay.n, (size_t)amax_stride * 4, 0,
                              (size_t)(amax_stride - ay.n) * 4, batch, st));
