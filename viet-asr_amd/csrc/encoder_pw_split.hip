@@ -181,53 +181,109 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: patch p of this thread -> (8 consecutive k rows, one column)
-  // gload only issues the loads (no use of the values, so nothing waits on HBM there); the MaskedConv1d mask is
-  // applied when the chunk is converted, in sstore(buf, k0) with the same k0.
-  float rb[PPT][8];
-  auto gload = [&](int k0) {
+  // ---- activation staging ----
+  // A thread owns PPT patches of a chunk: patch = 8 consecutive k rows x one column (one 16-byte B-fragment slot per
+  // plane).  With PPT even it loads them as float2 (two adjacent columns per row: 512 contiguous bytes per wavefront and
+  // row, half the load instructions of the dword form).  The rows of chunk c + 1 are CONVERTED during chunk c, a
+  // quarter per k-step, out of registers that were requested during chunk c - 1: an HBM round trip has a whole chunk
+  // (~5 us) to complete, and the conversion's VALU work is spread under the MFMAs instead of sitting behind the last
+  // one (measured on the one-chunk-ahead form: staging cost 7.5 of 42 us of a 512-channel layer's main loop).
+#ifndef VASR_PW_PAIRS
+#define VASR_PW_PAIRS 1
+#endif
+#ifndef VASR_PW_CVT_AT
+#define VASR_PW_CVT_AT 0   // n-tile of a k-step after which the step's share of the conversion is placed
+#endif
+  constexpr bool PAIRS = VASR_PW_PAIRS && PPT % 2 == 0;
+  auto patch_of = [&](int p, int& n, int& g) {
+    if constexpr (PAIRS) {
+      const int pi = tid + (p >> 1) * NT;
+      n = 2 * (pi % (BN / 2)) + (p & 1);
+      g = pi / (BN / 2);
+    } else {
+      const int idx = tid + p * NT;
+      n = idx % BN;
+      g = idx / BN;
+    }
+  };
+  // requests chunk k0 (clamped to the last chunk: past the end the last chunk is simply requested again, so that the
+  // number of loads in flight is the same on every path -- s_waitcnt vmcnt counts, it does not name)
+  float rr[2][PPT][8];   // two stage register sets: one being converted, one being filled (indexed by compile-time constants only)
+  auto gload = [&](int k0, auto set_tag) {
+    auto& r = rr[decltype(set_tag)::value];
+    k0 = k0 < a.K - BKC ? k0 : a.K - BKC;
     const bool second = DUAL && k0 >= K1;
     const float* __restrict__ base = second ? xb2 + (int64_t)(k0 - K1) * a.ldx2 : xb + (int64_t)k0 * a.ldx;
     const int64_t ld = second ? a.ldx2 : a.ldx;
+    if constexpr (PAIRS) {
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
-      const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
+      for (int q = 0; q < PPT / 2; ++q) {
+        int n, g;
+        patch_of(2 * q, n, g);
+        const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb[p][e] = src[(int64_t)e * ld];
+        for (int e = 0; e < 8; ++e) {
+          const v2f v = *reinterpret_cast<const v2f*>(src + (int64_t)e * ld);
+          r[2 * q][e] = v.x;
+          r[2 * q + 1][e] = v.y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        int n, g;
+        patch_of(p, n, g);
+        const float* __restrict__ src = base + (int64_t)(8 * g) * ld + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[p][e] = src[(int64_t)e * ld];
+      }
     }
   };
-  auto sstore = [&](int buf, int k0) {
+  // converts half h (k rows 4 h .. 4 h + 3) of patch p of chunk k0 and stores it into LDS buffer `buf`
+  auto sstore_half = [&](int buf, int k0, auto set_tag, int p, int h) {
+    const auto& r = rr[decltype(set_tag)::value];
     const bool second = DUAL && k0 >= K1;
     const int ml = second ? len2 : len;
     const bool masked = second || MASK;
+    int n, g;
+    patch_of(p, n, g);
+    const bool keep = !masked || (t0 + n < ml);   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118)
+    float x[4];
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int idx = tid + p * NT, n = idx % BN, g = idx / BN;
-      const bool keep = !masked || (t0 + n < ml);   // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118)
-      if (masked) {
+    for (int e = 0; e < 4; ++e) x[e] = keep ? r[p][4 * h + e] : 0.f;
+    if constexpr (ARITH == kF16x2) {
+      unsigned hh[2], ll[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rb[p][e] = keep ? rb[p][e] : 0.f;
+      for (int q = 0; q < 2; ++q) {
+        const v2f v = {x[2 * q] * xs, x[2 * q + 1] * xs};
+        const f16x2 hv = __builtin_convertvector(v, f16x2);
+        const v2f rr = v - __builtin_convertvector(hv, v2f);   // exact: the residual of a round-to-nearest conversion
+        hh[q] = __builtin_bit_cast(unsigned, hv);
+        ll[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, f16x2));
       }
-      if constexpr (ARITH == kF16x2) {
-        uint4 hi, lo;
-        split2h(rb[p], xs, hi, lo);
-        bs(buf, 0, g >> 1, g & 1, n) = hi;
-        bs(buf, 1, g >> 1, g & 1, n) = lo;
-      } else {
-        uint4 hi, mid, lo;
-        split3(rb[p], hi, mid, lo);
-        bs(buf, 0, g >> 1, g & 1, n) = hi;
-        bs(buf, 1, g >> 1, g & 1, n) = mid;
-        if constexpr (PL == 3) bs(buf, 2, g >> 1, g & 1, n) = lo;
+      reinterpret_cast<uint2*>(&bs(buf, 0, g >> 1, g & 1, n))[h] = make_uint2(hh[0], hh[1]);
+      reinterpret_cast<uint2*>(&bs(buf, 1, g >> 1, g & 1, n))[h] = make_uint2(ll[0], ll[1]);
+    } else {
+      unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float u = x[2 * q], v = x[2 * q + 1];
+        hh[q] = cvt2(u, v);
+        const float ru = u - __uint_as_float(hh[q] << 16), rv = v - __uint_as_float(hh[q] & 0xffff0000u);   // exact
+        mm[q] = cvt2(ru, rv);
+        const float su = ru - __uint_as_float(mm[q] << 16), sv = rv - __uint_as_float(mm[q] & 0xffff0000u); // exact
+        ll[q] = cvt2(su, sv);
       }
+      reinterpret_cast<uint2*>(&bs(buf, 0, g >> 1, g & 1, n))[h] = make_uint2(hh[0], hh[1]);
+      reinterpret_cast<uint2*>(&bs(buf, 1, g >> 1, g & 1, n))[h] = make_uint2(mm[0], mm[1]);
+      if constexpr (PL == 3) reinterpret_cast<uint2*>(&bs(buf, 2, g >> 1, g & 1, n))[h] = make_uint2(ll[0], ll[1]);
     }
   };
 
   // weights: the next k-step's fragments are in flight while the current ones are multiplied
   uint4 af[TM][PL], an[TM][PL];
   auto aload = [&](int s, uint4 (&dst)[TM][PL]) {
-    const int sc = s < ksteps ? s : ksteps - 1;   // harmless re-read past the end
+    const int sc = s < 0 ? 0 : (s < ksteps ? s : ksteps - 1);   // harmless re-reads before the start (zero chunk) / past the end
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -238,20 +294,44 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   // its outputs are shift (+ residual) through the ReLU, which is what the epilogue makes of zero accumulators.
   const int zf = a.zero_from ? max(a.zero_from[b], DUAL ? len2 : 0) : 0x7fffffff;
   const int nchunks = t0 >= zf ? 0 : a.K / BKC;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // Chunks are processed in PAIRS (the two stage register sets swap roles with every chunk, and the register names
+  // must be static).  An odd count is made even by a leading chunk "-1" that multiplies zeros: LDS buffer 1 is cleared
+  // instead of converted, the weight index clamps to step 0 (0 * w adds exact zeros), and chunk 0's rows are converted
+  // during it like any other.  Only the K = 64 layer of the first block (one chunk) and odd dual-source sums pay for it.
+  // (A separate tail for the odd chunk was tried first: a second conditional copy of the chunk body next to the
+  // final-pair block makes the register allocator spill ~160 registers around the merge of the 128 accumulators.)
+  const int odd = nchunks & 1;
   if (nchunks) {
-    gload(0);
+    gload(0, S0{});
     aload(0, af);
-    sstore(0, 0);
+    if (odd) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        int n, g;
+        patch_of(p, n, g);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) bs(1, pl, g >> 1, g & 1, n) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        sstore_half(0, 0, S0{}, p, 0);
+        sstore_half(0, 0, S0{}, p, 1);
+      }
+      gload(BKC, S0{});   // chunk 1: converted during chunk 0
+    }
   }
   __syncthreads();
 
-  // One K chunk.  LAST = false: the next chunk's activations are requested (behind the step-1 weight prefetch, because
-  // vmcnt retires in order and every later weight wait therefore also waits for them), converted and stored into the
-  // idle LDS buffer -- unconditionally, no branch anywhere in this body: with one, the compiler merges the two paths'
-  // load counters and waits for the HBM loads (vmcnt(0)) before the first MFMA of every chunk, and it sinks the loads
-  // down to sstore, their only use.  LAST = true is the peeled final chunk, which stages nothing.
-  auto run_chunk = [&](const int c, auto last_tag) {
+  // One K chunk c.  `cur` holds the rows of chunk c + 1 (requested one chunk ago), `nxt` receives those of chunk c + 2.
+  // LAST = false: request, convert a share of `cur` per k-step into the idle LDS buffer -- unconditionally, no branch
+  // anywhere in this body (with one the compiler merges the paths' load counters and waits for everything, vmcnt(0),
+  // before the first MFMA of every chunk).  LAST = true is the final chunk, which stages nothing.
+  auto run_chunk = [&](const int c, auto cur, auto nxt, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
+    constexpr int HALVES = 2 * PPT;
     const int cn = c + 1;
     // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
@@ -261,53 +341,68 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
-      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload(cn * BKC);
+      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload((c + 2) * BKC, nxt);
       // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
-      // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step, and the activation loads land
-      // next to sstore.  It also keeps sstore's conversion (which may overlap the last step's MFMAs) from moving
-      // further up, where its first instruction would wait for the HBM loads.
+      // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step.
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int cur = (s * TN + j) & 1, nxt = cur ^ 1;
+        const int cur_f = (s * TN + j) & 1, nxt_f = cur_f ^ 1;
         if (!(VASR_ABLATE & 2)) {
           if (j + 1 < TN) {
 #pragma unroll
-            for (int p = 0; p < PL; ++p) bf[nxt][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
           } else if (s + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < PL; ++p) bf[nxt][p] = bs(c & 1, p, s + 1, kh, l31);
+            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s + 1, kh, l31);
           }
         } else {
 #pragma unroll
-          for (int p = 0; p < PL; ++p) bf[nxt][p] = bf[cur][p];
+          for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bf[cur_f][p];
         }
         // cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
         if constexpr (ARITH == kBf16x3) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][2], bf[cur][0], acc[i][j]);   // lo  * hi
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][2], bf[cur_f][0], acc[i][j]);   // lo  * hi
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][2], acc[i][j]);   // hi  * lo
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][2], acc[i][j]);   // hi  * lo
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur][1], acc[i][j]);   // mid * mid
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur_f][1], acc[i][j]);   // mid * mid
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur][0], acc[i][j]);   // mid (lo) * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur_f][0], acc[i][j]);   // mid (lo) * hi
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][1], acc[i][j]);   // hi  * mid (lo)
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur][0], acc[i][j]);   // hi  * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
+        // this k-step's share of the next chunk's conversion, after the step's first n-tile: the scheduler spreads
+        // it under the MFMAs that follow
+        if (!LAST && !(VASR_ABLATE & 4) && j == (VASR_PW_CVT_AT < TN ? VASR_PW_CVT_AT : TN - 1)) {
+#pragma unroll
+          for (int hv = s * HALVES / STEPS; hv < (s + 1) * HALVES / STEPS; ++hv) sstore_half(cn & 1, cn * BKC, cur, hv >> 1, hv & 1);
+#ifdef VASR_PW_CVT_FENCE
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
     }
-    if (!LAST && !(VASR_ABLATE & 4)) sstore((c + 1) & 1, cn * BKC);
     if (!(VASR_ABLATE & 8)) __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
   };
-  for (int c = 0; c + 1 < nchunks; ++c) run_chunk(c, std::false_type{});
-  if (nchunks) run_chunk(nchunks - 1, std::true_type{});
+  {
+    int c = -odd;
+    for (; c + 2 < nchunks; c += 2) {
+      run_chunk(c, S0{}, S1{}, std::false_type{});
+      run_chunk(c + 1, S1{}, S0{}, std::false_type{});
+    }
+    if (nchunks) {   // the final pair: c + 2 == nchunks
+      run_chunk(c, S0{}, S1{}, std::false_type{});
+      run_chunk(c + 1, S1{}, S0{}, std::true_type{});
+    }
+  }
 
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
@@ -448,14 +543,14 @@ bool pointwise_split_supported(int M, int K, int K1) {
 int pointwise_amax_slots(int M, int64_t ld) { return (int)((int64_t)(M / 64) * ((ld + 31) / 32) * 2); }
 
 int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* amax_n) {
-  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..6 pins a tile shape
+  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..5 pins a tile shape
   static const bool no_skip = getenv("VASR_NO_TILE_SKIP") && atoi(getenv("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
   PwArgs a = args;
   if (no_skip) a.zero_from = nullptr;
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[7] = {0, 512, 256, 128, 64, 256, 256};
+  const int rows[6] = {0, 512, 256, 128, 64, 256};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
@@ -464,12 +559,14 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
   // one workgroup's prologue / epilogue behind another's main loop: 30.0 -> 28.7 us at K = 256, 49.1 -> 48.1 at K = 512
   if (tile == 2 && a.M == 256 && blocks(256, 64) >= 384) tile = 5;
   // (for the 512-channel layers both 256 x 64 and 512 x 64 measured slower than 512 x 128: 88-91 / 94-97 vs 86 us)
-  if (force >= 1 && force <= 6 && a.M % rows[force] == 0) tile = force;
+  if (force >= 1 && force <= 5 && a.M % rows[force] == 0) tile = force;
   switch (tile) {
     case 1: return launch_t<8, 2, 4>(a, arith, st, amax_n);
     case 2: return launch_t<8, 1, 4>(a, arith, st, amax_n);
     case 5: return launch_t<8, 1, 2>(a, arith, st, amax_n);
-    case 6: return launch_t<4, 2, 4>(a, arith, st, amax_n);   // 256 x 128 on four wavefronts: two workgroups per CU (kF16x2: 64 KB of LDS each)
+    // (256 x 128 on FOUR wavefronts, two workgroups per CU -- possible with the 64 KB of the two-plane arithmetics -- measured
+    // slower than one 512 x 128 workgroup: 57.5 vs 54.6 us on a 512-channel layer; one wavefront per SIMD and workgroup does
+    // not cover its own waits, and every workgroup converts the whole activation tile again)
     case 3: return launch_t<4, 1, 2>(a, arith, st, amax_n);
     default: return launch_t<2, 1, 1>(a, arith, st, amax_n);
   }
