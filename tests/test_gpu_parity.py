@@ -583,3 +583,35 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
         _lib.check(L.vasr_bench_depthwise(x0.data_ptr(), w_d.data_ptr(), lens_d.data_ptr(), B, C, T, K, y2.data_ptr(), st))
         torch.cuda.synchronize()
         assert float((y2[:, :, :t_out].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("gemm", ["f16x2", "fp32"])
+def test_long_recording_in_bounded_memory_equals_the_one_pass_result(gpu, gemm):
+    """engine.forward_long: a five-minute recording through windows of 2048 output frames + receptive-field halo (636 mel
+    frames each side for QuartzNet12x1), three windows per pass -- every kept frame sees exactly the inputs of the
+    one-pass computation, so predictions, ids AND log-probs are identical bit for bit; the workspace is bounded by the
+    window, not by the recording (the reference CLI refuses anything longer than 10 s, infer.py:201-203)."""
+    from viet_asr_amd import configs, synth
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 4), synth.decoder_state_dict(1024, 91, 4), gemm)
+    n = 5 * 60 * 16000 + 123
+    x = torch.from_numpy((0.1 * np.random.default_rng(5).standard_normal(n)).astype(np.float32)).to(gpu)
+    x[: n // 3] *= 0.05                                              # level changes along the recording
+    one = eng.forward(x[None], torch.tensor([n], device=gpu), want_logp=True)
+    r = eng.forward_long(x, chunk_frames=2048, rows_per_pass=3, want_logp=True)
+    assert eng.halo_mel_frames() == 636
+    assert r["logp"].shape == one["logp"].shape == (1, 15001, 91)
+    assert torch.equal(r["pred"], one["pred"])
+    assert torch.equal(r["id_len"], one["id_len"]) and torch.equal(r["ids"][0, : int(r["id_len"][0])], one["ids"][0, : int(one["id_len"][0])])
+    assert float(r["enc_len"][0]) == float(one["enc_len"][0])
+    _record("long_chunked", gemm=gemm, err=(r["logp"] - one["logp"]).abs().max(), scale=one["logp"].abs().max())
+    assert torch.equal(r["logp"], one["logp"])
+    # bounded: three windows of 2 * 2048 + 2 * 636 mel frames instead of 30 001 frames
+    assert r["workspace_bytes"] < 0.6 * r["one_pass_workspace_bytes"]
+    hour = eng.handle.workspace_bytes(1, samples=3600 * 16000)
+    assert r["workspace_bytes"] < hour / 20
+    # a recording shorter than one window degenerates to a single full-length row
+    short = eng.forward_long(x[:48000], chunk_frames=2048, rows_per_pass=3)
+    one_s = eng.forward(x[None, :48000].contiguous(), torch.tensor([48000], device=gpu))
+    assert torch.equal(short["pred"], one_s["pred"])

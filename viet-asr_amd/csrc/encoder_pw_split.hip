@@ -559,6 +559,19 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
   // one workgroup's prologue / epilogue behind another's main loop: 30.0 -> 28.7 us at K = 256, 49.1 -> 48.1 at K = 512
   if (tile == 2 && a.M == 256 && blocks(256, 64) >= 384) tile = 5;
   // (for the 512-channel layers both 256 x 64 and 512 x 64 measured slower than 512 x 128: 88-91 / 94-97 vs 86 us)
+  // ... when the 512 x 128 workgroups fill whole rounds of the chip (one per CU).  T' = 516 (a 10.3 s clip) is five
+  // 128-column tiles per utterance: 320 workgroups = two rounds, the second a quarter full.  256 x 64 tiles (two per CU,
+  // four times as many) quantise four times finer: measured 4.81 vs 5.68 ms of GEMM per step at 10.3 s, 4.84 vs 5.75 at
+  // 12 s, 5.79 vs 6.16 at 15 s -- and 7.95 vs 7.02 at 20 s, where 512 x 128 fills its two rounds exactly.
+  if (tile == 1) {
+    static const int n_cu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const int64_t n1 = blocks(512, 128), rounds = (n1 + n_cu - 1) / n_cu;
+    if ((double)n1 < 0.85 * (double)(rounds * n_cu)) tile = 5;
+  }
   if (force >= 1 && force <= 5 && a.M % rows[force] == 0) tile = force;
   switch (tile) {
     case 1: return launch_t<8, 2, 4>(a, arith, st, amax_n);

@@ -54,6 +54,7 @@ class QuartzNetCTC:
             raise NotImplementedError("only activation='relu', conv_mask=True is implemented")
         self.frontend = frontend_description(pre)
         self.hop = self.frontend["hop_length"]
+        self._blocks = blocks_from_config(jas)
         with torch.cuda.device(self.device):
             self.handle = _lib.Handle(frontend=self.frontend, feat_in=pre.get("features", 64),
                                       blocks=blocks_from_config(jas), dec_feat_in=jas[-1]["filters"],
@@ -165,6 +166,88 @@ class QuartzNetCTC:
             done.record(self._beam_stream)
         r["logp"].record_stream(self._beam_stream)     # allocated on the main stream, last read on the side stream
         return dict(ids=ids, id_len=n, score=score, done=done, enc_len=r["enc_len"])
+
+    # -- long recordings in bounded memory
+    def halo_mel_frames(self):
+        """Half-width of the encoder's receptive field in mel frames (even): sum over the depthwise convolutions of
+        (K - 1) / 2 * dilation, times the stride product in front of each."""
+        h, rate = 0, 1
+        for b in self._blocks:
+            k = b["kernel"] + (1 if b["kernel"] % 2 == 0 else 0)
+            for _ in range(b["repeat"]):
+                if b["separable"] or k > 1:
+                    h += (k - 1) // 2 * b["dilation"] * rate
+                rate *= b["stride"]
+                if b["stride"] > 1 and b["repeat"] > 1:
+                    raise NotImplementedError("strided block with repeat > 1")
+        return h + (h & 1)
+
+    def forward_long(self, wav, chunk_frames=4096, rows_per_pass=4, want_logp=False):
+        """One long recording [L] (float32, on the device) in BOUNDED memory: the reference CLI skips files longer than
+        10 s (infer.py:201-203); the one-call path handles any length but its workspace grows with it (2.6 GiB per hour of
+        audio on QuartzNet12x1).  Here the log-mel features -- whose per-feature statistics span the whole recording
+        (features.py:17-30), 256 bytes per frame -- are computed in one piece, and the encoder runs over windows of
+        ``chunk_frames`` OUTPUT frames, each extended by the receptive-field halo on both sides (``halo_mel_frames``;
+        zero padding only where the recording really ends), ``rows_per_pass`` windows at a time as the rows of one batch.
+        Frames inside a window's halo are discarded, the kept ones see exactly the inputs of the one-pass computation:
+        same predictions, same log-probs.  Returns dict(ids, id_len, pred, enc_len, logp or None, workspace_bytes)."""
+        from . import stages
+        if wav.dim() != 1 or wav.device.type != "cuda" or wav.dtype != torch.float32:
+            raise ValueError("wav must be a 1-D float32 cuda tensor")
+        h = self.handle
+        L = wav.shape[0]
+        mel, seq = stages.melspec(h, wav[None].contiguous(), torch.tensor([L], dtype=torch.int64, device=wav.device))
+        T, seq0 = mel.shape[2], int(seq[0])
+        T1 = h.encoded_frames(T)
+        H = self.halo_mel_frames()
+        stride = 1
+        for b in self._blocks:
+            stride *= b["stride"]
+        chunk_frames = max(int(chunk_frames), 1)
+        jobs = []                                           # (mel lo, mel hi, mask length, first kept frame, kept frames)
+        for o0 in range(0, T1, chunk_frames):
+            o1 = min(o0 + chunk_frames, T1)
+            lo = max(0, stride * o0 - H)
+            lo -= lo % stride                                # windows start on the stride grid: same conv phase
+            hi = min(T, stride * o1 + H)
+            jobs.append((lo, hi, max(min(seq0, hi) - lo, 0), o0 - lo // stride, o1 - o0))
+        c_out = self._blocks[-1]["filters"]
+        V1 = len(self.labels) + 1
+        logp = torch.empty((1, T1, V1), dtype=torch.float32, device=wav.device)
+        ws_bytes, done = 0, 0
+        for g in range(0, len(jobs), rows_per_pass):
+            grp = jobs[g : g + rows_per_pass]
+            W = max(hi - lo for lo, hi, *_ in grp)
+            x = torch.zeros((len(grp), mel.shape[1], W), dtype=torch.float32, device=wav.device)
+            for r, (lo, hi, *_rest) in enumerate(grp):
+                x[r, :, : hi - lo] = mel[0, :, lo:hi]
+            lens = torch.tensor([j[2] for j in grp], dtype=torch.int64, device=wav.device)
+            enc, _ = stages.encoder(h, x, lens, c_out)
+            ws_bytes = max(ws_bytes, h.workspace_bytes(len(grp), mel_frames=W))
+            for r, (_lo, _hi, _ml, skip, keep) in enumerate(grp):
+                piece = enc[r : r + 1, :, skip : skip + keep].contiguous()
+                logp[:, done : done + keep] = stages.decoder(h, piece)
+                done += keep
+        pred = stages.greedy_argmax(logp)
+        ids, id_len = stages.ctc_collapse(pred, V1 - 1)
+        enc_len = torch.tensor([float(self._encoded_length(seq0))], dtype=torch.float32, device=wav.device)
+        return dict(ids=ids, id_len=id_len, pred=pred, enc_len=enc_len, logp=logp if want_logp else None,
+                    workspace_bytes=ws_bytes, one_pass_workspace_bytes=h.workspace_bytes(1, samples=L))
+
+    def _encoded_length(self, seq):
+        """MaskedConv1d.get_seq_len chain (jasper.py:108-111, quirk Q3) on the host: float result, truncated between convs."""
+        lf = float(seq)
+        first = True
+        for b in self._blocks:
+            k = b["kernel"] + (1 if b["kernel"] % 2 == 0 else 0)
+            pad = (b["dilation"] * k) // 2 - 1 if b["dilation"] > 1 else k // 2
+            for _ in range(b["repeat"]):
+                convs = [(k, b["stride"], b["dilation"], pad), (1, 1, 1, 0)] if b["separable"] else [(k, b["stride"], b["dilation"], pad)]
+                for kk, st, dl, pd in convs:
+                    li = int(lf) if not first else int(seq)
+                    first = False
+                    lf = float(np.float32(np.float32(li + 2 * pd - dl * (kk - 1) - 1) / np.float32(st)) + np.float32(1.0))
+        return lf
 
     # -- pipelined host path: pinned staging, copies on their own stream, two batches in flight
     def launch(self, signals, row_independent=False):
