@@ -68,7 +68,7 @@ GEMM_MODES = {
 }
 
 
-def pmc_traffic(prefix):
+def pmc_traffic(prefix, suffix=""):
     """Launch-weighted mean HBM bytes per launch of the kernels whose name starts with ``prefix``, from the newest
     COMMITTED PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_round.sh;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  An offline figure: reported under traffic_offline, never as a
@@ -80,7 +80,7 @@ def pmc_traffic(prefix):
     d = json.load(open(files[-1]))
     n = b = 0
     for k, v in d.items():
-        if k.startswith(prefix) and "fetch_bytes_corrected_per_launch" in v and "write_bytes_per_launch" in v:
+        if k.startswith(prefix) and k.endswith(suffix) and "fetch_bytes_corrected_per_launch" in v and "write_bytes_per_launch" in v:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_corrected_per_launch"] + v["write_bytes_per_launch"])
     return (round(b / n) if n else None), os.path.basename(files[-1])
@@ -372,8 +372,9 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if gemm == "fp32" else PEAK_16BIT_MFMA_TFLOPS
         dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
         headline = a.config == 3 and not (a.model or a.batch or a.seconds or a.ragged)
-        kname = {"f16x2": "pw_gemm_f16x2_kernel", "fp32": "pw_gemm_kernel"}.get(gemm, "pw_gemm_bf16x3_kernel")
-        pw_traffic, traffic_src = pmc_traffic(kname) if headline else (None, None)
+        kname = "pw_gemm_kernel" if gemm == "fp32" else "pw_gemm_split_kernel"
+        arith_tag = {"f16x2": ", 2>", "bf16x3": ", 0>", "bf16x2": ", 1>"}.get(gemm, "")
+        pw_traffic, traffic_src = pmc_traffic(kname, arith_tag) if headline else (None, None)
         dw_traffic, _ = pmc_traffic("dw_") if headline else (None, None)
         what = {"greedy": "greedy CTC", "beam": f"beam search (width {a.beam_width}" + (", 3-gram LM" if lm_info else ", no LM") + ")"}[decoder]
         out = {

@@ -585,12 +585,16 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
         assert float((y2[:, :, :t_out].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("gemm", ["f16x2", "fp32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
 def test_long_recording_in_bounded_memory_equals_the_one_pass_result(gpu, gemm):
     """engine.forward_long: a five-minute recording through windows of 2048 output frames + receptive-field halo (636 mel
     frames each side for QuartzNet12x1), three windows per pass -- every kept frame sees exactly the inputs of the
-    one-pass computation, so predictions, ids AND log-probs are identical bit for bit; the workspace is bounded by the
-    window, not by the recording (the reference CLI refuses anything longer than 10 s, infer.py:201-203)."""
+    one-pass computation, so predictions and ids are identical, and so are the log-probs BIT FOR BIT in the fp32 and
+    3 x bf16 arithmetics.  In the default 2 x fp16 arithmetic the power-of-two operand scale follows the maximum of the
+    row a kernel works on -- a window here, the whole recording there -- and samples more than 2^17 below that maximum
+    keep fewer bits: the log-probs agree to 1e-4 (measured 8.8e-5 at |log-prob| 125), inside the tolerance against the
+    reference.  The workspace is bounded by the window, not by the recording (the reference CLI refuses anything longer
+    than 10 s, infer.py:201-203)."""
     from viet_asr_amd import configs, synth
     cfg = configs.builtin("quartznet12x1_vi")
     jas = cfg["JasperEncoder"]["jasper"]
@@ -606,7 +610,10 @@ def test_long_recording_in_bounded_memory_equals_the_one_pass_result(gpu, gemm):
     assert torch.equal(r["id_len"], one["id_len"]) and torch.equal(r["ids"][0, : int(r["id_len"][0])], one["ids"][0, : int(one["id_len"][0])])
     assert float(r["enc_len"][0]) == float(one["enc_len"][0])
     _record("long_chunked", gemm=gemm, err=(r["logp"] - one["logp"]).abs().max(), scale=one["logp"].abs().max())
-    assert torch.equal(r["logp"], one["logp"])
+    if gemm == "f16x2":
+        assert float((r["logp"] - one["logp"]).abs().max()) <= logp_tol(one["logp"].cpu().numpy())
+    else:
+        assert torch.equal(r["logp"], one["logp"])
     # bounded: three windows of 2 * 2048 + 2 * 636 mel frames instead of 30 001 frames
     assert r["workspace_bytes"] < 0.6 * r["one_pass_workspace_bytes"]
     hour = eng.handle.workspace_bytes(1, samples=3600 * 16000)
