@@ -61,7 +61,7 @@ struct TzGeom {
   static constexpr int LDS_TAB = 4 * TSZ;
   static constexpr int ORS = 144;                                   // output transposition: bytes per 32-float row
   static constexpr int LDS_OUT = 32 * ORS;
-  static constexpr int LDS_SCL = 16 * kPairsPerWave;                // (scale, 1 / scale) of the 2 * kPairsPerWave utterances
+  static constexpr int LDS_SCL = 16 * kPairsPerWave;                // per pair: (scale, 1 / scale) of both utterances
   static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_OUT + LDS_SCL;
 };
 
@@ -106,28 +106,37 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
 
   // ---- staging of one utterance pair: both rows, branch-free, all loads in flight together; the producers' maxima of
   //      the two utterances ride along (one word per lane and 64 slots) ----
+  // The kernel is instruction-issue bound (round-2 ablations: ~500 instructions per pair at ~4.5 cycles each), so every
+  // mask and address computation that hardware can do is handed to it: rows are read through raw buffer descriptors
+  // whose range is the utterance's length -- MaskedConv1d's x.masked_fill(t >= lens, 0) (jasper.py:113-118) and the
+  // conv's zero padding left of frame 0 (a negative offset is a huge unsigned one) both come back as zeros, per dword.
   struct Stage { v4f r0[NLD], r1[NLD]; };
+  const int64_t row_stride = (int64_t)channels * ldx;                 // floats between utterances of one channel
+  const float* xrow = x + ((int64_t)(2 * p_lo) * channels + c) * ldx;   // row of the first utterance of pair p_lo
+  const int64_t yrow_stride = (int64_t)channels * ldy;
+  float* yrow0 = y + ((int64_t)(2 * p_lo) * channels + c) * ldy;
   auto gload = [&](int p, Stage& sg) {
     const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
-    const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
-    const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
+    const float* xr0 = xrow + (int64_t)(b0 - 2 * p_lo) * row_stride;
+    const float* xr1 = xrow + (int64_t)(b1 - 2 * p_lo) * row_stride;
+    // (lengths through the scalar cache: the descriptor words must be wave-uniform for the compiler, or every load
+    // becomes a waterfall loop)
+    const auto d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr0), 0, 4 * min(lens_in[b0], (int)ldx), 0x00020000);
+    const auto d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr1), 0, 4 * min(lens_in[b1], (int)ldx), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int t = t_tile - G::PADL + 4 * (lane + 64 * j);
-      int tc = t < 0 ? 0 : t;
-      tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
+      const int off = 4 * (t_tile - G::PADL + 4 * (lane + 64 * j));
       if (!(VASR_TZ_ABLATE & 8)) {
-        sg.r0[j] = *reinterpret_cast<const v4f*>(xr0 + tc);
-        sg.r1[j] = *reinterpret_cast<const v4f*>(xr1 + tc);
+        sg.r0[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d0, off, 0, 0));
+        sg.r1[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d1, off, 0, 0));
       } else {
-        sg.r0[j] = v4f{(float)tc, 1.f, 2.f, 3.f};
-        sg.r1[j] = v4f{(float)tc, 3.f, 2.f, 1.f};
+        sg.r0[j] = v4f{(float)off, 1.f, 2.f, 3.f};
+        sg.r1[j] = v4f{(float)off, 3.f, 2.f, 1.f};
       }
     }
   };
-  // MaskedConv1d: x.masked_fill(t >= lens, 0) (jasper.py:113-118); t < 0 is the conv zero padding (t, PADL multiples of 4)
   // scale by the utterance's power of two, split into fp16 hi / lo, 8 + 8 bytes into the two planes
-  auto sstore = [&](const v4f (&sv)[NLD], int u, int len, float sx) {
+  auto sstore = [&](const v4f (&sv)[NLD], int u, float sx) {
     unsigned char* ph = dat + (u * 2 + 0) * G::UROW;
     unsigned char* pl = dat + (u * 2 + 1) * G::UROW;
     // Branch-free: a lane past the staged row (last slab only) writes into the 16 spare bytes behind it.  With a
@@ -139,13 +148,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     for (int j = 0; j < NLD; ++j) {
       const int tau = 4 * (lane + 64 * j);
       {
-        const int t = t_tile - G::PADL + tau;
-        const int n = t < 0 ? 0 : len - t;
-        v4f v = sv[j];
-        v.x = n > 0 ? v.x : 0.f;
-        v.y = n > 1 ? v.y : 0.f;
-        v.z = n > 2 ? v.z : 0.f;
-        v.w = n > 3 ? v.w : 0.f;
+        const v4f v = sv[j];
         const v2f a = {v.x * sx, v.y * sx}, b = {v.z * sx, v.w * sx};
         const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
         const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, v2f), f16x2);
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const float4 sc = scl[p - p_lo];   // (scale, 1 / scale) of both utterances: LDS broadcast, no vector-memory wait
     const float sx0 = sc.x, ix0 = sc.y, sx1 = sc.z, ix1 = sc.w;
     if (!(VASR_TZ_ABLATE & 4)) {
-      sstore(sg.r0, 0, lens_in[b0], sx0);
-      sstore(sg.r1, 1, lens_in[b1], sx1);
+      sstore(sg.r0, 0, sx0);
+      sstore(sg.r1, 1, sx1);
     } else {
       asm volatile("" :: "v"(sg.r0[0]), "v"(sg.r1[NLD - 1]));
     }
@@ -205,30 +208,47 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       *reinterpret_cast<v4f*>(orow + 32 * q) = o;
     }
     wave_sync();
-    const int lo0 = lens_out[b0], lo1 = lens_out[b1];
-    unsigned m0 = 0, m1 = 0;
+    // Read back as rows: lanes 0-31 take utterance 0 (windows 0-15), lanes 32-63 utterance 1 -- 2 x 512 contiguous
+    // bytes per store instruction, and ONE row-wise reduction yields both utterances' maxima (rows 0-1 / rows 2-3).
+    const int u = lane >> 5;
+    const int lo0 = lens_out[b0], lo1 = lens_out[b1];   // scalar loads
+    const int lo_u = u ? lo1 : lo0;
+    float* y0 = yrow0 + (int64_t)(b0 - 2 * p_lo) * yrow_stride;
+    float* y1 = yrow0 + (int64_t)(b1 - 2 * p_lo) * yrow_stride;
+    float* yrow = u ? y1 : y0;
+    const bool live = u == 0 || twin;
+    float mx = 0.f;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      // flat float index 4 lane + 256 ps -> row (window) lane / 8 + 8 ps, column 4 (lane % 8)
-      const int row = (lane >> 3) + 8 * ps;
-      v4f v = *reinterpret_cast<const v4f*>(outb + row * G::ORS + 16 * (lane & 7));
-      const int u = ps >> 1;
-      const int t = t_tile + 32 * (row & 15) + 4 * (lane & 7);
-      const int nv = (u ? lo1 : lo0) - t;
+      // float4 index (lane & 31) + 32 ps inside the utterance's 16 x 8 float4 -> row (window) of the block, column 4 (idx % 8)
+      const int idx = (lane & 31) + 32 * ps, row = idx >> 3;
+      v4f v = *reinterpret_cast<const v4f*>(outb + (16 * u + row) * G::ORS + 16 * (idx & 7));
+      const int t = t_tile + 32 * row + 4 * (idx & 7);
+      const int nv = lo_u - t;
       v.x = nv > 0 ? v.x : 0.f;
       v.y = nv > 1 ? v.y : 0.f;
       v.z = nv > 2 ? v.z : 0.f;
       v.w = nv > 3 ? v.w : 0.f;
-      if (t < ldy && (u == 0 || twin) && (!(VASR_TZ_ABLATE & 2) || v.x == 12345.678f)) {
-        *reinterpret_cast<v4f*>(y + ((int64_t)(u ? b1 : b0) * channels + c) * ldy + t) = v;
-        const unsigned m = max(max(abs_bits(v.x), abs_bits(v.y)), max(abs_bits(v.z), abs_bits(v.w)));
-        if (u) m1 = max(m1, m); else m0 = max(m0, m);
+      if (t < ldy && live && (!(VASR_TZ_ABLATE & 2) || v.x == 12345.678f)) {
+        *reinterpret_cast<v4f*>(yrow + t) = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
     }
     if (amax_y && !(VASR_TZ_ABLATE & 32)) {
+      unsigned m = __float_as_uint(mx);   // |x| bit patterns order like unsigned integers
+#define VASR_DPP(xx, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(xx), (ctrl), 0xF, 0xF, false))
+      m = max(m, VASR_DPP(m, 0xB1));
+      m = max(m, VASR_DPP(m, 0x4E));
+      m = max(m, VASR_DPP(m, 0x141));
+      m = max(m, VASR_DPP(m, 0x140));
+#undef VASR_DPP
+      const unsigned m0 = max((unsigned)__builtin_amdgcn_readlane((int)m, 0), (unsigned)__builtin_amdgcn_readlane((int)m, 16));
+      const unsigned m1 = max((unsigned)__builtin_amdgcn_readlane((int)m, 32), (unsigned)__builtin_amdgcn_readlane((int)m, 48));
       const int slot = c * gridDim.z + blockIdx.z;
-      amax_publish(amax_y, amax_y_stride, b0, slot, m0, lane);
-      if (twin) amax_publish(amax_y, amax_y_stride, b1, slot, m1, lane);
+      if (lane == 0) {
+        amax_y[(int64_t)b0 * amax_y_stride + slot] = m0;
+        if (twin) amax_y[(int64_t)b1 * amax_y_stride + slot] = m1;
+      }
     }
     wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
   };

@@ -519,8 +519,11 @@ static int run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStrea
 }
 
 // Encoder over an input [B][feat_in][x_ld]; writes [B][c_last][out_ld] (T1 valid frames).
+// enc_amax (optional): receives the maxima table of the encoder output when one was published (fp16-split mode, padded
+// output pitch), for the CTC head of the fused path; the table lives in the workspace until the next encoder pass.
 int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const int64_t* seq, int batch,
-                float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st) {
+                float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st,
+                AmaxTab* enc_amax = nullptr) {
   int32_t* lens_tab = reinterpret_cast<int32_t*>(ws + p.lens_tab);
   auto lens = [&](int step) { return lens_tab + (size_t)step * batch; };
   launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st);
@@ -613,7 +616,11 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.amax_x = gx_amax;
       a.amax_x2 = fuse ? blk_amax : AmaxTab{};
       // this GEMM's output is masked at lens(S.pw.step + 1) by whatever reads it next
-      if (want_amax && !(last_block && last_sub)) { a.amax_y = free_tab(gx_amax); a.lens_y = lens(S.pw.step + 1); }
+      // (the encoder output's maxima are only wanted by the fused path's CTC head, which reads every column < T')
+      if (want_amax && (!(last_block && last_sub) || enc_amax)) {
+        a.amax_y = free_tab(gx_amax);
+        a.lens_y = (last_block && last_sub) ? nullptr : lens(S.pw.step + 1);
+      }
       int published;
       {
         ProfScope ps(h, kProfPointwise, st);
@@ -624,18 +631,21 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       cur_amax = published ? a.amax_y : AmaxTab{};
     }
   }
+  if (enc_amax) *enc_amax = cur_amax;
   return check_launch("encoder");
 }
 
 int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int batch, float* logits, float* logp,
-                int64_t* pred, hipStream_t st) {
+                int64_t* pred, hipStream_t st, AmaxTab enc_amax = AmaxTab{}) {
   PwArgs a{};
   a.wt = h->dec.d_w; a.x = encp; a.lens = nullptr; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
   a.res = nullptr; a.y = logits; a.M = h->dec.m_pad; a.K = h->dec.cin; a.batch = batch;
   a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
   a.relu = 0;
   ProfScope ps(h, kProfHead, st);
-  // 3 x bf16 split GEMM unless fp32 mode is selected (no maxima are passed: the head, HBM-bound, never takes the fp16 form)
+  // split GEMM unless fp32 mode is selected: the fp16 form when the encoder published its output's maxima (fused path),
+  // else 3 x bf16 (port tensors of the per-module entry point carry none)
+  a.amax_x = enc_amax;
   if (run_pointwise(h, a, h->dec, st) < 0) return VASR_ERR_HIP;
   launch_logsoftmax_argmax(logits, ld, (int64_t)h->num_classes * ld, batch, (int)T1, h->num_classes, logp, pred, st);
   return check_launch("decoder");
@@ -845,9 +855,10 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
                        h->fe.preemph, h->fe.log_guard, melp, p.Tp0, (int)T, st);
     launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
   }
-  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st);
+  AmaxTab enc_amax{};
+  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st, &enc_amax);
   if (rc) return rc;
-  if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st))) return rc;
+  if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st, enc_amax))) return rc;
   if (d_ids && d_id_len) {
     ProfScope ps(h, kProfHead, st);
     if (h->row_independent)
