@@ -208,9 +208,13 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   };
   // requests chunk k0 (clamped to the last chunk: past the end the last chunk is simply requested again, so that the
   // number of loads in flight is the same on every path -- s_waitcnt vmcnt counts, it does not name)
-  float rr[2][PPT][8];   // two stage register sets: one being converted, one being filled (indexed by compile-time constants only)
+#ifndef VASR_PW_STAGE_SETS
+#define VASR_PW_STAGE_SETS 2   // 2 = rows requested two chunks ahead and converted a quarter per k-step; 1 = requested at the
+#endif                         // start of the previous chunk and converted during its last k-step (16 registers less)
+  constexpr int SSETS = VASR_PW_STAGE_SETS;
+  float rr[SSETS][PPT][8];   // stage register sets: one being converted, one being filled (indexed by compile-time constants only)
   auto gload = [&](int k0, auto set_tag) {
-    auto& r = rr[decltype(set_tag)::value];
+    auto& r = rr[decltype(set_tag)::value % SSETS];
     k0 = k0 < a.K - BKC ? k0 : a.K - BKC;
     const bool second = DUAL && k0 >= K1;
     const float* __restrict__ base = second ? xb2 + (int64_t)(k0 - K1) * a.ldx2 : xb + (int64_t)k0 * a.ldx;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   };
   // converts half h (k rows 4 h .. 4 h + 3) of patch p of chunk k0 and stores it into LDS buffer `buf`
   auto sstore_half = [&](int buf, int k0, auto set_tag, int p, int h) {
-    const auto& r = rr[decltype(set_tag)::value];
+    const auto& r = rr[decltype(set_tag)::value % SSETS];
     const bool second = DUAL && k0 >= K1;
     const int ml = second ? len2 : len;
     const bool masked = second || MASK;
@@ -281,7 +285,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   };
 
   // weights: the next k-step's fragments are in flight while the current ones are multiplied
-  uint4 af[TM][PL], an[TM][PL];
+#ifndef VASR_PW_WSETS
+#define VASR_PW_WSETS 2   // weight fragment sets in rotation: 2 = one k-step ahead, 4 = three k-steps ahead (STEPS % sets == 0)
+#endif
+  constexpr int WSETS = PL == 2 && TM * TN >= 8 ? VASR_PW_WSETS : 2;   // (3 planes / the small tiles: no registers or no need)
+  static_assert(STEPS % WSETS == 0 || WSETS == 2, "weight sets must divide the k-steps of a chunk");
+  uint4 aw[WSETS][TM][PL];            // aw[s % WSETS] holds the fragments of global k-step s
+  uint4 (&af)[TM][PL] = aw[0];
+  uint4 (&an)[TM][PL] = aw[1];
   auto aload = [&](int s, uint4 (&dst)[TM][PL]) {
     const int sc = s < 0 ? 0 : (s < ksteps ? s : ksteps - 1);   // harmless re-reads before the start (zero chunk) / past the end
 #pragma unroll
@@ -306,6 +317,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   if (nchunks) {
     gload(0, S0{});
     aload(0, af);
+    if constexpr (WSETS > 2) {
+      // chunk "-1" (odd counts) starts at global step -STEPS: its steps clamp to fragment 0, which is what aw[*] then holds
+#pragma unroll
+      for (int w = 1; w < WSETS - 1; ++w) aload(odd ? 0 : w, aw[w]);
+    }
     if (odd) {
 #pragma unroll
       for (int p = 0; p < PPT; ++p) {
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
         sstore_half(0, 0, S0{}, p, 0);
         sstore_half(0, 0, S0{}, p, 1);
       }
-      gload(BKC, S0{});   // chunk 1: converted during chunk 0
+      if constexpr (SSETS == 2) gload(BKC, S0{});   // chunk 1: converted during chunk 0
     }
   }
   __syncthreads();
@@ -340,11 +356,16 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
     for (int p = 0; p < PL; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
-      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload((c + 2) * BKC, nxt);
+      if constexpr (WSETS == 2) {
+        if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
+      } else {
+        if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + WSETS - 1, aw[(s + WSETS - 1) % WSETS]);
+      }
+      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload((c + SSETS) * BKC, nxt);   // one set: `nxt` and `cur` are the same registers
       // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
       // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step.
       __builtin_amdgcn_sched_barrier(0);
+      uint4 (&cw)[TM][PL] = aw[WSETS == 2 ? 0 : s % WSETS];   // this k-step's weight fragments
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int cur_f = (s * TN + j) & 1, nxt_f = cur_f ^ 1;
@@ -363,32 +384,37 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
         // cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
         if constexpr (ARITH == kBf16x3) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][2], bf[cur_f][0], acc[i][j]);   // lo  * hi
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][2], bf[cur_f][0], acc[i][j]);   // lo  * hi
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][2], acc[i][j]);   // hi  * lo
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][2], acc[i][j]);   // hi  * lo
 #pragma unroll
-          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur_f][1], acc[i][j]);   // mid * mid
+          for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][1], bf[cur_f][1], acc[i][j]);   // mid * mid
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][1], bf[cur_f][0], acc[i][j]);   // mid (lo) * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][1], bf[cur_f][0], acc[i][j]);   // mid (lo) * hi
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(af[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
+        for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
         // this k-step's share of the next chunk's conversion, after the step's first n-tile: the scheduler spreads
         // it under the MFMAs that follow
         if (!LAST && !(VASR_ABLATE & 4) && j == (VASR_PW_CVT_AT < TN ? VASR_PW_CVT_AT : TN - 1)) {
+          // two sets: a share per k-step; one set: everything in the last k-step (the rows were requested in the first)
+          const int h0 = SSETS == 2 ? s * HALVES / STEPS : (s == STEPS - 1 ? 0 : HALVES);
+          const int h1 = SSETS == 2 ? (s + 1) * HALVES / STEPS : HALVES;
 #pragma unroll
-          for (int hv = s * HALVES / STEPS; hv < (s + 1) * HALVES / STEPS; ++hv) sstore_half(cn & 1, cn * BKC, cur, hv >> 1, hv & 1);
+          for (int hv = h0; hv < h1; ++hv) sstore_half(cn & 1, cn * BKC, cur, hv >> 1, hv & 1);
 #ifdef VASR_PW_CVT_FENCE
           __builtin_amdgcn_sched_barrier(0);
 #endif
         }
       }
+      if constexpr (WSETS == 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
+          for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
+      }
     }
     if (!(VASR_ABLATE & 8)) __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
   };
