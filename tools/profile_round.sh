@@ -14,5 +14,5 @@ python "$R/tools/pmc_summary.py" "$O"/fetch/*/*counter_collection.csv "$O"/write
 find "$O" -name '*kernel_trace.csv' -delete
 find "$O" -name '*counter_collection.csv' -delete
 find "$O" -name '*.db' -delete
-python "$R/bench.py" > "$O/bench_plain.json" 2> /dev/null
+timeout 300 python "$R/bench.py" > "$O/bench_plain.json" 2> /dev/null
 ls -R "$O" | head -30

@@ -661,7 +661,7 @@ size_t beam_lds_bytes() {
          8 * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2 + kMaxBeams) + 16;
 }
 
-void launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+int launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
                         float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
                         int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                         const int32_t* row_frames) {
@@ -674,14 +674,12 @@ void launch_beam_search(const float* logp, int batch, int frames, int V1, int sp
     v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
   }
   const size_t lds = beam_lds_bytes();
-  static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)beam_lds_bytes());
-    return true;
-  }();
-  (void)once;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)beam_lds_bytes());
+  if (attr != hipSuccess) return (int)attr;
   hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, row_frames, V1, space_id,
                      beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, out_ids, out_len, out_score);
+  return 0;
 }
 
 unsigned long long beam_hash_step(unsigned long long h, unsigned long long v) { return hmix(h, v); }

@@ -1003,9 +1003,10 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (space_id < -1 || space_id >= num_classes - 1) return fail(VASR_ERR_INVALID, "space_id out of range");
   const size_t need_bytes = vasr_beam_workspace_bytes(batch, frames);
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
-  launch_beam_search(d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width,
-                     token_min_logp, beam_prune_logp, lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws),
-                     d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream), d_row_frames);
+  const int e = launch_beam_search(d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width,
+                                   token_min_logp, beam_prune_logp, lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws),
+                                   d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream), d_row_frames);
+  if (e) return fail(VASR_ERR_HIP, "beam search: %s", hipGetErrorString((hipError_t)e));
   return check_launch("beam_search");
 }
 

@@ -162,7 +162,8 @@ struct BeamLm {  // device-resident hashed back-off n-gram model
   float alpha, beta, unk_offset;
 };
 constexpr int kBeamMax = 128;  // beams kept per utterance at most
-void launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+int launch_beam_search(const float* logp,   // 0 or a hipError_t
+                        int batch, int frames, int V1, int space_id, int beam_width,
                         float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
                         int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                         const int32_t* row_frames = nullptr);   // [batch] frames searched per row, nullptr = all
