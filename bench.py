@@ -395,6 +395,9 @@ def main():
                          "bound": "mfma", "achieved": round(exec_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(exec_tflops / peak, 4),
                          "mfma_products_per_multiply": terms, "fp32_equivalent_tflops": round(pw_tflops, 2),
+                         # the same algorithmic work against the matrix pipe's fp32 peak (what an fp32-MFMA kernel could
+                         # reach at most): > 1 means the split arithmetic beats the best possible exact-fp32 GEMM
+                         "frac_of_fp32_mfma_peak": round(pw_tflops / PEAK_F32_MFMA_TFLOPS, 3),
                          "traffic": None, "traffic_offline": pw_traffic,
                          "traffic_note": "HBM bytes per launch from the committed PMC pass named in traffic_source (not measured in "
                                          "this run; null off the headline workload)", "traffic_source": traffic_src,
