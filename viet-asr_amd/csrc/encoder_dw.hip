@@ -188,18 +188,30 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float* __restrict__ 
 //     an odd stride, so the 16 lanes of a group always hit 16 different slots, and because 4 l is a multiple of 4
 //     the pad seen at window offset q is q/4 for every lane -- all reads stay immediate offsets from one base.
 // Odd batch tail: the last utterance is paired with itself and stored once.
-template <int K, int DIL = 1>
+// SUB (1, 2 or 4): utterance PAIRS per wavefront.  SUB = 1 is the tile described above (64 lanes x 8 frames = 512 frames of
+// one pair).  A row pitch off the 512-frame grid leaves a short tail tile -- T' = 516 is 640 columns: one full tile and
+// 128 columns -- which the SUB = 1 form computes at full price (depthwise 1.75 -> 2.75 ms per step at 10.3 s clips).  The
+// tail launch instead gives each pair 64 / SUB lanes (SUB = 4: 16 lanes x 8 frames = 128 frames, SUB = 2: 256) and a
+// window of its own in the wavefront's LDS region: same channel, so the taps stay wave-uniform scalars, and the FMA phase
+// is instruction for instruction the one of the full tile -- a quarter (half) of the wavefront-passes for the tail.
+template <int K, int DIL = 1, int SUB = 1>
 struct PairGeom {
+  static constexpr int LP = 64 / SUB;                               // lanes per pair
   static constexpr int PAD = DIL > 1 ? (DIL * K) / 2 - 1 : K / 2;   // get_same_padding (jasper.py:60-65)
   static constexpr int PADL = (PAD + 3) & ~3;
   static constexpr int OFF = PADL - PAD;
   static constexpr int NP = OFF + DIL * (K - 1) + 8;                // pairs in one lane's register window
   static constexpr int NQ = (NP + 1) / 2;                           // quads = 2 pairs = one ds_read_b128
-  static constexpr int QNEED = 4 * 63 + NQ;                         // logical quads lane 63's window reaches
-  static constexpr int NLD = (QNEED + 127) / 128;                   // staging float4 per lane and utterance
-  static constexpr int LAST = (QNEED - 128 * (NLD - 1) + 1) / 2;    // lanes that take part in the last staging slab
-  static constexpr int QUADS = 128 * (NLD - 1) + 2 * (LAST < 64 ? LAST : 64);   // logical quads staged
-  static constexpr int PHYS = QUADS + QUADS / 4 + 1;                // + one pad quad per 4
+  static constexpr int QNEED = 4 * (LP - 1) + NQ;                   // logical quads the last lane's window reaches
+  static constexpr int NLD = (QNEED + 2 * LP - 1) / (2 * LP);       // staging float4 per lane and utterance
+  static constexpr int LAST = (QNEED - 2 * LP * (NLD - 1) + 1) / 2; // lanes (of a pair's LP) that take part in the last slab
+  static constexpr int QUADS = 2 * LP * (NLD - 1) + 2 * (LAST < LP ? LAST : LP);   // logical quads staged per pair
+  static constexpr int PHYS1 = QUADS + QUADS / 4 + 1;               // + one pad quad per 4
+  // SUB > 1: the pairs' regions start a multiple of 16 quads apart, so that the 16 lanes of a ds_read_b128 service group
+  // -- which then straddle two pairs -- still hit 16 different 16-byte slots (5 ll mod 16 is a permutation)
+  static constexpr int PHYS_SUB = SUB == 1 ? PHYS1 : (PHYS1 + 15) / 16 * 16;
+  static constexpr int PHYS = SUB * PHYS_SUB;
+  static constexpr int JSTRIDE = 2 * LP + LP / 2;                   // physical quads between a lane's staging slabs
   static constexpr int TB = 8;                                      // taps per software-pipeline block
   static constexpr int NB = (K + TB - 1) / TB;
   // one past the last quad that taps [0, min(K, TB*(blk+1))) touch
@@ -212,37 +224,43 @@ struct PairGeom {
 // grid (C/4, ceil(B/2), ceil(ldy/512)), block 256 = 4 wavefronts, one (channel, utterance pair, 512-frame tile) each.
 // (Walking several pairs per wavefront with the next pair's rows prefetched measured 5-15% slower than simply keeping
 // 6-7 short-lived wavefronts per SIMD resident, so there is no row loop.)
-template <int K, int DIL>
+// t_base: first frame of this launch's tile 0; tile0 / tiles_total: this launch's tiles in the layer's numbering (slots of
+// the maxima table are c * tiles_total + tile).
+template <int K, int DIL, int SUB>
 __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ w,
                                                       const int32_t* __restrict__ lens_in,
                                                       const int32_t* __restrict__ lens_out, int channels, int batch,
                                                       float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
-                                                      int amax_stride) {
-  using G = PairGeom<K, DIL>;
-  constexpr int NLD = G::NLD;
+                                                      int amax_stride, int t_base, int tile0, int tiles_total) {
+  using G = PairGeom<K, DIL, SUB>;
+  constexpr int NLD = G::NLD, LP = G::LP;
   __shared__ v4f lds4[4 * G::PHYS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // (Mapping workgroups to XCDs so that XCD k gets the utterances the GEMM kernels give it was measured: depthwise
   // +5 %, GEMM -0.3 % -- nothing useful survives the kernel boundary in an XCD's L2.)
   const int c = blockIdx.x * 4 + wave;
-  const int b0 = 2 * blockIdx.y;
+  const int sub = SUB == 1 ? 0 : lane / LP, ll = SUB == 1 ? lane : lane % LP;   // pair of this lane, lane inside the pair
+  const int n_pairs = (batch + 1) / 2;
+  const int pp = blockIdx.y * SUB + sub;
+  const bool live = SUB == 1 || pp < n_pairs;                       // SUB > 1: the last wavefront may hold fewer pairs
+  const int b0 = 2 * (live ? pp : n_pairs - 1);                     // (idle lanes compute the last pair again and store nothing)
   const bool twin = b0 + 1 < batch;
   const int b1 = twin ? b0 + 1 : b0;
-  const int t_start = blockIdx.z * kTile;
-  v4f* win = lds4 + wave * G::PHYS;
+  const int t_start = t_base + blockIdx.z * kTile;
+  v4f* win = lds4 + wave * G::PHYS + sub * G::PHYS_SUB;
 
   // ---- staging: both rows, branch-free (clamped address + selects), all loads in flight together ----
-  // The last slab only reaches as far as lane 63's window: lanes past it neither load nor store.
+  // The last slab only reaches as far as the pair's last lane's window: lanes past it neither load nor store.
   v4f s0[NLD], s1[NLD];
-  const bool in_last = G::LAST >= 64 || lane < G::LAST;
+  const bool in_last = G::LAST >= LP || ll < G::LAST;
   {
     const float* xr0 = x + ((int64_t)b0 * channels + c) * ldx;
     const float* xr1 = x + ((int64_t)b1 * channels + c) * ldx;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+      const int t = t_start - G::PADL + 4 * (ll + LP * j);
       int tc = t < 0 ? 0 : t;
       tc = tc > (int)ldx - 4 ? (int)ldx - 4 : tc;
       if (j + 1 < NLD || in_last) {
@@ -271,19 +289,19 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     v.w = n > 3 ? v.w : 0.f;
     return v;
   };
-  v4f* wr = win + 2 * lane + (lane >> 1);   // logical quads 2*(lane + 64 j), +1 -> physical (+ 160 j), +1
-  // sliding window: logical quad 4*lane + q lives at 4*lane + q + ((4*lane + q) >> 2) = 5*lane + q + (q >> 2)
-  const v4f* rb = win + 5 * lane;
+  v4f* wr = win + 2 * ll + (ll >> 1);   // logical quads 2*(ll + LP j), +1 -> physical (+ JSTRIDE j), +1
+  // sliding window: logical quad 4*ll + q lives at 4*ll + q + ((4*ll + q) >> 2) = 5*ll + q + (q >> 2)
+  const v4f* rb = win + 5 * ll;
 
   const int len_in0 = lens_in[b0], len_in1 = lens_in[b1];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
-    const int t = t_start - G::PADL + 4 * (lane + 64 * j);
+    const int t = t_start - G::PADL + 4 * (ll + LP * j);
     const v4f a = masked(s0[j], t, len_in0), bq = masked(s1[j], t, len_in1);
     const v4f q0 = {a.x, bq.x, a.y, bq.y}, q1 = {a.z, bq.z, a.w, bq.w};
     if (j + 1 < NLD || in_last) {
-      wr[160 * j] = q0;
-      wr[160 * j + 1] = q1;
+      wr[G::JSTRIDE * j] = q0;
+      wr[G::JSTRIDE * j + 1] = q1;
     }
   }
   wave_sync();
@@ -338,14 +356,14 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
   }
 
   // ---- store: the following 1x1 MaskedConv1d masks with lens_out, so frames past it are written as zeros ----
-  const int t = t_start + 8 * lane;
+  const int t = t_start + 8 * ll;
   const int n0 = lens_out[b0] - t, n1 = lens_out[b1] - t;
   float* y0 = y + ((int64_t)b0 * channels + c) * ldy + t;
   float* y1 = y + ((int64_t)b1 * channels + c) * ldy + t;
   unsigned m0 = 0, m1 = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (t + 4 * h < ldy) {
+    if (t + 4 * h < ldy && live) {
       v4f o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -364,20 +382,63 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     }
   }
   if (amax) {   // masked outputs only (zeros past lens_out): the maximum over the utterance's valid frames
-    const int slot = c * gridDim.z + blockIdx.z;
-    amax_publish(amax, amax_stride, b0, slot, m0, lane);
-    if (twin) amax_publish(amax, amax_stride, b1, slot, m1, lane);
+    const int slot = c * tiles_total + tile0 + blockIdx.z;
+    if constexpr (SUB == 1) {
+      amax_publish(amax, amax_stride, b0, slot, m0, lane);
+      if (twin) amax_publish(amax, amax_stride, b1, slot, m1, lane);
+    } else {
+      // one reduction inside each 16-lane row (DPP), the rows of a pair combined through SGPRs; lane 0 stores every pair's
+#define VASR_DPP(xx, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(xx), (ctrl), 0xF, 0xF, false))
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned m = u ? m1 : m0;
+        m = max(m, VASR_DPP(m, 0xB1));
+        m = max(m, VASR_DPP(m, 0x4E));
+        m = max(m, VASR_DPP(m, 0x141));
+        m = max(m, VASR_DPP(m, 0x140));
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (unsigned)__builtin_amdgcn_readlane((int)m, 16 * k);
+#pragma unroll
+        for (int sp = 0; sp < SUB; ++sp) {
+          const unsigned ms = SUB == 4 ? r[sp] : max(r[2 * sp], r[2 * sp + 1]);
+          const int bq0 = 2 * (blockIdx.y * SUB + sp) + u;
+          if (lane == 0 && bq0 < batch) amax[(int64_t)bq0 * amax_stride + slot] = ms;
+        }
+      }
+#undef VASR_DPP
+    }
   }
 }
 
 template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
                     int channels, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
-  dim3 grid(channels / 4, (batch + 1) / 2, (unsigned)((ldy + kTile - 1) / kTile));
-  if (amax) amax->n = channels * grid.z;
   static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  VASR_LAUNCH((dw_pair_kernel<K, DIL>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy,
-              amax ? amax->p : nullptr, amax ? amax->stride : 0);
+  static const bool tail = !(getenv("VASR_DW_TAIL") && atoi(getenv("VASR_DW_TAIL")) == 0);   // A/B switch
+  const int n_pairs = (batch + 1) / 2;
+  // full 512-frame tiles, then a tail of 128 or 256 columns (the pitch is a multiple of 128; 384 runs as a full tile)
+  int nt_main = (int)(ldy / kTile);
+  int rest = (int)(ldy - (int64_t)nt_main * kTile);
+  if (!tail || rest > 256) { nt_main += rest ? 1 : 0; rest = 0; }
+  const int tiles_total = nt_main + (rest ? 1 : 0);
+  if (amax) amax->n = channels * tiles_total;
+  unsigned* ap = amax ? amax->p : nullptr;
+  const int as = amax ? amax->stride : 0;
+  if (nt_main) {
+    dim3 grid(channels / 4, n_pairs, nt_main);
+    VASR_LAUNCH_PART(true, rest == 0, (dw_pair_kernel<K, DIL, 1>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels,
+                     batch, y, ldy, ap, as, 0, 0, tiles_total);
+  }
+  if (rest == 128) {
+    dim3 grid(channels / 4, (n_pairs + 3) / 4, 1);
+    VASR_LAUNCH_PART(nt_main == 0, true, (dw_pair_kernel<K, DIL, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels,
+                     batch, y, ldy, ap, as, nt_main * kTile, nt_main, tiles_total);
+  } else if (rest == 256) {
+    dim3 grid(channels / 4, (n_pairs + 1) / 2, 1);
+    VASR_LAUNCH_PART(nt_main == 0, true, (dw_pair_kernel<K, DIL, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels,
+                     batch, y, ldy, ap, as, nt_main * kTile, nt_main, tiles_total);
+  }
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.

@@ -23,6 +23,19 @@ extern thread_local LaunchProbe g_probe;
     }                                                                                                      \
   } while (0)
 
+// One logical layer issued as several launches (full tiles + tail): the first launch carries the probe's start event, the
+// last its stop event, so the bracket covers all of them (and the dispatch gaps between them).
+#define VASR_LAUNCH_PART(first, last, kern, grid, block, lds, st, ...)                                     \
+  do {                                                                                                     \
+    if (::vasr::g_probe.start) {                                                                           \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, (first) ? ::vasr::g_probe.start : nullptr,         \
+                            (last) ? ::vasr::g_probe.stop : nullptr, 0, __VA_ARGS__);                      \
+      if (last) ::vasr::g_probe.start = nullptr;                                                           \
+    } else {                                                                                               \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                         \
+    }                                                                                                      \
+  } while (0)
+
 // Activations live in HBM as [B][C][ld] fp32 with the time axis contiguous and
 // ld = pad_frames(T): every row starts 512-byte aligned and every (32..128)-frame GEMM tile stays
 // inside one utterance.  Columns t >= T are padding (never consumed unmasked).
