@@ -226,16 +226,16 @@ struct PairGeom {
 // 6-7 short-lived wavefronts per SIMD resident, so there is no row loop.)
 // t_base: first frame of this launch's tile 0; tile0 / tiles_total: this launch's tiles in the layer's numbering (slots of
 // the maxima table are c * tiles_total + tile).
+// One workgroup's work: `group` = index of its SUB pairs, `tile` = time tile (512 frames each; a SUB > 1 tile is the short one
+// that starts at 512 * tile), slots of the maxima table are c * tiles_total + tile.
 template <int K, int DIL, int SUB>
-__global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ x, int64_t ldx,
-                                                      const float* __restrict__ w,
-                                                      const int32_t* __restrict__ lens_in,
-                                                      const int32_t* __restrict__ lens_out, int channels, int batch,
-                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
-                                                      int amax_stride, int t_base, int tile0, int tiles_total) {
+__device__ __forceinline__ void dw_pair_body(v4f* __restrict__ lds4, const float* __restrict__ x, int64_t ldx,
+                                             const float* __restrict__ w, const int32_t* __restrict__ lens_in,
+                                             const int32_t* __restrict__ lens_out, int channels, int batch,
+                                             float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
+                                             int amax_stride, int group, int tile, int tiles_total) {
   using G = PairGeom<K, DIL, SUB>;
   constexpr int NLD = G::NLD, LP = G::LP;
-  __shared__ v4f lds4[4 * G::PHYS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // (Mapping workgroups to XCDs so that XCD k gets the utterances the GEMM kernels give it was measured: depthwise
@@ -243,12 +243,12 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
   const int c = blockIdx.x * 4 + wave;
   const int sub = SUB == 1 ? 0 : lane / LP, ll = SUB == 1 ? lane : lane % LP;   // pair of this lane, lane inside the pair
   const int n_pairs = (batch + 1) / 2;
-  const int pp = blockIdx.y * SUB + sub;
+  const int pp = group * SUB + sub;
   const bool live = SUB == 1 || pp < n_pairs;                       // SUB > 1: the last wavefront may hold fewer pairs
   const int b0 = 2 * (live ? pp : n_pairs - 1);                     // (idle lanes compute the last pair again and store nothing)
   const bool twin = b0 + 1 < batch;
   const int b1 = twin ? b0 + 1 : b0;
-  const int t_start = t_base + blockIdx.z * kTile;
+  const int t_start = tile * kTile;
   v4f* win = lds4 + wave * G::PHYS + sub * G::PHYS_SUB;
 
   // ---- staging: both rows, branch-free (clamped address + selects), all loads in flight together ----
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     }
   }
   if (amax) {   // masked outputs only (zeros past lens_out): the maximum over the utterance's valid frames
-    const int slot = c * tiles_total + tile0 + blockIdx.z;
+    const int slot = c * tiles_total + tile;
     if constexpr (SUB == 1) {
       amax_publish(amax, amax_stride, b0, slot, m0, lane);
       if (twin) amax_publish(amax, amax_stride, b1, slot, m1, lane);
@@ -402,12 +402,36 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
 #pragma unroll
         for (int sp = 0; sp < SUB; ++sp) {
           const unsigned ms = SUB == 4 ? r[sp] : max(r[2 * sp], r[2 * sp + 1]);
-          const int bq0 = 2 * (blockIdx.y * SUB + sp) + u;
+          const int bq0 = 2 * (group * SUB + sp) + u;
           if (lane == 0 && bq0 < batch) amax[(int64_t)bq0 * amax_stride + slot] = ms;
         }
       }
 #undef VASR_DPP
     }
+  }
+}
+
+// grid (C/4, pairs, tiles): tiles below nt_main are full 512-frame tiles (one pair per wavefront); the last one, when
+// SUBT > 1, is the short tail (SUBT pairs per wavefront: only the first ceil(pairs / SUBT) workgroups of the row have work).
+// ONE launch for both: as a launch of its own the tail cost almost a full tile (few, latency-bound wavefronts plus a
+// dispatch gap: 0.88 of 1.05 ms per step at 10.3 s clips); inside the main launch its wavefronts run beside the others.
+template <int K, int DIL, int SUBT>
+__global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ w,
+                                                      const int32_t* __restrict__ lens_in,
+                                                      const int32_t* __restrict__ lens_out, int channels, int batch,
+                                                      float* __restrict__ y, int64_t ldy, unsigned* __restrict__ amax,
+                                                      int amax_stride, int nt_main) {
+  constexpr int PHYS = PairGeom<K, DIL, 1>::PHYS > PairGeom<K, DIL, SUBT>::PHYS ? PairGeom<K, DIL, 1>::PHYS : PairGeom<K, DIL, SUBT>::PHYS;
+  __shared__ v4f lds4[4 * PHYS];
+  const int tile = blockIdx.z, tiles_total = gridDim.z;
+  if (SUBT == 1 || tile < nt_main) {
+    dw_pair_body<K, DIL, 1>(lds4, x, ldx, w, lens_in, lens_out, channels, batch, y, ldy, amax, amax_stride, blockIdx.y, tile,
+                            tiles_total);
+  } else {
+    if ((int)blockIdx.y * SUBT >= (batch + 1) / 2) return;
+    dw_pair_body<K, DIL, SUBT>(lds4, x, ldx, w, lens_in, lens_out, channels, batch, y, ldy, amax, amax_stride, blockIdx.y,
+                               tile, tiles_total);
   }
 }
 
@@ -425,20 +449,13 @@ void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* 
   if (amax) amax->n = channels * tiles_total;
   unsigned* ap = amax ? amax->p : nullptr;
   const int as = amax ? amax->stride : 0;
-  if (nt_main) {
-    dim3 grid(channels / 4, n_pairs, nt_main);
-    VASR_LAUNCH_PART(true, rest == 0, (dw_pair_kernel<K, DIL, 1>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels,
-                     batch, y, ldy, ap, as, 0, 0, tiles_total);
-  }
-  if (rest == 128) {
-    dim3 grid(channels / 4, (n_pairs + 3) / 4, 1);
-    VASR_LAUNCH_PART(nt_main == 0, true, (dw_pair_kernel<K, DIL, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels,
-                     batch, y, ldy, ap, as, nt_main * kTile, nt_main, tiles_total);
-  } else if (rest == 256) {
-    dim3 grid(channels / 4, (n_pairs + 1) / 2, 1);
-    VASR_LAUNCH_PART(nt_main == 0, true, (dw_pair_kernel<K, DIL, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels,
-                     batch, y, ldy, ap, as, nt_main * kTile, nt_main, tiles_total);
-  }
+  dim3 grid(channels / 4, n_pairs, tiles_total);
+  if (rest == 128)
+    VASR_LAUNCH((dw_pair_kernel<K, DIL, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
+  else if (rest == 256)
+    VASR_LAUNCH((dw_pair_kernel<K, DIL, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
+  else
+    VASR_LAUNCH((dw_pair_kernel<K, DIL, 1>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
