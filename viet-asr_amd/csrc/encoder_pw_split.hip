@@ -341,6 +341,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   }
   __syncthreads();
 
+#ifndef VASR_PW_FILLER
+#define VASR_PW_FILLER 0
+#endif
+#if VASR_PW_FILLER
+  float fill[8], fill_a = 1.0f + 1e-7f * tid, fill_b = 1e-9f * lane;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) fill[f] = (float)(tid + f);
+#endif
   // One K chunk c.  `cur` holds the rows of chunk c + 1 (requested one chunk ago), `nxt` receives those of chunk c + 2.
   // LAST = false: request, convert a share of `cur` per k-step into the idle LDS buffer -- unconditionally, no branch
   // anywhere in this body (with one the compiler merges the paths' load counters and waits for everything, vmcnt(0),
@@ -396,6 +404,13 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
+#if VASR_PW_FILLER
+        // dev-only experiment (dw -> pw fusion budget): VASR_PW_FILLER independent v_fma_f32 per MFMA of this n-tile group,
+        // the VALU work a fused depthwise would have to co-issue (8.5 per MFMA at K = 51, 12.5 at K = 75 for kF16x2)
+#pragma unroll
+        for (int f = 0; f < VASR_PW_FILLER * TM * (ARITH == kBf16x3 ? 6 : 3); ++f)
+          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fill[f & 7]) : "v"(fill_a), "v"(fill_b));
+#endif
         // this k-step's share of the next chunk's conversion, after the step's first n-tile: the scheduler spreads
         // it under the MFMAs that follow
         if (!LAST && !(VASR_ABLATE & 4) && j == (VASR_PW_CVT_AT < TN ? VASR_PW_CVT_AT : TN - 1)) {
@@ -430,6 +445,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
     }
   }
 
+#if VASR_PW_FILLER
+  {
+    float fsum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fsum += fill[f];
+    if (fsum == 12345.678f) acc[0][0][0] += fsum;   // keeps the filler registers alive
+  }
+#endif
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
   // max |y| over the utterance's VALID output frames, for the split of the next kF16x2 consumer of y
