@@ -318,11 +318,12 @@ print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
                                  {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"},
                                  {"VASR_GEMM": "f16x2", "VASR_DW_PAIR": "0"}, {"VASR_GEMM": "f16x2", "VASR_NO_FUSED_RESIDUAL": "1"},
                                  {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "2"}, {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "3"},
-                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "4"}, {"VASR_GEMM": "f16x2", "VASR_DW_MFMA": "1"}],
+                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "4"}, {"VASR_DW_MFMA": "0"}, {"VASR_DW_UPW": "3"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):
-    """The kernels a default run does not pick (one-row depthwise, two-GEMM residual, latency GEMM tiles, batch slices
-    on side streams) are selected by environment variables read once per process: run each in a child process."""
+    """The kernels a default run does not pick (one-row depthwise, packed-FMA depthwise under the fp16-split GEMMs,
+    two-GEMM residual, latency GEMM tiles, batch slices on side streams) are selected by environment variables read
+    once per process: run each in a child process."""
     import os
     import subprocess
     import sys
@@ -527,10 +528,12 @@ def test_real_recordings_through_vietasr(gpu, tmp_path, name):
 
 
 @pytest.mark.parametrize("K,dil,C,B,T,ragged", [(33, 1, 256, 5, 501, True), (39, 1, 256, 2, 130, False), (51, 1, 512, 4, 1300, True),
-                                                (63, 1, 512, 3, 516, True), (75, 1, 512, 6, 501, False), (87, 2, 512, 3, 777, True)])
+                                                (63, 1, 512, 3, 516, True), (75, 1, 512, 6, 501, False), (87, 2, 512, 3, 777, True),
+                                                (75, 1, 512, 65, 501, True), (33, 1, 256, 21, 1030, True)])
 def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B, T, ragged):
     """encoder_dw_mfma.hip (Toeplitz form, fp16-split operands) on one isolated layer against a float64 depthwise
-    convolution of the masked input: odd batches (the last utterance pairs with itself), several 512-frame tiles,
+    convolution of the masked input: utterance counts that do not fill a wavefront's walk (8, 4 or 2 utterances per
+    wavefront; the last one is then computed twice), several 512-frame tiles, a last tile of one 256-frame group,
     ragged lengths (input mask, output zeroed past the length), dilation 2; error bounded like the packed-FMA kernel's
     (2e-6 of the largest output), which is run beside it where it exists (dilation 1); published maxima exact."""
     import ctypes as C_

@@ -5,21 +5,29 @@
 // VALU-issue bound from K = 51 up (600 v_pk_fma_f32 per wavefront-pass at K = 75: 23 us of pure issue per 512-channel
 // layer against 17-20 us of copy-speed traffic).  Here the taps of ONE channel are laid out as a banded matrix
 //
-//     A[m][j] = w[(j - m - OFF) / DIL]     (0 where that is not a tap)        m = 0..31 output offset inside a window
+//     A[m][j] = w[(j - m - OFF) / DIL]     (0 where that is not a tap)        m = 0..15 output offset inside a window
 //
-// and 32 windows of 32 consecutive outputs -- 16 windows = 512 frames of each of TWO utterances -- are its right-hand
-// sides: B[j][n] = x_n[t_n - PADL + j], eight consecutive samples per lane and k-step, so every B fragment is one
-// aligned 16-byte LDS read.  One v_mfma_f32_32x32x16 then produces 32 x 32 outputs from a 16-sample slice of the windows:
-// a K = 75 kernel spans 31 + 74 + OFF + 1 = 109 window samples = 7 k-steps.  Arithmetic as in the fp16-split GEMM
+// and 16 windows of 16 consecutive outputs -- 256 frames of one utterance -- are its right-hand sides:
+// B[j][n] = x[t0 + 16 n - PADL + j], eight consecutive samples per lane and k-step, so every B fragment is one aligned
+// 16-byte LDS read of a plainly linear fp16 row (the lane groups of ds_read_b128 land on distinct 16-byte slots without
+// any padding).  One v_mfma_f32_16x16x32 then produces 16 x 16 outputs from a 32-sample slice of the windows: a K = 75
+// kernel spans 15 + 74 + OFF + 1 = 93 window samples = 3 k-steps.  Arithmetic as in the fp16-split GEMM
 // (encoder_pw_split.hip, kF16x2): operands scaled by a power of two (taps per channel, samples per utterance -- from the
 // maxima the producing GEMM published) and split into two fp16 terms, three products per k-step, fp32 accumulation:
-// 21 MFMAs for 1024 outputs x 75 taps instead of 600 packed FMAs, 5 us of matrix time per 512-channel layer.  What is
-// left is the HBM traffic: each sample is read once (16-byte coalesced loads), converted once, and every store
-// instruction writes 1 KB of one row (the accumulators are transposed through LDS).
+// 9 MFMAs of 16 cycles for 256 outputs x 75 taps instead of 150 packed FMAs of 4-8 cycles.
 //
-//   grid (C / 4, ceil(pairs / kPairsPerWave), ceil(ldy / 512)), block 256 = 4 wavefronts = 4 channels; a wavefront builds
-//   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks kPairsPerWave
-//   utterance pairs with them, the next pair's rows in flight while the current pair is multiplied.
+// Round 2 first built this on v_mfma_f32_32x32x16 (32 windows of 32 outputs, two utterances per task): 7 k-steps at
+// K = 75 = 112 VGPRs of A fragments, 16 accumulators per lane that had to be transposed through LDS before a store could
+// write rows, ~500 instructions per 1024 outputs at under two wavefronts per SIMD -- 30-36 us per 512-channel layer,
+// slower than the packed-FMA kernels.  The 16 x 16 x 32 shape fixes all three: 24 VGPRs of A
+// fragments, and its D layout (lane = window n + 16 g, registers = outputs 4 g .. 4 g + 3) already holds four
+// CONSECUTIVE frames per lane, so one lane rotation (4 ds_bpermute_b32, no LDS storage, no barrier) makes every store
+// instruction write 1 KB of one row.
+//
+//   grid (C / 4, ceil(B / utterances per wave), ceil(ldy / 512)), block 256 = 4 wavefronts = 4 channels; a wavefront builds
+//   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks its utterances
+//   with them, 512 frames (two MFMA groups sharing one staged row) per utterance, the rows of the next TWO utterances in
+//   flight while the current one is multiplied.
 #include <cstdlib>
 
 #include "vasr_internal.h"
@@ -29,40 +37,40 @@ namespace vasr {
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using v4f = __attribute__((ext_vector_type(4))) float;
 using v2f = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((vector_size(16))) unsigned int;
 
 #ifndef VASR_TZ_ABLATE
 #define VASR_TZ_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no MFMAs, 2 no global stores, 4 no conversion /
-#endif                     // LDS staging, 8 no row loads, 16 no transposition epilogue at all, 32 no maxima publishing
-constexpr int kTile = 512;          // output frames per utterance and task: 16 windows of 32
-// Utterance pairs one wavefront walks with its channel's A fragments.  8: a 64-utterance batch gives 2048 wavefronts per
-// 512-channel layer, all resident at once (8 per CU), each streaming its pairs with the next TWO pairs' rows in flight --
-// with 2 (and one pair ahead) the kernel took 30 us per layer whatever K: every wavefront paid the fragment set-up and an
-// exposed HBM round trip per pair.
-constexpr int kPairsPerWave = 8;   // upper bound; the launch passes the count in use (VASR_DW_PPW, default below)
+#endif                     // LDS staging, 8 no row loads, 16 no lane rotation, 32 no maxima publishing
+constexpr int kTile = 512;          // output frames per task: 2 groups of 16 windows x 16 outputs
+constexpr int kGroup = 256;
+constexpr int kUttPerWave = 8;      // upper bound; the launch passes the count in use
+#ifndef VASR_TZ_STAGES
+#define VASR_TZ_STAGES 2   // 3 and 4 measured 25-30 % SLOWER (31 us against 24.4 at K = 75): more rows in flight only queue up
+#endif
 
 template <int K, int DIL>
 struct TzGeom {
   static constexpr int PAD = DIL > 1 ? (DIL * K) / 2 - 1 : K / 2;   // get_same_padding (jasper.py:60-65)
-  static constexpr int PADL = (PAD + 7) & ~7;                       // window origin: 8-sample aligned
+  static constexpr int PADL = (PAD + 3) & ~3;                       // staged row origin: 16-byte aligned in x
   static constexpr int OFF = PADL - PAD;
-  static constexpr int SPAN = 31 + DIL * (K - 1) + OFF + 1;         // window samples one 32-output window touches
-  static constexpr int NS = (SPAN + 15) / 16;                       // k-steps
-  static constexpr int TSZ = (16 * NS + 31 + 3) & ~3;               // tap-table entries: entry i = dense tap i - (31 + OFF)
-  static constexpr int NBLK = 15 + (NS + 1) / 2;                    // 32-sample blocks of one staged row
-  static constexpr int ROWS = 32 * NBLK;                            // samples staged per utterance
-  static constexpr int NLD = (ROWS / 4 + 63) / 64;                  // float4 loads per lane and utterance
-  static constexpr int UROW = (80 * NBLK + 255) & ~255;             // bytes of one plane of one utterance (80 B per block)
-  static constexpr int LDS_DATA = 2 * 2 * UROW;                     // [utterance][plane]
+  static constexpr int SPAN = 15 + DIL * (K - 1) + OFF + 1;         // window samples one 16-output window touches
+  static constexpr int NS = (SPAN + 31) / 32;                       // k-steps
+  static constexpr int STAGES = NS > 3 ? 2 : VASR_TZ_STAGES;        // rows in flight per wavefront (NLD float4 registers each)
+  static constexpr int TSZ = 32 * NS + 16;                          // tap-table entries: entry i = dense tap i - (15 + OFF)
+  static constexpr int ROWS = kTile - 16 + 32 * NS;                 // samples staged per task
+  static constexpr int NLD = (ROWS / 4 + 63) / 64;                  // float4 loads per lane and task
+  static constexpr int PLANE = 2 * 256 * NLD;                       // bytes of one fp16 plane (every lane stores, no branch)
+  static constexpr int LDS_DATA = 2 * PLANE;                        // [hi | lo]
   static constexpr int LDS_TAB = 4 * TSZ;
-  static constexpr int ORS = 144;                                   // output transposition: bytes per 32-float row
-  static constexpr int LDS_OUT = 32 * ORS;
-  static constexpr int LDS_SCL = 16 * kPairsPerWave;                // per pair: (scale, 1 / scale) of both utterances
-  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_OUT + LDS_SCL;
+  static constexpr int LDS_SCL = 8 * kUttPerWave;                   // per utterance: (scale, 1 / scale)
+  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_SCL;
+  static_assert(ROWS % 4 == 0 && LDS_WAVE % 16 == 0, "staging granularity");
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -70,8 +78,11 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float lane_pull(int src4, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v)));
 }
 
 template <int K, int DIL>
@@ -83,180 +94,176 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
                                                           const unsigned* __restrict__ amax_x, int amax_x_stride,
                                                           int amax_x_n, int channels, int batch,
                                                           float* __restrict__ y, int64_t ldy,
-                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int ppw) {
+                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int upw) {
   using G = TzGeom<K, DIL>;
-  constexpr int NS = G::NS, NLD = G::NLD;
+  constexpr int NS = G::NS, NLD = G::NLD, kStages = G::STAGES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* base = lds_raw + wave * G::LDS_WAVE;
-  unsigned char* dat = base;                                               // [u][plane][UROW]
+  unsigned char* dat = base;                                               // [plane][PLANE]
   unsigned* tab = reinterpret_cast<unsigned*>(base + G::LDS_DATA);
-  unsigned char* outb = base + G::LDS_DATA + G::LDS_TAB;
-  float4* scl = reinterpret_cast<float4*>(base + G::LDS_DATA + G::LDS_TAB + G::LDS_OUT);
+  float2* scl = reinterpret_cast<float2*>(base + G::LDS_DATA + G::LDS_TAB);
   const int c = blockIdx.x * 4 + wave;
   const int t_tile = blockIdx.z * kTile;
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int n_pairs = (batch + 1) / 2;
-  const int p_lo = blockIdx.y * ppw;
-  const int p_hi = min(p_lo + ppw, n_pairs);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int b_lo = blockIdx.y * upw;
+  const int b_hi = min(b_lo + upw, batch);
+  if (b_lo >= b_hi) return;
+  const bool two = t_tile + kGroup < ldy;   // the second group has columns to write (wave-uniform)
 
   uint4 ah[NS], al[NS];   // A fragments of this channel (built below, after the first rows have been requested)
   const float w_inv = tap_inv[c];
 
-  // ---- staging of one utterance pair: both rows, branch-free, all loads in flight together; the producers' maxima of
-  //      the two utterances ride along (one word per lane and 64 slots) ----
-  // The kernel is instruction-issue bound (round-2 ablations: ~500 instructions per pair at ~4.5 cycles each), so every
-  // mask and address computation that hardware can do is handed to it: rows are read through raw buffer descriptors
-  // whose range is the utterance's length -- MaskedConv1d's x.masked_fill(t >= lens, 0) (jasper.py:113-118) and the
-  // conv's zero padding left of frame 0 (a negative offset is a huge unsigned one) both come back as zeros, per dword.
-  struct Stage { v4f r0[NLD], r1[NLD]; };
+  // ---- staging of one task's row: branch-free, all loads in flight together ----
+  // Every mask and address computation that hardware can do is handed to it: rows are read through raw buffer
+  // descriptors whose range is the utterance's length -- MaskedConv1d's x.masked_fill(t >= lens, 0) (jasper.py:113-118)
+  // and the conv's zero padding left of frame 0 (a negative offset is a huge unsigned one) both come back as zeros, per
+  // dword; so do the lanes past the staged row (offset 2^31).  The offsets depend on the tile only: computed once.
+  struct Stage { v4f r[NLD]; };
+  int voff[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int tau = 4 * (lane + 64 * j);
+    voff[j] = tau < G::ROWS ? 4 * (t_tile - G::PADL + tau) : (int)0x80000000u;
+  }
   const int64_t row_stride = (int64_t)channels * ldx;                 // floats between utterances of one channel
-  const float* xrow = x + ((int64_t)(2 * p_lo) * channels + c) * ldx;   // row of the first utterance of pair p_lo
+  const float* xrow = x + ((int64_t)b_lo * channels + c) * ldx;
   const int64_t yrow_stride = (int64_t)channels * ldy;
-  float* yrow0 = y + ((int64_t)(2 * p_lo) * channels + c) * ldy;
-  auto gload = [&](int p, Stage& sg) {
-    const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
-    const float* xr0 = xrow + (int64_t)(b0 - 2 * p_lo) * row_stride;
-    const float* xr1 = xrow + (int64_t)(b1 - 2 * p_lo) * row_stride;
-    // (lengths through the scalar cache: the descriptor words must be wave-uniform for the compiler, or every load
+  float* yrow0 = y + ((int64_t)b_lo * channels + c) * ldy;
+  auto gload = [&](int b, Stage& sg) {
+    const float* xr = xrow + (int64_t)(b - b_lo) * row_stride;
+    // (length through the scalar cache: the descriptor words must be wave-uniform for the compiler, or every load
     // becomes a waterfall loop)
-    const auto d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr0), 0, 4 * min(lens_in[b0], (int)ldx), 0x00020000);
-    const auto d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr1), 0, 4 * min(lens_in[b1], (int)ldx), 0x00020000);
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr), 0, 4 * min(lens_in[b], (int)ldx), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int off = 4 * (t_tile - G::PADL + 4 * (lane + 64 * j));
-      if (!(VASR_TZ_ABLATE & 8)) {
-        sg.r0[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d0, off, 0, 0));
-        sg.r1[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d1, off, 0, 0));
-      } else {
-        sg.r0[j] = v4f{(float)off, 1.f, 2.f, 3.f};
-        sg.r1[j] = v4f{(float)off, 3.f, 2.f, 1.f};
-      }
+      if (!(VASR_TZ_ABLATE & 8)) sg.r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d, voff[j], 0, 0));
+      else sg.r[j] = v4f{(float)voff[j], 1.f, 2.f, 3.f};
     }
   };
-  // scale by the utterance's power of two, split into fp16 hi / lo, 8 + 8 bytes into the two planes
-  auto sstore = [&](const v4f (&sv)[NLD], int u, float sx) {
-    unsigned char* ph = dat + (u * 2 + 0) * G::UROW;
-    unsigned char* pl = dat + (u * 2 + 1) * G::UROW;
-    // Branch-free: a lane past the staged row (last slab only) writes into the 16 spare bytes behind it.  With a
-    // lane-dependent branch here the compiler cannot tell, where the paths merge, whether the skipped lanes' loads have
-    // been waited for, and drains the vector-memory counter (vmcnt(0)) before the next prefetch overwrites the stage
-    // registers -- which also waits for the OTHER stage's rows and for the previous pair's stores: no prefetch at all.
-    static_assert(G::UROW - 80 * G::NBLK >= 16, "no spare bytes behind the staged row");
+  // scale by the utterance's power of two, split into fp16 hi / lo, 8 + 8 bytes into the two planes: sample tau at byte
+  // 2 tau.  EVERY lane stores (the planes hold 256 NLD samples): with a lane-dependent branch here the compiler cannot
+  // tell, where the paths merge, whether the skipped lanes' loads have been waited for, and drains the vector-memory
+  // counter (vmcnt(0)) before the next prefetch overwrites the stage registers -- no prefetch at all.
+  auto sstore = [&](const Stage& sg, float sx) {
+    unsigned char* ph = dat + 8 * lane;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int tau = 4 * (lane + 64 * j);
-      {
-        const v4f v = sv[j];
-        const v2f a = {v.x * sx, v.y * sx}, b = {v.z * sx, v.w * sx};
-        const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-        const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, v2f), f16x2);
-        const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, v2f), f16x2);
-        const int off = tau < G::ROWS ? 80 * (tau >> 5) + 2 * (tau & 31) : 80 * G::NBLK + 8 * (lane & 1);
-        *reinterpret_cast<uint2*>(ph + off) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-        *reinterpret_cast<uint2*>(pl + off) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-      }
+      const v4f v = sg.r[j];
+      const v2f a = {v.x * sx, v.y * sx}, b = {v.z * sx, v.w * sx};
+      const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+      const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, v2f), f16x2);
+      const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, v2f), f16x2);
+      *reinterpret_cast<uint2*>(ph + 512 * j) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+      *reinterpret_cast<uint2*>(ph + G::PLANE + 512 * j) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
     }
   };
 
-  // B fragments: lane (n' = l31, kh): utterance u = n' / 16, window n = n' % 16 -> samples 32 n + 16 s + 8 kh + e
-  const unsigned char* bb = dat + (l31 >> 4) * 2 * G::UROW + 80 * (l31 & 15) + 16 * kh;
-  unsigned char* orow = outb + l31 * G::ORS + 16 * kh;   // transposition: lane writes row n', floats 8 q + 4 kh .. + 3
+  // B fragments: lane (n, kg), group q, step s -> samples 256 q + 16 n + 32 s + 8 kg + e of the staged row
+  const unsigned char* bb = dat + 32 * n16 + 16 * kg;
+  // D fragment: lane n + 16 g holds frames 16 n + 4 g .. + 3; lane L pulls the registers of lane (L >> 2) + 16 (L & 3) and
+  // then holds frames 4 L .. 4 L + 3
+  const int pull = 4 * ((lane >> 2) + 16 * (lane & 3));
+  const int slot = c * gridDim.z + blockIdx.z;
+  const int am_off = lane == 0 ? 4 * slot : (int)0x80000000u;   // one word per wavefront, no branch around the store
 
-  // One pair: convert the staged rows, refill the stage with the pair two ahead, multiply, store.
-  auto do_pair = [&](int p, Stage& sg) {
-    const int b0 = 2 * p;
-    const bool twin = b0 + 1 < batch;
-    const int b1 = twin ? b0 + 1 : b0;
-    const float4 sc = scl[p - p_lo];   // (scale, 1 / scale) of both utterances: LDS broadcast, no vector-memory wait
-    const float sx0 = sc.x, ix0 = sc.y, sx1 = sc.z, ix1 = sc.w;
-    if (!(VASR_TZ_ABLATE & 4)) {
-      sstore(sg.r0, 0, sx0);
-      sstore(sg.r1, 1, sx1);
-    } else {
-      asm volatile("" :: "v"(sg.r0[0]), "v"(sg.r1[NLD - 1]));
-    }
-    // The pair two ahead, in flight while this pair and the next are multiplied and stored.  UNCONDITIONAL (past the end
-    // the last pair is requested again): s_waitcnt vmcnt counts outstanding operations, so the compiler can only leave
-    // the other stage's rows in flight if it knows how many younger loads there are on every path.
-    gload(min(p + 2, p_hi - 1), sg);
+  auto do_task = [&](int b, Stage& sg) {
+    const float2 sc = scl[b - b_lo];   // (scale, 1 / scale): LDS broadcast, no vector-memory wait
+    if (!(VASR_TZ_ABLATE & 4)) sstore(sg, sc.x);
+    else asm volatile("" :: "v"(sg.r[0]), "v"(sg.r[NLD - 1]));
+    // The utterance kStages ahead, in flight while this one and the next ones are multiplied and stored.  UNCONDITIONAL
+    // (past the end the last one is requested again): s_waitcnt vmcnt counts outstanding operations, so the compiler can
+    // only leave the other stages' rows in flight if it knows how many younger operations there are on every path.
+    gload(min(b + kStages, b_hi - 1), sg);
     wave_sync();
 
-    f32x16 acc;
+    // All B fragments of the task are requested before the first multiply (one exposed LDS round trip per task instead of
+    // one per k-step), and the two groups' accumulation chains alternate on the matrix pipe.
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#ifndef VASR_TZ_ALLB
+#define VASR_TZ_ALLB 1
+#endif
+    constexpr bool kAllB = VASR_TZ_ALLB && NS <= 3;   // 16 NS registers of B fragments for both groups
+    auto load_b = [&](int q, uint4 (&bh)[NS], uint4 (&bl)[NS]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int off = 80 * (s >> 1) + 32 * (s & 1);
-      const uint4 bh = *reinterpret_cast<const uint4*>(bb + off);
-      const uint4 bl = *reinterpret_cast<const uint4*>(bb + G::UROW + off);
+      for (int s = 0; s < NS; ++s) {
+        bh[s] = *reinterpret_cast<const uint4*>(bb + 2 * kGroup * q + 64 * s);
+        bl[s] = *reinterpret_cast<const uint4*>(bb + G::PLANE + 2 * kGroup * q + 64 * s);
+      }
+    };
+    auto step = [&](f32x4 acc, int s, const uint4 (&bh)[NS], const uint4 (&bl)[NS]) {
       if (!(VASR_TZ_ABLATE & 1)) {
-        acc = mma(al[s], bh, acc);
-        acc = mma(ah[s], bl, acc);
-        acc = mma(ah[s], bh, acc);
+        acc = mma(al[s], bh[s], acc);
+        acc = mma(ah[s], bl[s], acc);
+        acc = mma(ah[s], bh[s], acc);
       } else {
-        acc[s & 15] += __uint_as_float(bh.x ^ bl.y ^ al[s].x ^ ah[s].y);
+        acc[s & 3] += __uint_as_float(bh[s].x ^ bl[s].y ^ al[s].x ^ ah[s].y);
+      }
+      return acc;
+    };
+    {
+      uint4 b0h[NS], b0l[NS], b1h[NS], b1l[NS];
+      load_b(0, b0h, b0l);
+      if (kAllB && two) {
+        load_b(1, b1h, b1l);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc0 = step(acc0, s, b0h, b0l);
+          acc1 = step(acc1, s, b1h, b1l);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc0 = step(acc0, s, b0h, b0l);
+        if (two) {
+          load_b(1, b1h, b1l);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) acc1 = step(acc1, s, b1h, b1l);
+        }
       }
     }
 
-    // ---- epilogue: unscale, transpose through LDS, zero past lens_out, 1 KB of one row per store instruction ----
-    const float os = w_inv * (l31 < 16 ? ix0 : ix1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4f o = {acc[4 * q] * os, acc[4 * q + 1] * os, acc[4 * q + 2] * os, acc[4 * q + 3] * os};
-      *reinterpret_cast<v4f*>(orow + 32 * q) = o;
+    // ---- epilogue: unscale, rotate lanes, zero past lens_out, 1 KB of one row per store instruction ----
+    const float os = w_inv * sc.y;
+    const int lo = lens_out[b];   // scalar load
+    float* yr = yrow0 + (int64_t)(b - b_lo) * yrow_stride;
+    // columns >= ldy are dropped by the descriptor's range, like the whole second group of a tile that has none
+    const auto dy = __builtin_amdgcn_make_buffer_rsrc(yr, 0, 4 * (int)ldy, 0x00020000);
+    v4f o0 = {acc0[0] * os, acc0[1] * os, acc0[2] * os, acc0[3] * os};
+    v4f o1 = {acc1[0] * os, acc1[1] * os, acc1[2] * os, acc1[3] * os};
+    if (!(VASR_TZ_ABLATE & 16)) {   // all eight pulls in flight together
+      o0.x = lane_pull(pull, o0.x); o0.y = lane_pull(pull, o0.y); o0.z = lane_pull(pull, o0.z); o0.w = lane_pull(pull, o0.w);
+      o1.x = lane_pull(pull, o1.x); o1.y = lane_pull(pull, o1.y); o1.z = lane_pull(pull, o1.z); o1.w = lane_pull(pull, o1.w);
     }
-    wave_sync();
-    // Read back as rows: lanes 0-31 take utterance 0 (windows 0-15), lanes 32-63 utterance 1 -- 2 x 512 contiguous
-    // bytes per store instruction, and ONE row-wise reduction yields both utterances' maxima (rows 0-1 / rows 2-3).
-    const int u = lane >> 5;
-    const int lo0 = lens_out[b0], lo1 = lens_out[b1];   // scalar loads
-    const int lo_u = u ? lo1 : lo0;
-    float* y0 = yrow0 + (int64_t)(b0 - 2 * p_lo) * yrow_stride;
-    float* y1 = yrow0 + (int64_t)(b1 - 2 * p_lo) * yrow_stride;
-    float* yrow = u ? y1 : y0;
-    const bool live = u == 0 || twin;
     float mx = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      // float4 index (lane & 31) + 32 ps inside the utterance's 16 x 8 float4 -> row (window) of the block, column 4 (idx % 8)
-      const int idx = (lane & 31) + 32 * ps, row = idx >> 3;
-      v4f v = *reinterpret_cast<const v4f*>(outb + (16 * u + row) * G::ORS + 16 * (idx & 7));
-      const int t = t_tile + 32 * row + 4 * (idx & 7);
-      const int nv = lo_u - t;
-      v.x = nv > 0 ? v.x : 0.f;
-      v.y = nv > 1 ? v.y : 0.f;
-      v.z = nv > 2 ? v.z : 0.f;
-      v.w = nv > 3 ? v.w : 0.f;
-      if (t < ldy && live && (!(VASR_TZ_ABLATE & 2) || v.x == 12345.678f)) {
-        *reinterpret_cast<v4f*>(yrow + t) = v;
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    auto finish = [&](v4f o, int q) {
+      const int tq = t_tile + kGroup * q;
+      if (lo < tq + kGroup) {   // wave-uniform: only the group that straddles the utterance's end masks per element
+        const int nv = lo - tq - 4 * lane;
+        o.x = nv > 0 ? o.x : 0.f;
+        o.y = nv > 1 ? o.y : 0.f;
+        o.z = nv > 2 ? o.z : 0.f;
+        o.w = nv > 3 ? o.w : 0.f;
       }
-    }
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+      if (!(VASR_TZ_ABLATE & 2))
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 0);
+      else
+        asm volatile("" :: "v"(o));
+    };
+    finish(o0, 0);
+    finish(o1, 1);
     if (amax_y && !(VASR_TZ_ABLATE & 32)) {
-      unsigned m = __float_as_uint(mx);   // |x| bit patterns order like unsigned integers
-#define VASR_DPP(xx, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(xx), (ctrl), 0xF, 0xF, false))
-      m = max(m, VASR_DPP(m, 0xB1));
-      m = max(m, VASR_DPP(m, 0x4E));
-      m = max(m, VASR_DPP(m, 0x141));
-      m = max(m, VASR_DPP(m, 0x140));
-#undef VASR_DPP
-      const unsigned m0 = max((unsigned)__builtin_amdgcn_readlane((int)m, 0), (unsigned)__builtin_amdgcn_readlane((int)m, 16));
-      const unsigned m1 = max((unsigned)__builtin_amdgcn_readlane((int)m, 32), (unsigned)__builtin_amdgcn_readlane((int)m, 48));
-      const int slot = c * gridDim.z + blockIdx.z;
-      if (lane == 0) {
-        amax_y[(int64_t)b0 * amax_y_stride + slot] = m0;
-        if (twin) amax_y[(int64_t)b1 * amax_y_stride + slot] = m1;
-      }
+      const unsigned m = wave_max_u32(__float_as_uint(mx));   // |x| bit patterns order like unsigned integers
+      const auto da = __builtin_amdgcn_make_buffer_rsrc(amax_y + (int64_t)b * amax_y_stride, 0, 4 * amax_y_stride, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(m, da, am_off, 0, 0);
     }
-    wave_sync();   // the next pair's staging overwrites the rows, its epilogue the transposition buffer
+    wave_sync();   // the next task's staging overwrites the row
   };
 
-  if (p_lo >= p_hi) return;
-  Stage sa, sb;
-  gload(p_lo, sa);
-  gload(min(p_lo + 1, p_hi - 1), sb);
+  Stage stg[kStages];
+#pragma unroll
+  for (int i = 0; i < kStages; ++i) gload(min(b_lo + i, b_hi - 1), stg[i]);
 
   // tap table of this channel: requested now, so that it shares the flight of the rows and of the maxima below
   constexpr int NTL = (G::TSZ + 63) / 64;
@@ -264,29 +271,43 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < NTL; ++j) tapv[j] = lane + 64 * j < G::TSZ ? taps[(int64_t)c * G::TSZ + lane + 64 * j] : 0u;
 
-  // ---- scales of every utterance this wavefront will touch, once: the reduction of the producers' slots is a loop of
-  //      dependent loads (a wait for ALL outstanding vector-memory operations -- inside the pair loop it would also wait
-  //      for the rows just requested two pairs ahead); here it overlaps the first rows' flight ----
-  for (int p = p_lo; p < p_hi; ++p) {
-    const int b0 = 2 * p, b1 = b0 + 1 < batch ? b0 + 1 : b0;
-    float4 sc;
-    f16_scale(amax_read(amax_x, amax_x_stride, amax_x_n, b0, lane), &sc.x, &sc.y);
-    f16_scale(amax_read(amax_x, amax_x_stride, amax_x_n, b1, lane), &sc.z, &sc.w);
-    if (lane == 0) scl[p - p_lo] = sc;
+  // ---- scales of every utterance this wavefront will touch, once, ALL AT ONCE: the reduction of a producer's slots is a
+  //      round trip to L2 per 64 slots, and a wavefront that took its utterances one after the other would sit through
+  //      8-30 of them (5-15 us on a 25 us kernel) before its first multiply.  Unrolled over the utterances, the loads of
+  //      one trip are in flight together, next to the first rows and the tap table. ----
+  {
+    unsigned m[kUttPerWave];
+    const unsigned* ap[kUttPerWave];
+#pragma unroll
+    for (int u = 0; u < kUttPerWave; ++u) {
+      m[u] = 0u;
+      ap[u] = amax_x + (int64_t)min(b_lo + u, b_hi - 1) * amax_x_stride;
+    }
+    for (int i0 = 0; i0 < amax_x_n; i0 += 64) {
+      const int i = min(i0 + lane, amax_x_n - 1);   // clamped, not predicated: a slot read twice does not change a maximum
+#pragma unroll
+      for (int u = 0; u < kUttPerWave; ++u) m[u] = max(m[u], ap[u][i]);
+    }
+#pragma unroll
+    for (int u = 0; u < kUttPerWave; ++u) {
+      float2 sc;
+      f16_scale(wave_max_u32(m[u]), &sc.x, &sc.y);
+      if (lane == 0) scl[u] = sc;
+    }
   }
 
-  // ---- A fragments of this channel: lane (m = l31, kh), step s, element e <- table[31 - m + 16 s + 8 kh + e] ----
+  // ---- A fragments of this channel: lane (m = n16, kg), step s, element e <- table[15 - m + 32 s + 8 kg + e] ----
 #pragma unroll
   for (int j = 0; j < NTL; ++j)
     if (lane + 64 * j < G::TSZ) tab[lane + 64 * j] = tapv[j];
   wave_sync();
   {
-    const unsigned* tp = tab + 31 - l31 + 8 * kh;
+    const unsigned* tp = tab + 15 - n16 + 8 * kg;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       unsigned v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tp[16 * s + e];
+      for (int e = 0; e < 8; ++e) v[e] = tp[32 * s + e];
       // (hi | lo << 16) pairs -> four dwords of hi halves, four of lo halves (v_perm_b32 each)
       ah[s] = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u),
                          __builtin_amdgcn_perm(v[5], v[4], 0x05040100u), __builtin_amdgcn_perm(v[7], v[6], 0x05040100u));
@@ -295,11 +316,11 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     }
   }
 
-  // two pairs per trip, both always executed (same reason as above); with an odd count the last pair is simply computed
-  // and stored twice
-  for (int p = p_lo; p < p_hi; p += 2) {
-    do_pair(p, sa);
-    do_pair(min(p + 1, p_hi - 1), sb);
+  // kStages tasks per trip, all always executed (same reason as above); when the count is not a multiple the last
+  // utterance is simply computed and stored again
+  for (int b = b_lo; b < b_hi; b += kStages) {
+#pragma unroll
+    for (int i = 0; i < kStages; ++i) do_task(min(b + i, b_hi - 1), stg[i]);
   }
 }
 
@@ -309,19 +330,20 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
   using G = TzGeom<K, DIL>;
   auto kern = dw_toeplitz_kernel<K, DIL>;
   constexpr int lds = 4 * G::LDS_WAVE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (attr != hipSuccess) return (int)attr;
-  const int n_pairs = (batch + 1) / 2;
-  static const int ppw_env = getenv("VASR_DW_PPW") ? atoi(getenv("VASR_DW_PPW")) : 0;
-  const int ppw = ppw_env >= 1 && ppw_env <= kPairsPerWave ? ppw_env : 8;
-  dim3 grid(channels / 4, (n_pairs + ppw - 1) / ppw, (unsigned)((ldy + kTile - 1) / kTile));
+  const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
+  // utterances one wavefront walks with its channel's A fragments: as many as leave >= 4096 wavefronts (4 per SIMD)
+  static const int upw_env = getenv("VASR_DW_UPW") ? atoi(getenv("VASR_DW_UPW")) : 0;
+  int upw = kUttPerWave;
+  if (upw_env >= 1 && upw_env <= kUttPerWave) upw = upw_env;
+  else
+    while (upw > 2 && (int64_t)channels * ((batch + upw - 1) / upw) * tiles < 4096) upw /= 2;
+  dim3 grid(channels / 4, (batch + upw - 1) / upw, tiles);
   if (amax_y) {
     amax_y->n = channels * grid.z;
     if (amax_y->n > amax_y->stride) return -1;
   }
   VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x.p, amax_x.stride, amax_x.n, channels, batch,
-              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0, ppw);
+              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0, upw);
   return 0;
 }
 
@@ -345,17 +367,17 @@ int depthwise_mfma_table_size(int kernel, int dilation) {
 }
 
 // Host: one channel's taps w[K] -> table[tsz] of (hi | lo << 16) fp16 pairs of the scaled DENSE tap sequence
-// (entry i = dense tap i - (31 + OFF), dense tap k * DIL = w[k]); returns 1 / scale.
+// (entry i = dense tap i - (15 + OFF), dense tap k * DIL = w[k]); returns 1 / scale.
 float pack_depthwise_taps_f16x2(const float* w, int kernel, int dilation, int tsz, unsigned* table) {
   const int pad = dilation > 1 ? (dilation * kernel) / 2 - 1 : kernel / 2;
-  const int off = ((pad + 7) & ~7) - pad;
+  const int off = ((pad + 3) & ~3) - pad;
   float mx = 0.f;
   for (int k = 0; k < kernel; ++k) mx = fabsf(w[k]) > mx ? fabsf(w[k]) : mx;
   int e = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
   e = e < 16 ? 16 : (e > 254 ? 254 : e);
   const float s = __builtin_bit_cast(float, (unsigned)(268 - e) << 23), inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
   for (int i = 0; i < tsz; ++i) {
-    const int d = i - (31 + off);
+    const int d = i - (15 + off);
     float v = 0.f;
     if (d >= 0 && d % dilation == 0 && d / dilation < kernel) v = w[d / dilation] * s;
     const _Float16 h = (_Float16)v;

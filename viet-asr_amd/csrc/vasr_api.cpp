@@ -580,10 +580,11 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         const int64_t ld_out = pad_frames(t_out);
         ProfScope ps(h, kProfDepthwise, st);
         AmaxTab am = want_amax ? free_tab(AmaxTab{}) : AmaxTab{};
-        // fp16-split mode with the input's maxima at hand: the Toeplitz form on the matrix pipe; else packed FMAs
-        // (opt-in while it is slower than the packed-FMA kernels: 33 vs 30 us per K = 75 layer, 25 vs 13 at K = 33 -- it
-        // issues ~500 instructions per utterance pair and is instruction-issue bound)
-        static const bool dw_mfma = getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) != 0;
+        // fp16-split mode with the input's maxima at hand: the Toeplitz form on the matrix pipe (in the pipeline, per
+        // 512-channel layer: 22.8 / 23.7 / 23.8 / 28.1 us at K = 51 / 63 / 75 / 87 x 2 against 25.6 / 28.4 / 31.0 / 35.5 us
+        // of packed FMAs; 256 channels, K = 33 / 39: 12.8 / 12.6 against 13.3 / 13.4), else packed FMAs.
+        // VASR_DW_MFMA=0 keeps the packed-FMA kernels.
+        static const bool dw_mfma = !(getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) == 0);
         int e = -1;
         if (want_amax && dw_mfma && cur_amax.p && S.dw.d_taps)
           e = launch_depthwise_mfma(cur, cur_ld, S.dw.d_taps, S.dw.d_tap_inv, lens(S.dw.step), lens(S.dw.step + 1), cur_amax,
