@@ -154,16 +154,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   const int len = MASK ? a.lens[b] : 0;
   const int len2 = DUAL ? a.lens2[b] : 0;
 
-  // kF16x2: one power-of-two scale per utterance from the maxima the producers of x (and x2) published
+  // kF16x2: one power-of-two scale per utterance from the maxima the producers of x (and x2) published -- requested
+  // below together with the first rows and weight fragments, so that the reduction's trip to L2 runs inside the rows'
+  // HBM round trip instead of in front of it
   float xs = 1.f, out_scale = 1.f;
-  if constexpr (ARITH == kF16x2) {
-    // every wavefront reduces the producers' per-wavefront maxima of its utterance itself (a few KB from L2, no barrier)
-    unsigned mx = amax_read(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane);
-    if (DUAL) mx = max(mx, amax_read(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane));
-    float inv;
-    f16_scale(mx, &xs, &inv);
-    out_scale = inv * a.w_inv_scale;
-  }
 
   const int K1 = DUAL ? a.K1 : a.K;
   const float* __restrict__ xb = a.x + (int64_t)b * K1 * a.ldx + t0;
@@ -314,13 +308,27 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   // (A separate tail for the odd chunk was tried first: a second conditional copy of the chunk body next to the
   // final-pair block makes the register allocator spill ~160 registers around the merge of the 128 accumulators.)
   const int odd = nchunks & 1;
+  unsigned amv[8], amv2[8];
   if (nchunks) {
+    if constexpr (ARITH == kF16x2) {
+      amax_request(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
+      if (DUAL) amax_request(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2);
+    }
     gload(0, S0{});
     aload(0, af);
     if constexpr (WSETS > 2) {
       // chunk "-1" (odd counts) starts at global step -STEPS: its steps clamp to fragment 0, which is what aw[*] then holds
 #pragma unroll
       for (int w = 1; w < WSETS - 1; ++w) aload(odd ? 0 : w, aw[w]);
+    }
+    if constexpr (ARITH == kF16x2) {
+      // every wavefront reduces the producers' per-wavefront maxima of its utterance itself (a few KB from L2, no barrier);
+      // a tile without chunks multiplies nothing and needs no scale
+      unsigned mx = amax_collect(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
+      if (DUAL) mx = max(mx, amax_collect(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2));
+      float inv;
+      f16_scale(mx, &xs, &inv);
+      out_scale = inv * a.w_inv_scale;
     }
     if (odd) {
 #pragma unroll

@@ -37,6 +37,36 @@ __device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ tab, 
   return wave_max_u32(m);
 }
 
+// The same reduction in two halves, eight slots per lane in flight: amax_request() issues the loads of the first 512
+// slots (one per channel of a depthwise layer) and returns; the caller requests whatever else it needs next (a GEMM
+// workgroup: its first rows and weight fragments) and calls amax_collect() when it needs the value -- s_waitcnt counts in
+// order, so waiting for these OLDER loads leaves the younger ones in flight.  The serial form was four to eight dependent
+// round trips to L2 (2-3 us) at the head of every GEMM workgroup, before its first row was even requested.  (Clamped, not
+// predicated: a slot read twice does not change a maximum, and the loads stay unconditional.)
+__device__ __forceinline__ void amax_request(const unsigned* __restrict__ tab, int stride, int n, int b, int lane,
+                                             unsigned (&v)[8]) {
+  const unsigned* p = tab + (int64_t)b * stride;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = p[min(64 * u + lane, n - 1)];
+}
+__device__ __forceinline__ unsigned amax_collect(const unsigned* __restrict__ tab, int stride, int n, int b, int lane,
+                                                 const unsigned (&v)[8]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) m = max(m, v[u]);
+  if (n > 512) {   // several time tiles per channel (long recordings): the rest in further trips
+    const unsigned* p = tab + (int64_t)b * stride;
+    for (int i0 = 512; i0 < n; i0 += 512) {
+      unsigned w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = p[min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = max(m, w[u]);
+    }
+  }
+  return wave_max_u32(m);
+}
+
 // power-of-two scale (and its inverse) that puts a maximum of magnitude `amax_bits` (fp32 bit pattern of |x|) into
 // [2^14, 2^15): the fp16 planes then have 18 octaves of full 22-bit precision below the maximum
 __device__ __forceinline__ void f16_scale(unsigned amax_bits, float* scale, float* inv) {
