@@ -25,13 +25,21 @@
 // instruction write 1 KB of one row.
 //
 //   grid (C / 4, ceil(B / utterances per wave), ceil(ldy / 512)), block 256 = 4 wavefronts = 4 channels; a wavefront builds
-//   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks its utterances
-//   with them, 512 frames (two MFMA groups sharing one staged row) per utterance, the rows of the next TWO utterances in
-//   flight while the current one is multiplied.
+//   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks up to eight
+//   utterances with them, 512 frames (two MFMA groups sharing one staged row) per utterance, the next utterance's row in
+//   flight while the current one is multiplied.  The walk is fully unrolled: what depends on the utterance (row
+//   descriptors, lengths, scales) is fetched once into scalar registers, and the eight output maxima are reduced
+//   across the lanes together at the end.
+//
+// Measured (MI355X, B = 64 x 501 frames, 512 channels, in the pipeline): 22-23 us per layer whatever K (134 MB -> 5.8-6.0
+// TB/s = 0.72-0.75 of the 8 TB/s peak; a copy_ of the same bytes 19.7 us), against 25.6 / 28.4 / 31.0 / 35.5 us of the
+// packed-FMA kernels at K = 51 / 63 / 75 / 87 x 2.  Compiled-out ablations: rows and stores only 18.1 us, everything but
+// rows and stores 16.0 us -- both streams are long and they overlap imperfectly; the MFMAs themselves cost 0.4 us.
 #include <cstdlib>
 
 #include "vasr_internal.h"
 #include "vasr_device.h"
+#include <type_traits>
 
 namespace vasr {
 
@@ -50,8 +58,12 @@ using u32x4 = __attribute__((vector_size(16))) unsigned int;
 constexpr int kTile = 512;          // output frames per task: 2 groups of 16 windows x 16 outputs
 constexpr int kGroup = 256;
 constexpr int kUttPerWave = 8;      // upper bound; the launch passes the count in use
+#ifndef VASR_TZ_LDAUX
+#define VASR_TZ_LDAUX 0   // cache-policy bits of the row loads (dev)
+#endif
 #ifndef VASR_TZ_STAGES
-#define VASR_TZ_STAGES 2   // 3 and 4 measured 25-30 % SLOWER (31 us against 24.4 at K = 75): more rows in flight only queue up
+#define VASR_TZ_STAGES 1   // rows in flight per wavefront beyond the one being multiplied: 1 and 2 measure the same at 512
+                           // channels (23.2 us at K = 75), 1 is 5-10 % faster at 256; 3 and 4 are 25-30 % SLOWER (31 us)
 #endif
 
 template <int K, int DIL>
@@ -61,15 +73,14 @@ struct TzGeom {
   static constexpr int OFF = PADL - PAD;
   static constexpr int SPAN = 15 + DIL * (K - 1) + OFF + 1;         // window samples one 16-output window touches
   static constexpr int NS = (SPAN + 31) / 32;                       // k-steps
-  static constexpr int STAGES = NS > 3 ? 2 : VASR_TZ_STAGES;        // rows in flight per wavefront (NLD float4 registers each)
+  static constexpr int STAGES = VASR_TZ_STAGES;                     // register stages of NLD float4 each
   static constexpr int TSZ = 32 * NS + 16;                          // tap-table entries: entry i = dense tap i - (15 + OFF)
   static constexpr int ROWS = kTile - 16 + 32 * NS;                 // samples staged per task
   static constexpr int NLD = (ROWS / 4 + 63) / 64;                  // float4 loads per lane and task
   static constexpr int PLANE = 2 * 256 * NLD;                       // bytes of one fp16 plane (every lane stores, no branch)
   static constexpr int LDS_DATA = 2 * PLANE;                        // [hi | lo]
   static constexpr int LDS_TAB = 4 * TSZ;
-  static constexpr int LDS_SCL = 8 * kUttPerWave;                   // per utterance: (scale, 1 / scale)
-  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB + LDS_SCL;
+  static constexpr int LDS_WAVE = LDS_DATA + LDS_TAB;
   static_assert(ROWS % 4 == 0 && LDS_WAVE % 16 == 0, "staging granularity");
 };
 
@@ -103,7 +114,6 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   unsigned char* base = lds_raw + wave * G::LDS_WAVE;
   unsigned char* dat = base;                                               // [plane][PLANE]
   unsigned* tab = reinterpret_cast<unsigned*>(base + G::LDS_DATA);
-  float2* scl = reinterpret_cast<float2*>(base + G::LDS_DATA + G::LDS_TAB);
   const int c = blockIdx.x * 4 + wave;
   const int t_tile = blockIdx.z * kTile;
   const int n16 = lane & 15, kg = lane >> 4;
@@ -127,18 +137,30 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const int tau = 4 * (lane + 64 * j);
     voff[j] = tau < G::ROWS ? 4 * (t_tile - G::PADL + tau) : (int)0x80000000u;
   }
+  // Everything a task needs that depends on its utterance alone is a wave-uniform scalar, fetched ONCE up front; the task
+  // sequence below is fully unrolled, so that these live in SGPRs under compile-time indices.  (As a loop over the
+  // utterance index the kernel spent 82 scalar instructions per task -- 27 % of its issue cycles, SQ_INSTS_SALU -- on
+  // 64-bit row addresses, length loads and their waits, descriptor words and clamps.)
+  const int n_utt = b_hi - b_lo;   // 1 .. kUttPerWave
   const int64_t row_stride = (int64_t)channels * ldx;                 // floats between utterances of one channel
-  const float* xrow = x + ((int64_t)b_lo * channels + c) * ldx;
+  const float* xrow0 = x + ((int64_t)b_lo * channels + c) * ldx;
   const int64_t yrow_stride = (int64_t)channels * ldy;
   float* yrow0 = y + ((int64_t)b_lo * channels + c) * ldy;
-  auto gload = [&](int b, Stage& sg) {
-    const float* xr = xrow + (int64_t)(b - b_lo) * row_stride;
-    // (length through the scalar cache: the descriptor words must be wave-uniform for the compiler, or every load
-    // becomes a waterfall loop)
-    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr), 0, 4 * min(lens_in[b], (int)ldx), 0x00020000);
+  int rng[kUttPerWave], lout[kUttPerWave];
+#pragma unroll
+  for (int u = 0; u < kUttPerWave; ++u) {
+    const int b = min(b_lo + u, batch - 1);
+    // past the wavefront's last utterance: an empty range -- the unconditional prefetches there return zeros without a
+    // memory access
+    rng[u] = u < n_utt ? 4 * min(lens_in[b], (int)ldx) : 0;
+    lout[u] = lens_out[b];
+  }
+  auto gload = [&](int u, Stage& sg) {
+    // (descriptor words are wave-uniform scalars, or every load becomes a waterfall loop)
+    const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xrow0 + u * row_stride), 0, rng[u], 0x00020000);
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      if (!(VASR_TZ_ABLATE & 8)) sg.r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d, voff[j], 0, 0));
+      if (!(VASR_TZ_ABLATE & 8)) sg.r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d, voff[j], 0, VASR_TZ_LDAUX));
       else sg.r[j] = v4f{(float)voff[j], 1.f, 2.f, 3.f};
     }
   };
@@ -166,16 +188,52 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   // then holds frames 4 L .. 4 L + 3
   const int pull = 4 * ((lane >> 2) + 16 * (lane & 3));
   const int slot = c * gridDim.z + blockIdx.z;
-  const int am_off = lane == 0 ? 4 * slot : (int)0x80000000u;   // one word per wavefront, no branch around the store
 
-  auto do_task = [&](int b, Stage& sg) {
-    const float2 sc = scl[b - b_lo];   // (scale, 1 / scale): LDS broadcast, no vector-memory wait
-    if (!(VASR_TZ_ABLATE & 4)) sstore(sg, sc.x);
+  float sxu[kUttPerWave], ixu[kUttPerWave];   // (scale, 1 / scale) per utterance, set below
+  unsigned mxu[kUttPerWave];                  // per-lane maxima of the outputs, per utterance
+#pragma unroll
+  for (int u = 0; u < kUttPerWave; ++u) mxu[u] = 0u;
+  // ---- the eight maxima across the wavefront in ONE butterfly (29 instructions instead of 8 x 16): each exchange step
+  //      also halves the number of registers -- a lane keeps the utterances whose index agrees with its lane bit and
+  //      hands the others to its partner -- until lane L holds utterance L & 7; one store writes all of them ----
+  auto publish = [&]() {
+    if (!amax_y || (VASR_TZ_ABLATE & 32)) return;
+#define VASR_DPP(xx, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(xx), (ctrl), 0xF, 0xF, false))
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    unsigned r[4], q[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // lanes L, L ^ 1
+      r[k] = max(b0 ? mxu[2 * k + 1] : mxu[2 * k], VASR_DPP(b0 ? mxu[2 * k] : mxu[2 * k + 1], 0xB1));
+#pragma unroll
+    for (int k = 0; k < 2; ++k)   // lanes L, L ^ 2
+      q[k] = max(b1 ? r[2 * k + 1] : r[2 * k], VASR_DPP(b1 ? r[2 * k] : r[2 * k + 1], 0x4E));
+    // lanes L, L ^ 4: a shift by four lanes in BOTH directions -- whatever arrives from four lanes away (inside the row of
+    // 16; nothing, i.e. zero, from outside) is a partial maximum of the very utterance the lane keeps
+    const unsigned send = b2 ? q[0] : q[1];
+    unsigned m = max(b2 ? q[1] : q[0], max(VASR_DPP(send, 0x104), VASR_DPP(send, 0x114)));   // row_shl:4, row_shr:4
+    m = max(m, VASR_DPP(m, 0x128));   // row_ror:8: lanes L, L ^ 8
+#undef VASR_DPP
+    {
+      const auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);   // rows 0 <-> 1, 2 <-> 3
+      m = max((unsigned)sw[0], (unsigned)sw[1]);
+    }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);   // halves
+      m = max((unsigned)sw[0], (unsigned)sw[1]);
+    }
+    // lane u < n_utt -> row b_lo + u of the table; every other lane's offset lies outside the descriptor's range
+    const auto da = __builtin_amdgcn_make_buffer_rsrc(amax_y + (int64_t)b_lo * amax_y_stride, 0, 4 * n_utt * amax_y_stride, 0x00020000);
+    const int off = lane < kUttPerWave ? 4 * (lane * amax_y_stride + slot) : (int)0x80000000u;
+    __builtin_amdgcn_raw_buffer_store_b32(m, da, off, 0, 0);
+  };
+  auto do_task = [&](auto u_tag, Stage& sg) {
+    constexpr int u = decltype(u_tag)::value;
+    if (!(VASR_TZ_ABLATE & 4)) sstore(sg, sxu[u]);
     else asm volatile("" :: "v"(sg.r[0]), "v"(sg.r[NLD - 1]));
-    // The utterance kStages ahead, in flight while this one and the next ones are multiplied and stored.  UNCONDITIONAL
-    // (past the end the last one is requested again): s_waitcnt vmcnt counts outstanding operations, so the compiler can
-    // only leave the other stages' rows in flight if it knows how many younger operations there are on every path.
-    gload(min(b + kStages, b_hi - 1), sg);
+    // The utterance kStages ahead, in flight while this one and the next ones are multiplied and stored: issued whether
+    // or not it exists (see rng[]), so that on the straight-line path the compiler knows how many vector-memory
+    // operations are younger than the rows it waits for (s_waitcnt vmcnt counts, it does not name).
+    if constexpr (u + kStages < kUttPerWave) gload(u + kStages, sg);
     wave_sync();
 
     // All B fragments of the task are requested before the first multiply (one exposed LDS round trip per task instead of
@@ -224,9 +282,9 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     }
 
     // ---- epilogue: unscale, rotate lanes, zero past lens_out, 1 KB of one row per store instruction ----
-    const float os = w_inv * sc.y;
-    const int lo = lens_out[b];   // scalar load
-    float* yr = yrow0 + (int64_t)(b - b_lo) * yrow_stride;
+    const float os = w_inv * ixu[u];
+    const int lo = lout[u];
+    float* yr = yrow0 + u * yrow_stride;
     // columns >= ldy are dropped by the descriptor's range, like the whole second group of a tile that has none
     const auto dy = __builtin_amdgcn_make_buffer_rsrc(yr, 0, 4 * (int)ldy, 0x00020000);
     v4f o0 = {acc0[0] * os, acc0[1] * os, acc0[2] * os, acc0[3] * os};
@@ -253,17 +311,13 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     };
     finish(o0, 0);
     finish(o1, 1);
-    if (amax_y && !(VASR_TZ_ABLATE & 32)) {
-      const unsigned m = wave_max_u32(__float_as_uint(mx));   // |x| bit patterns order like unsigned integers
-      const auto da = __builtin_amdgcn_make_buffer_rsrc(amax_y + (int64_t)b * amax_y_stride, 0, 4 * amax_y_stride, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b32(m, da, am_off, 0, 0);
-    }
+    mxu[u] = __float_as_uint(mx);   // |x| bit patterns order like unsigned integers; reduced across the lanes at the end
     wave_sync();   // the next task's staging overwrites the row
   };
 
   Stage stg[kStages];
 #pragma unroll
-  for (int i = 0; i < kStages; ++i) gload(min(b_lo + i, b_hi - 1), stg[i]);
+  for (int i = 0; i < kStages; ++i) gload(i, stg[i]);
 
   // tap table of this channel: requested now, so that it shares the flight of the rows and of the maxima below
   constexpr int NTL = (G::TSZ + 63) / 64;
@@ -289,11 +343,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       for (int u = 0; u < kUttPerWave; ++u) m[u] = max(m[u], ap[u][i]);
     }
 #pragma unroll
-    for (int u = 0; u < kUttPerWave; ++u) {
-      float2 sc;
-      f16_scale(wave_max_u32(m[u]), &sc.x, &sc.y);
-      if (lane == 0) scl[u] = sc;
-    }
+    for (int u = 0; u < kUttPerWave; ++u) f16_scale(wave_max_u32(m[u]), &sxu[u], &ixu[u]);
   }
 
   // ---- A fragments of this channel: lane (m = n16, kg), step s, element e <- table[15 - m + 32 s + 8 kg + e] ----
@@ -316,12 +366,18 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     }
   }
 
-  // kStages tasks per trip, all always executed (same reason as above); when the count is not a multiple the last
-  // utterance is simply computed and stored again
-  for (int b = b_lo; b < b_hi; b += kStages) {
-#pragma unroll
-    for (int i = 0; i < kStages; ++i) do_task(min(b + i, b_hi - 1), stg[i]);
-  }
+  // the wavefront's utterances, unrolled; one that has fewer leaves early (never rejoining: the counts stay exact)
+  auto run = [&](auto u_tag, auto& self) -> void {
+    constexpr int u = decltype(u_tag)::value;
+    if constexpr (u < kUttPerWave) {
+      if (u >= n_utt) return publish();
+      do_task(u_tag, stg[u % kStages]);
+      self(std::integral_constant<int, u + 1>{}, self);
+    } else {
+      publish();
+    }
+  };
+  run(std::integral_constant<int, 0>{}, run);
 }
 
 template <int K, int DIL>
