@@ -62,6 +62,45 @@ def test_pointwise_weight_packing_layout():
         _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, 63, m_pad, out.ctypes.data))
 
 
+@pytest.mark.parametrize("K,dil", [(33, 1), (39, 1), (51, 1), (63, 1), (75, 1), (87, 2)])
+def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
+    """vasr_pack_depthwise_taps (host side of encoder_dw_mfma.hip): the [hi | lo] fp16 table of a channel, read the way the
+    kernel builds its A fragments -- A[m][k] = table[15 - m + k], 16 output offsets x 32 NS window samples -- times
+    windows of 16 consecutive outputs cut from the zero-padded row, B[k][n] = row[16 n - PADL + k], IS the "same"-padded
+    depthwise convolution of jasper.py:60-65 / :119-132; hi + lo carries the scaled tap to 2^-22."""
+    L = _lib.lib()
+    tsz = int(L.vasr_depthwise_mfma_table_size(K, dil))
+    pad = (dil * K) // 2 - 1 if dil > 1 else K // 2
+    padl = (pad + 3) & ~3
+    ns = (15 + dil * (K - 1) + (padl - pad) + 1 + 31) // 32
+    assert tsz == 32 * ns + 16
+    rng = np.random.default_rng(K)
+    C_ = 3
+    w = (rng.standard_normal((C_, K)) / np.sqrt(K)).astype(np.float32)
+    w[1] *= 1e-4
+    tab, inv = np.empty((C_, tsz), dtype=np.uint32), np.empty(C_, dtype=np.float32)
+    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, K, dil, tab.ctypes.data, inv.ctypes.data))
+    hi = (tab & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64)
+    lo = (tab >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
+    T = 64                                                        # four windows of 16 outputs
+    x = rng.standard_normal((C_, T))
+    row = np.zeros((C_, padl + T + 32 * ns))                      # row[padl + t] = x[t], zeros around it
+    row[:, padl:padl + T] = x
+    m, k = np.arange(16)[:, None], np.arange(32 * ns)[None, :]
+    for c in range(C_):
+        assert np.log2(inv[c]) == np.round(np.log2(inv[c]))       # power-of-two scale
+        assert 2.0 ** 14 <= np.abs(hi[c]).max() < 2.0 ** 15
+        A = (hi[c] + lo[c])[15 - m + k] * float(inv[c])           # [16][32 ns]
+        got = np.concatenate([A @ row[c, 16 * n:16 * n + 32 * ns] for n in range(T // 16)])
+        xp = np.zeros(T + 2 * pad)
+        xp[pad:pad + T] = x[c]
+        ref = np.array([sum(float(w[c, j]) * xp[t + dil * j] for j in range(K)) for t in range(T)])
+        assert np.abs(got - ref).max() <= 2.0 ** -20 * np.abs(w[c]).max() * np.abs(x[c]).sum()
+    assert int(L.vasr_depthwise_mfma_table_size(35, 1)) == 0      # shapes without an instantiation
+    with pytest.raises(ValueError):
+        _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, 35, 1, tab.ctypes.data, inv.ctypes.data))
+
+
 def test_builtin_configs_and_state_dict_layout():
     for name, n_blocks, n_labels, n_keys in (("quartznet12x1_vi", 15, 90, 182), ("quartznet15x5", 18, 28, 635)):
         cfg = configs.builtin(name)
