@@ -193,6 +193,11 @@ int vasr_set_slices(vasr_handle* h, int slices);
  * whatever the other rows are.  Every length[b] must exceed n_fft / 2 (an unbatched torch.stft refuses shorter input);
  * pred / logp keep their [B, T'] shapes, frames past a row's own count are unspecified. */
 int vasr_set_row_independent(vasr_handle* h, int on);
+/* Compute units that another kernel of the caller's keeps busy while this handle's kernels run -- e.g. the beam search of
+ * the previous batch on a side stream, one workgroup per utterance (engine.forward_beam).  The GEMM tile choice then
+ * fills whole rounds of the REMAINING units: with 64 of 256 taken, 512 x 128 workgroups (one per CU) would need two
+ * rounds, the second a third full; 256 x 64 ones quantise four times finer.  0 (default) = the whole device. */
+int vasr_set_busy_cus(vasr_handle* h, int cus);
 
 /* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */
 /* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "vasr_bench_depthwise_mfma": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_set_row_independent": (C.c_int, [_P, C.c_int]),
+    "vasr_set_busy_cus": (C.c_int, [_P, C.c_int]),
     "vasr_beam_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vasr_beam_search_f32": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P,
                                        _P, _P, _P, _P, C.c_size_t, _P]),
@@ -205,6 +206,9 @@ class Handle:
 
     def set_row_independent(self, on):
         check(lib().vasr_set_row_independent(self.h, int(bool(on))))
+
+    def set_busy_cus(self, cus):
+        check(lib().vasr_set_busy_cus(self.h, int(cus)))
 
     def profile_begin(self):
         check(lib().vasr_profile_begin(self.h))

@@ -626,8 +626,10 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
       return n;
     }();
-    const int64_t n1 = blocks(512, 128), rounds = (n1 + n_cu - 1) / n_cu;
-    if ((double)n1 < 0.85 * (double)(rounds * n_cu)) tile = 5;
+    // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- do not take workgroups)
+    const int cus = a.busy_cus > 0 && a.busy_cus < n_cu - 32 ? n_cu - a.busy_cus : n_cu;
+    const int64_t n1 = blocks(512, 128), rounds = (n1 + cus - 1) / cus;
+    if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
   if (force >= 1 && force <= 5 && a.M % rows[force] == 0) tile = force;
   switch (tile) {

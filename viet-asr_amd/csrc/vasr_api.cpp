@@ -115,6 +115,7 @@ struct vasr_handle {
   int slices = getenv("VASR_SLICES") ? atoi(getenv("VASR_SLICES")) : 1;
   bool slice_ready = false;
   bool row_independent = false;   // vasr_set_row_independent
+  int busy_cus = 0;               // vasr_set_busy_cus
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16 (measured
@@ -559,6 +560,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
     if (B.has_res && !B.fused_res) {
       // res branch: MaskedConv1d(1x1)(block input, lens_orig) -> BN   (parts/jasper.py:428-436)
       PwArgs a{};
+      a.busy_cus = h->busy_cus;
       a.wt = B.res.d_w; a.x = cur; a.lens = lens(B.first_step); a.scale = B.res.d_scale; a.shift = B.res.d_shift;
       a.res = nullptr; a.y = R; a.M = B.res.m_pad; a.K = B.res.cin; a.batch = batch;
       a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
@@ -604,6 +606,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       const bool fuse = last_sub && B.fused_res;
       const ConvLayer& W = fuse ? B.fused : S.pw;
       PwArgs a{};
+      a.busy_cus = h->busy_cus;
       a.wt = W.d_w; a.x = gx; a.lens = g_lens; a.scale = W.d_scale; a.shift = W.d_shift;
       a.res = (last_sub && B.has_res && !B.fused_res) ? R : nullptr;
       a.y = dst; a.M = W.m_pad; a.K = W.cin; a.batch = batch;
@@ -639,6 +642,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
 int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int batch, float* logits, float* logp,
                 int64_t* pred, hipStream_t st, AmaxTab enc_amax = AmaxTab{}) {
   PwArgs a{};
+  a.busy_cus = h->busy_cus;
   a.wt = h->dec.d_w; a.x = encp; a.lens = nullptr; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
   a.res = nullptr; a.y = logits; a.M = h->dec.m_pad; a.K = h->dec.cin; a.batch = batch;
   a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
@@ -968,6 +972,13 @@ int vasr_set_gemm_mode(vasr_handle* h, int mode) {
 }
 
 int vasr_get_gemm_mode(const vasr_handle* h) { return h ? h->gemm_mode : -1; }
+
+int vasr_set_busy_cus(vasr_handle* h, int cus) {
+  if (!h || cus < 0) return fail(VASR_ERR_INVALID, "busy compute units must be >= 0");
+  static const bool off = getenv("VASR_NO_BUSY_CUS") && atoi(getenv("VASR_NO_BUSY_CUS")) != 0;   // A/B switch
+  h->busy_cus = off ? 0 : cus;
+  return 0;
+}
 
 int vasr_set_row_independent(vasr_handle* h, int on) {
   if (!h) return fail(VASR_ERR_INVALID, "null handle");

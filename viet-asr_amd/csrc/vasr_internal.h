@@ -125,6 +125,7 @@ struct PwArgs {
   // the masks guarantee it), so a time tile that starts there skips its K loop: its outputs are relu(shift (+ res)).
   // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
   const int32_t* zero_from;
+  int32_t busy_cus;       // compute units held by a concurrent kernel of the caller's (vasr_set_busy_cus); tile choice only
   // kF16x2 only: maxima tables of x / x2 (inputs) and 1 / (weight scale) of the fp16 pack
   AmaxTab amax_x;
   AmaxTab amax_x2;

@@ -68,6 +68,7 @@ class QuartzNetCTC:
         self._slots, self._copy_stream, self._launched = None, None, 0
         self._row_independent = False
         self._beam_stream = None
+        self._beam_inflight = None                         # (done event, workgroups) of the last overlapped search
 
     # -- shapes
     def frames(self, samples):
@@ -150,7 +151,14 @@ class QuartzNetCTC:
         log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
         score, done): ``done`` is an event on the side stream (None when overlap is off); wait for it -- or
         synchronise the device -- before reading the results from another stream."""
-        r = self.forward(wav, length, want_logp=True, want_pred=False)
+        # a search of the previous batch that is still queued or running holds one compute unit per utterance while this
+        # acoustic pass runs: the GEMM tile choice should fill whole rounds of what is left (vasr_set_busy_cus)
+        busy = self._beam_inflight[1] if overlap and self._beam_inflight and not self._beam_inflight[0].query() else 0
+        self.handle.set_busy_cus(busy)
+        try:
+            r = self.forward(wav, length, want_logp=True, want_pred=False)
+        finally:
+            self.handle.set_busy_cus(0)
         if not overlap:
             ids, n, score = beam_decoder.decode_ids(r["logp"], beam_width, frames)
             return dict(ids=ids, id_len=n, score=score, done=None, enc_len=r["enc_len"])
@@ -164,6 +172,7 @@ class QuartzNetCTC:
             ids, n, score = beam_decoder.decode_ids(r["logp"], beam_width, frames)
             done = torch.cuda.Event()
             done.record(self._beam_stream)
+        self._beam_inflight = (done, int(r["logp"].shape[0]))
         r["logp"].record_stream(self._beam_stream)     # allocated on the main stream, last read on the side stream
         return dict(ids=ids, id_len=n, score=score, done=done, enc_len=r["enc_len"])
 
