@@ -130,12 +130,20 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   // descriptors whose range is the utterance's length -- MaskedConv1d's x.masked_fill(t >= lens, 0) (jasper.py:113-118)
   // and the conv's zero padding left of frame 0 (a negative offset is a huge unsigned one) both come back as zeros, per
   // dword; so do the lanes past the staged row (offset 2^31).  The offsets depend on the tile only: computed once.
+  // A last tile with few columns (a row pitch off the 512-frame grid: 10.3 s clips have 640) needs only the head of the
+  // staged row -- its columns plus the window overhang: the 256-sample slabs behind that are neither requested (offset
+  // 2^31 again) nor converted; they are cleared once, so that the windows nobody stores multiply zeros.
   struct Stage { v4f r[NLD]; };
+  const int n_ld = min(NLD, (min((int)ldy - t_tile, kTile) - 16 + 32 * NS + 255) / 256);   // wave-uniform, 1 .. NLD
   int voff[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
     const int tau = 4 * (lane + 64 * j);
-    voff[j] = tau < G::ROWS ? 4 * (t_tile - G::PADL + tau) : (int)0x80000000u;
+    voff[j] = tau < G::ROWS && j < n_ld ? 4 * (t_tile - G::PADL + tau) : (int)0x80000000u;
+    if (j >= n_ld) {
+      *reinterpret_cast<uint2*>(dat + 8 * lane + 512 * j) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(dat + G::PLANE + 8 * lane + 512 * j) = make_uint2(0u, 0u);
+    }
   }
   // Everything a task needs that depends on its utterance alone is a wave-uniform scalar, fetched ONCE up front; the task
   // sequence below is fully unrolled, so that these live in SGPRs under compile-time indices.  (As a loop over the
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     unsigned char* ph = dat + 8 * lane;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
+      if (j >= n_ld) continue;   // wave-uniform; VALU and LDS only, the loads themselves stay unconditional
       const v4f v = sg.r[j];
       const v2f a = {v.x * sx, v.y * sx}, b = {v.z * sx, v.w * sx};
       const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
