@@ -46,8 +46,9 @@ __device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ tab, 
 __device__ __forceinline__ void amax_request(const unsigned* __restrict__ tab, int stride, int n, int b, int lane,
                                              unsigned (&v)[8]) {
   const unsigned* p = tab + (int64_t)b * stride;
+  const int last = max(n, 1) - 1;   // (a table always has a slot 0; n <= 0 does not occur for a published table)
 #pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = p[min(64 * u + lane, n - 1)];
+  for (int u = 0; u < 8; ++u) v[u] = p[min(64 * u + lane, last)];
 }
 __device__ __forceinline__ unsigned amax_collect(const unsigned* __restrict__ tab, int stride, int n, int b, int lane,
                                                  const unsigned (&v)[8]) {
