@@ -101,6 +101,49 @@ def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
         _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, 35, 1, tab.ctypes.data, inv.ctypes.data))
 
 
+def test_toeplitz_kernel_lane_algebra():
+    """The index algebra of dw_toeplitz_kernel (encoder_dw_mfma.hip) replayed lane by lane in numpy, K = 75: staged row
+    sample tau <- frame t0 - PADL + tau; B fragment of lane (n = lane & 15, kg = lane >> 4), group q, step s = samples
+    256 q + 16 n + 32 s + 8 kg + e; A fragment of lane (m = lane & 15, kg) = table[15 - m + 32 s + 8 kg + e];
+    v_mfma_f32_16x16x32 D: lane n + 16 g holds rows 4 g + r of column n; after the rotation lane L (pulling from lane
+    (L >> 2) + 16 (L & 3)) holds frames t0 + 256 q + 4 L + r -- which must be the convolution's."""
+    L = _lib.lib()
+    K, pad = 75, 37
+    padl, ns = (pad + 3) & ~3, 3
+    tsz = int(L.vasr_depthwise_mfma_table_size(K, 1))
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((1, K)) / np.sqrt(K)).astype(np.float32)
+    tab, inv = np.empty((1, tsz), dtype=np.uint32), np.empty(1, dtype=np.float32)
+    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, 1, K, 1, tab.ctypes.data, inv.ctypes.data))
+    taps = ((tab[0] & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64) +
+            (tab[0] >> 16).astype(np.uint16).view(np.float16).astype(np.float64)) * float(inv[0])
+    T, t0 = 1200, 512                                              # second 512-frame tile of a 1200-frame row
+    x = rng.standard_normal(T)
+    rows = 512 - 16 + 32 * ns
+    staged = np.array([x[t] if 0 <= (t := t0 - padl + tau) < T else 0.0 for tau in range(rows)])
+    lanes = np.arange(64)
+    n16, kg = lanes & 15, lanes >> 4
+    out = np.zeros(512)
+    for q in range(2):
+        d = np.zeros((64, 4))                                      # accumulators: lane, register
+        for s in range(ns):
+            a = np.stack([taps[15 - n16 + 32 * s + 8 * kg + e] for e in range(8)], 1)             # [lane][e]
+            b = np.stack([staged[256 * q + 16 * n16 + 32 * s + 8 * kg + e] for e in range(8)], 1)
+            A = np.zeros((16, 32)); B = np.zeros((32, 16))
+            for l in range(64):
+                A[n16[l], 8 * kg[l]:8 * kg[l] + 8] = a[l]
+                B[8 * kg[l]:8 * kg[l] + 8, n16[l]] = b[l]
+            D = A @ B
+            for l in range(64):
+                d[l] += D[4 * (l >> 4):4 * (l >> 4) + 4, l & 15]
+        pulled = d[(lanes >> 2) + 16 * (lanes & 3)]
+        for l in range(64):
+            out[256 * q + 4 * l:256 * q + 4 * l + 4] = pulled[l]
+    xp = np.concatenate([np.zeros(pad), x, np.zeros(pad + 512)])
+    ref = np.array([np.dot(w[0].astype(np.float64), xp[t0 + t:t0 + t + K]) for t in range(512)])
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_builtin_configs_and_state_dict_layout():
     for name, n_blocks, n_labels, n_keys in (("quartznet12x1_vi", 15, 90, 182), ("quartznet15x5", 18, 28, 635)):
         cfg = configs.builtin(name)
