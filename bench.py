@@ -403,7 +403,7 @@ def main():
                                          "this run; null off the headline workload)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps},
-            "depthwise": {"kernel": "depthwise conv kernels (dw_*)", "bound": "hbm", "achieved": round(dw_gbs, 1),
+            "depthwise": {"kernel": "depthwise conv kernels (dw_toeplitz_kernel<K,DIL> on the matrix pipe; dw_conv_generic for the stride-2 prologue; dw_pair_kernel under --gemm fp32 | bf16x3 or VASR_DW_MFMA=0)", "bound": "hbm", "achieved": round(dw_gbs, 1),
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": None,
                           "traffic_offline": dw_traffic, "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
                           "launches_per_step": prof["depthwise"]["launches"] // a.steps},
