@@ -108,7 +108,7 @@ def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0):
     def once():
         r = O.forward_all(sig, lens, enc_sd, dec_sd, jas)
         if decoder == "beam":
-            return [BO.decode(r["logp"][i].numpy(), cfg["labels"], 128, lm=lm, table_fill=1434, eos_ignores_cache=True)
+            return [BO.decode(r["logp"][i].numpy(), cfg["labels"], 128, lm=lm)
                     for i in range(b)]
         return O.ctc_decode_strings(r["pred"], cfg["labels"])
 

@@ -134,20 +134,12 @@ def _merge_beams(beams):
     return list(d.values())
 
 
-def _lm_beams(beams, lm, cached_lm, cached_partial, is_eos=False, eos_ignores_cache=False):
+def _lm_beams(beams, lm, cached_lm, cached_partial, is_eos=False):
     out = []
     for text, next_word, word_part, last_char, logit_score in beams:
         new_text = _merge_tokens(text, next_word)
         if lm is None:
             out.append((new_text, "", word_part, last_char, logit_score, logit_score))
-            continue
-        if is_eos and eos_ignores_cache and next_word:
-            # deterministic variant used by the device kernel: a pending word is always scored with </s>,
-            # whatever an earlier frame cached for the same text (pyctcdecode would reuse a non-</s> entry)
-            _, prev_raw, start_state = cached_lm[text]
-            score, _ = lm.score(start_state, next_word, is_last_word=True)
-            lm_score = prev_raw + score
-            out.append((new_text, "", word_part, last_char, logit_score, logit_score + lm_score))
             continue
         if new_text not in cached_lm:
             _, prev_raw, start_state = cached_lm[text]
@@ -163,13 +155,12 @@ def _lm_beams(beams, lm, cached_lm, cached_partial, is_eos=False, eos_ignores_ca
 
 
 def decode_beams(probs, labels, beam_width, lm=None, beam_prune_logp=DEFAULT_BEAM_PRUNE_LOGP,
-                 token_min_logp=DEFAULT_TOKEN_MIN_LOGP, table_fill=None, eos_ignores_cache=False):
+                 token_min_logp=DEFAULT_TOKEN_MIN_LOGP):
     """probs [T, V+1] (rows sum to 1, blank last) -> list of (text, logit_score, combined_score), best first.
 
-    Two switches that are NOT in pyctcdecode mirror the device kernel: ``table_fill`` keeps only the
-    ``table_fill // len(beams)`` most probable characters per frame (the kernel's merge table is finite), and
-    ``eos_ignores_cache`` makes the final </s> scoring independent of pyctcdecode's score cache.
-    """
+    pyctcdecode's loop as published, nothing bent towards the device kernel: every character that clears
+    ``token_min_logp`` is expanded on every beam, and the final </s> pass goes through the LM score cache the frames
+    filled (a text whose commit was scored on an earlier frame keeps that cached score, without </s>)."""
     probs = np.asarray(probs, dtype=np.float64)
     logits = np.log(np.clip(probs, MIN_TOKEN_CLIP_P, 1))          # rows look like probabilities
     idx2vocab = list(labels) + [""]
@@ -178,10 +169,6 @@ def decode_beams(probs, labels, beam_width, lm=None, beam_prune_logp=DEFAULT_BEA
     beams = [("", "", "", None, 0.0)]
     for col in logits:
         idx_list = set(np.where(col >= token_min_logp)[0]) | {int(col.argmax())}
-        if table_fill is not None:
-            cap = max(1, table_fill // len(beams))
-            if len(idx_list) > cap:
-                idx_list = set(sorted(idx_list, key=lambda i: (-col[i], i))[:cap])
         new_beams = []
         for idx in sorted(idx_list):
             p_char, char = col[idx], idx2vocab[idx]
@@ -198,8 +185,7 @@ def decode_beams(probs, labels, beam_width, lm=None, beam_prune_logp=DEFAULT_BEA
         scored.sort(key=lambda b: -b[-1])
         beams = [b[:-1] for b in scored[:beam_width]]
     final = [(text, word_part, "", None, logit_score) for text, _, word_part, _, logit_score in beams]
-    scored = _lm_beams(_merge_beams(final), lm, cached_lm, cached_partial, is_eos=True,
-                       eos_ignores_cache=eos_ignores_cache)
+    scored = _lm_beams(_merge_beams(final), lm, cached_lm, cached_partial, is_eos=True)
     max_score = max(b[-1] for b in scored)
     scored = [b for b in scored if b[-1] >= max_score + beam_prune_logp]
     scored.sort(key=lambda b: -b[-1])

@@ -19,7 +19,10 @@ reference tree and NOT installed here, so they are *parity unpinned*:
   * the mel filterbank (librosa.filters.mel, unpinned, call site
     parts/features.py:199-205) -- restated below from librosa's published
     Slaney-scale algorithm;
-  * beam search (pyctcdecode + kenlm, requirements.txt:16) -- see beam_oracle.py.
+  * beam search (pyctcdecode + kenlm, requirements.txt:16) -- see beam_oracle.py;
+  * the ``stft_conv=True`` STFT (torch_stft, requirements.txt, call site
+    parts/features.py:155-166; configs/quartznet15x5.yaml:26 selects it) --
+    ``torch_stft_magnitude`` below restates its published transform.
 """
 import math
 
@@ -90,12 +93,35 @@ def normalize_batch_per_feature(x, seq_len):
     return (x - x_mean.unsqueeze(2)) / x_std.unsqueeze(2)
 
 
+def torch_stft_magnitude(x, n_fft, hop, win_length, window="hann"):
+    """``torch_stft.STFT(n_fft, hop, win_length, window).transform(x)[0]`` -- PARITY UNPINNED: the package is
+    third-party (pseeth/torch-stft, requirements.txt, unpinned), absent from /root/reference and from this image;
+    the reference holds no test of it.  Call site parts/features.py:155-166 (STFTPatch.forward).  Published
+    algorithm: forward basis = rows [Re; Im] of fft(eye(n_fft))[:n_fft//2+1], each multiplied by
+    ``scipy.signal.get_window(window, win_length, fftbins=True)`` (the PERIODIC window) zero-padded symmetrically to
+    n_fft; the signal is reflect-padded by n_fft//2 on both sides and convolved with the basis at stride ``hop``;
+    magnitude = sqrt(re^2 + im^2).  x [B, L] f32 -> [B, n_fft//2+1, 1 + L//hop] f32."""
+    from scipy.signal import get_window
+    x = torch.as_tensor(x, dtype=torch.float32)
+    cutoff = n_fft // 2 + 1
+    basis = np.fft.fft(np.eye(n_fft))
+    basis = np.vstack([np.real(basis[:cutoff]), np.imag(basis[:cutoff])])
+    win = get_window(window, win_length, fftbins=True)
+    lpad = (n_fft - win_length) // 2                                   # librosa.util.pad_center
+    win = np.pad(win, (lpad, n_fft - win_length - lpad))
+    fwd = torch.FloatTensor(basis[:, None, :]) * torch.from_numpy(win).float()
+    xp = F.pad(x.unsqueeze(1).unsqueeze(1), (n_fft // 2, n_fft // 2, 0, 0), mode="reflect").squeeze(1)
+    t = F.conv1d(xp, fwd, stride=hop, padding=0)
+    return torch.sqrt(t[:, :cutoff] ** 2 + t[:, cutoff:] ** 2)
+
+
 def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_stride=160, n_fft=512,
                     preemph=0.97, nfilt=64, lowfreq=0, highfreq=None, log_zero_guard_value=2 ** -24,
-                    normalize="per_feature", pad_value=0.0, fb=None):
+                    normalize="per_feature", pad_value=0.0, fb=None, stft_conv=False):
     """FilterbankFeatures.forward (parts/features.py:245-301) with dither=0, pad_to=0
     (infer.py:89-90; quirk Q1: the featurizer is never put in eval mode, so no pad-to-16),
-    stft_conv=False, mag_power=2, log guard "add", frame_splicing=1.
+    mag_power=2, log guard "add", frame_splicing=1.  stft_conv=True (unpinned, see
+    torch_stft_magnitude) squares the package's magnitude and skips the re/im sum (:260-263).
 
     x [B, L] float32, length [B] int64 -> (mel [B, nfilt, 1 + L//hop] f32, seq_len [B] i64)
     """
@@ -104,12 +130,15 @@ def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_st
     seq_len = featurizer_seq_len(length, n_window_stride)                      # :246
     if preemph is not None:                                                    # :254-255
         x = torch.cat((x[:, 0].unsqueeze(1), x[:, 1:] - preemph * x[:, :-1]), dim=1)
-    window = torch.hann_window(n_window_size, periodic=False)                  # :179-180
-    # :181-188 torch.stft(center=True) -> reflect pad n_fft//2, window centred in n_fft
-    spec = torch.stft(x, n_fft=n_fft, hop_length=n_window_stride, win_length=n_window_size,
-                      center=True, window=window, return_complex=True, pad_mode="reflect")
-    spec = torch.view_as_real(spec)                                            # legacy [B,F,T,2]
-    p = spec.pow(2.0).sum(-1)                                                  # :260-263
+    if stft_conv:
+        p = torch_stft_magnitude(x, n_fft, n_window_stride, n_window_size).pow(2.0)     # :155-166, :260-261
+    else:
+        window = torch.hann_window(n_window_size, periodic=False)              # :179-180
+        # :181-188 torch.stft(center=True) -> reflect pad n_fft//2, window centred in n_fft
+        spec = torch.stft(x, n_fft=n_fft, hop_length=n_window_stride, win_length=n_window_size,
+                          center=True, window=window, return_complex=True, pad_mode="reflect")
+        spec = torch.view_as_real(spec)                                        # legacy [B,F,T,2]
+        p = spec.pow(2.0).sum(-1)                                              # :260-263
     if fb is None:
         fb = slaney_mel_filterbank(sample_rate, n_fft, nfilt, lowfreq, highfreq or sample_rate / 2)
     fb = torch.as_tensor(fb, dtype=torch.float32).unsqueeze(0)

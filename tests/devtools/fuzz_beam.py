@@ -58,7 +58,7 @@ def run_case(case):
     ids, n, score = dec.decode_ids(x, bw)
     text = dec.decode_batch(x, bw)[0]
     lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=alpha, beta=beta) if path else None
-    ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm, table_fill=1434, eos_ignores_cache=True)
+    ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm)
     close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
     ok_text = text == ref[0][0] or (close and text == ref[1][0])
     ok_score = (not ok_text) or text != ref[0][0] or abs(float(score[0]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50)

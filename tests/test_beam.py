@@ -94,8 +94,7 @@ def test_device_beam_search_matches_oracle(gpu, tmp_path, use_lm, beam_width, V1
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), beam_width)
     lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
     for b in range(3):
-        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), labels, beam_width, lm=lm, table_fill=1434,
-                              eos_ignores_cache=True)
+        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), labels, beam_width, lm=lm)
         # near-ties between the two best hypotheses may legitimately resolve differently (fp rounding)
         close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (texts[b], ref[:2])
@@ -117,7 +116,7 @@ def test_beam_module_on_model_output(gpu):
     out = beam(force_pt=True, log_probs=logp, log_probs_length=None)
     assert isinstance(out, list) and len(out) == 2
     for b in range(2):
-        assert out[b] == BO.decode(g["logp"][b], cfg["labels"], 16, table_fill=1434)
+        assert out[b] == BO.decode(g["logp"][b], cfg["labels"], 16)
     single = beam(force_pt=True, log_probs=logp[:1], log_probs_length=None)
     assert isinstance(single, str) and single == out[0]            # what infer.py consumes: evaluated_tensors[0][0]
 
@@ -125,9 +124,10 @@ def test_beam_module_on_model_output(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_lm", [False, True])
 def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
-    """Flat posteriors over 150 frames: every class clears token_min_logp, so the candidate cap (1434 // n_beams = 22 of
-    29 classes at beam 64) bites on every frame -- the ballot threshold search, multi-pass radix select and heavy prefix
-    merging are all on the path."""
+    """Flat posteriors over 150 frames: every class clears token_min_logp, 64 beams x 29 candidates = 1856 pairs do not
+    fit the merge table (1434), so every frame takes two candidate passes with the first pass's survivors carried into
+    the second selection; multi-digit radix select and heavy prefix merging are all on the path.  Compared with the
+    UNMODIFIED restatement of pyctcdecode (round 2 compared with an oracle capped like the kernel was)."""
     from viet_asr_amd.beam import BeamSearchDecoder
     path, _ = toy_lm(str(tmp_path))
     lp = np.stack([random_posteriors(150, 29, 70 + b, peaky=1.0) for b in range(2)])
@@ -136,7 +136,7 @@ def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), 64)
     lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
     for b in range(2):
-        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, 64, lm=lm, table_fill=1434, eos_ignores_cache=True)
+        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, 64, lm=lm)
         close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (texts[b], ref[:2])
         if texts[b] == ref[0][0]:
@@ -171,8 +171,7 @@ def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), beam_width)
     lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
     for b in range(4):
-        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, beam_width, lm=lm, table_fill=1434,
-                              eos_ignores_cache=True)
+        ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, beam_width, lm=lm)
         close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (b, texts[b], ref[:2])
         if texts[b] == ref[0][0]:

@@ -57,14 +57,24 @@ class AudioToMelSpectrogramPreprocessor(NonTrainableNM):
             n_fft=n_fft, preemph=preemph, features=features, lowfreq=lowfreq, highfreq=highfreq, log=log,
             log_zero_guard_type=log_zero_guard_type, log_zero_guard_value=log_zero_guard_value,
             frame_splicing=frame_splicing, stft_conv=stft_conv, pad_value=pad_value, mag_power=mag_power))
-        # dither adds random noise to the signal (features.py:250-251): not reproducible, not part of the inference
-        # path -- infer.py:89 forces it to 0 and so must the caller here.  pad_to: FilterbankFeatures zero-pads T up to
+        # dither adds random noise to the signal (features.py:250-251): not reproducible, and infer.py:89 forces it to 0.
+        # The constructor default and every shipped YAML say 1e-5, so a module built with the reference's defaults or
+        # from **cfg must construct: a training-time level (<= 1e-4, i.e. <= -80 dB re full scale) is accepted, NOT
+        # applied (the features are the dither=0 ones) and announced once; anything louder is a request for noise this
+        # inference path does not generate and raises.  pad_to: FilterbankFeatures zero-pads T up to
         # a multiple of self.pad_to in training mode -- the mode the executor leaves this NonTrainableNM in, quirk Q1 --
         # and of 16 in eval mode (features.py:292-300); infer.py:90 sets 0 = no padding.  A non-zero pad_to is applied
         # here the way the reference's (training-mode) branch does it: extra all-zero frames appended on the device.
+        if dither and dither > 1e-4:
+            raise NotImplementedError(f"dither={dither!r}: random noise on the input is not generated on this inference "
+                                      "path; pass dither=0 as infer.py:89 does (levels <= 1e-4 are accepted and ignored)")
         if dither:
-            raise NotImplementedError("dither > 0 (random noise on the input) is not implemented: pass dither=0 as "
-                                      "infer.py:89 does")
+            import warnings
+            warnings.warn(f"AudioToMelSpectrogramPreprocessor: dither={dither!r} is not applied (inference path, "
+                          "infer.py:89 sets it to 0); features are those of dither=0", stacklevel=2)
+        if pad_to == "max":
+            raise NotImplementedError("pad_to='max' (pad every batch to max_duration, a training-time option, "
+                                      "features.py:295-296) is not implemented; infer.py:90 uses pad_to=0")
         if pad_to is not None and (int(pad_to) != pad_to or pad_to < 0):
             raise ValueError(f"pad_to must be a non-negative integer, got {pad_to!r}")
         self.dither, self.pad_to = dither, int(pad_to or 0)

@@ -5,8 +5,12 @@
 // and absent (parity unpinned); the algorithm restated here is oracle/beam_oracle.py (file header there).
 //
 // One workgroup (512 threads) per utterance walks the frames; per frame
-//   1. candidate characters {c : logp >= token_min_logp} U {argmax}, capped so the merge table stays < 70 % full:
-//      one wavefront, ballots only (bitwise threshold search when the cap bites);
+//   1. candidate characters {c : logp >= token_min_logp} U {argmax}: one wavefront, ballots only.  The merge table
+//      holds kMaxFill (beam, character) pairs; when a frame has more (flat posteriors: beams x candidates > 1434) the
+//      candidates are taken in several PASSES of steps 2-3.  That is exact, not an approximation: the merge key carries
+//      the candidate as "last character", so pairs of different candidates never merge, and the survivors of the
+//      earlier passes are carried in registers into the next pass's selection (top-k of a union = top-k of the
+//      partial top-ks; the prune threshold only rises from pass to pass and the last pass sees the global maximum);
 //   2. every (beam, character) pair is hashed -- key = hash(prefix string incl. committed spaces, last character) --
 //      into an LDS open-addressing table: identical prefixes MERGE by log-sum-exp (fp64 max via ordered-int
 //      atomicMax, then a 2^-44 fixed-point atomicAdd of exp(score - max): associative, hence deterministic);
@@ -60,6 +64,7 @@ struct Beam {
   int last;                  // last emitted class (blank = V, none = -1)
   int wlen;                  // characters in the partial word
   int ctx[kMaxCtx];          // LM history, most recent last, -1 = empty
+  int cached;                // "text + pending word" already sits in pyctcdecode's LM score cache (see eoslog below)
 };
 
 // Merge table, structure-of-arrays in LDS (consecutive threads touch consecutive words: no bank conflicts):
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
                                                           int space_id, int beam_width, float token_min_logp,
                                                           float beam_prune_logp, LmView lm, int use_lm,
                                                           unsigned int* __restrict__ bp_all,
+                                                          unsigned long long* __restrict__ eoslog_all,
                                                           int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
                                                           float* __restrict__ out_score) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -265,11 +271,15 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   int* hist = cand + kMaxClasses;                              // [256]
   int* misc = hist + 256;                                      // [16] + [16] block-scan scratch
   long long* best = reinterpret_cast<long long*>(misc + 16 + 2 * kWaves + (kWaves & 1) * 0);   // [1] (+1 pad)
-  long long* sel_lgt = best + 2;                                // [kMaxBeams] merged logit of the survivor at each rank
-  float* sl_lmd = reinterpret_cast<float*>(sel_lgt + kMaxBeams);   // [kSlots] LM score of the word a slot commits
+  // the survivor at each rank, as the record a new beam is built from (and the next pass's selection carries on)
+  long long* sel_lgt = best + 2;                                // [kMaxBeams] bits of the merged logit
+  long long* sel_tot = sel_lgt + kMaxBeams;                     // [kMaxBeams] ordered bits of the combined score
+  float* sl_lmd = reinterpret_cast<float*>(sel_tot + kMaxBeams);   // [kSlots] LM score of the word a slot commits
   int* sl_wid = reinterpret_cast<int*>(sl_lmd + kSlots);            // [kSlots] its word id
-  unsigned short* pair_slot = reinterpret_cast<unsigned short*>(sl_wid + kSlots);   // [kMaxFill + 2] slot of a pair
-  unsigned short* sel_slot = pair_slot + kMaxFill + 2;              // [kMaxBeams] slot of the survivor at each rank
+  int* sel_src = sl_wid + kSlots;                                   // [kMaxBeams] (beam << 8) | class
+  float* sel_lmd = reinterpret_cast<float*>(sel_src + kMaxBeams);   // [kMaxBeams]
+  int* sel_wid = reinterpret_cast<int*>(sel_lmd + kMaxBeams);       // [kMaxBeams]
+  unsigned short* pair_slot = reinterpret_cast<unsigned short*>(sel_wid + kMaxBeams);   // [kMaxFill + 2] slot of a pair
 
   const int tid = threadIdx.x, b = blockIdx.x, V = V1 - 1;
   // frames searched: all of them (the reference hands pyctcdecode every frame of its batch-1 tensor), or the row's own
@@ -277,15 +287,22 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
   const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
   const float* lrow = logp + (int64_t)b * frames_ld * V1;
   unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
+  // pyctcdecode caches the LM score of every text it has scored and consults that cache again when the pending word
+  // is scored with </s> after the last frame: a text whose commit (text + ' ') was a candidate of ANY earlier frame
+  // keeps its cached score WITHOUT </s>.  eoslog is that cache's key set: the hash of "text + pending word" of every
+  // beam that met a frame with ' ' among the candidates (once per beam lineage, `cached`); <= frames x kMaxBeams entries.
+  unsigned long long* eoslog = eoslog_all + (int64_t)b * frames_ld * kMaxBeams;
 
   if (tid == 0) {
     Beam s{};
     s.key = kFnvOffset; s.whash = kFnvOffset; s.logit = 0.0; s.lm_text = 0.f; s.last = -1; s.wlen = 0;
     for (int i = 0; i < kMaxCtx; ++i) s.ctx[i] = -1;
     if (use_lm) s.ctx[kMaxCtx - 1] = lm.bos;
+    s.cached = 0;
     beams[0] = s;
     misc[0] = 1;  // live beams
     misc[9] = 0;  // not every live beam ends in blank
+    misc[11] = 0; // entries in eoslog
   }
   lds_barrier();
 
@@ -335,26 +352,17 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
       bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
       bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
       const unsigned long long lt = (1ull << tid) - 1ull;
-      const int cap = max(1, kMaxFill / nb);
-      if (__popcll(__ballot(k0)) + __popcll(__ballot(k1)) > cap) {
-        unsigned thr = 0;   // the cap-th largest wanted key
-        for (int bit = 31; bit >= 0; --bit) {
-          const unsigned trial = thr | (1u << bit);
-          if (__popcll(__ballot(k0 && key0 >= trial)) + __popcll(__ballot(k1 && key1 >= trial)) >= cap) thr = trial;
-        }
-        const int room = cap - (__popcll(__ballot(k0 && key0 > thr)) + __popcll(__ballot(k1 && key1 > thr)));
-        const unsigned long long e0 = __ballot(k0 && key0 == thr), e1 = __ballot(k1 && key1 == thr);
-        k0 = k0 && (key0 > thr || (key0 == thr && __popcll(e0 & lt) < room));
-        k1 = k1 && (key1 > thr || (key1 == thr && __popcll(e0) + __popcll(e1 & lt) < room));
-      }
       const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
       if (k0) cand[__popcll(m0 & lt)] = c0;
       if (k1) cand[__popcll(m0) + __popcll(m1 & lt)] = c1;
-      if (tid == 0) misc[1] = __popcll(m0) + __popcll(m1);
+      if (tid == 0) {
+        misc[1] = __popcll(m0) + __popcll(m1);
+        misc[10] = space_id < 64 ? (int)(m0 >> space_id & 1) : (space_id < 128 ? (int)(m1 >> (space_id - 64) & 1) : 0);
+      }
     }
     BEAM_TICK(10)
     lds_barrier();
-    const int nc = misc[1];
+    const int nc_all = misc[1];
     BEAM_TICK(0)
     // A frame whose only candidate is blank, met by beams that all end in blank already, changes nothing but the
     // scores, and those by the same amount: prefixes and last characters stay distinct (no merge), the LM parts and
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 #ifdef VASR_BEAM_NO_BLANK_EXIT   // dev build for A/B runs
     if (false) {
 #else
-    if (nc == 1 && all_blank && cand[0] == V) {
+    if (nc_all == 1 && all_blank && cand[0] == V) {
 #endif
       if (tid < nb) {
         beams[tid].logit += lp[V];
@@ -374,12 +382,31 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
       continue;
     }
     if (tid == 0) misc[9] = 1;   // cleared below by any new beam that ends in a character
+    const int has_space = misc[10];
+    if (use_lm && has_space && tid < nb) {   // this frame puts "text + pending word" of every live beam into the LM cache
+      const Beam& s = beams[tid];
+      if (s.wlen > 0 && !s.cached) eoslog[atomicAdd(&misc[11], 1)] = hmix(s.key, (unsigned long long)space_id) | 1ull;
+    }
+    const int cap = max(1, kMaxFill / nb);   // candidates per pass: nb * cap pairs fit the merge table
+    constexpr int kSel = kSpt + 1;           // a thread's table slots + the survivor it carries from the earlier passes
+    long long c_tot = ord64(-1e300), c_lgt = 0;
+    int c_src = 0, c_wid = 0, n_sel = 0;
+    float c_lmd = 0.f;
+#pragma unroll 1
+    for (int c_lo = 0; c_lo < nc_all; c_lo += cap) {
+    const int nc = min(cap, nc_all - c_lo);
+    if (c_lo > 0) {
+      if (tid == 0) best[1] = 0;
+#pragma unroll
+      for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.mx[i] = ord64(-1e300); sl.sum[i] = 0; }
+      lds_barrier();
+    }
     // ---- 2. expand: every (beam, character) pair claims / finds its slot and raises the slot's max, then (after a
     //         barrier) adds exp(score - max).  Deliberately NOT unrolled: the kernel must stay inside the 64 KB
     //         instruction cache it shares with the neighbouring CU (68 KB unrolled: every section fetch-bound). ----
 #pragma unroll 1
     for (int p = tid; p < nb * nc; p += kThreads) {
-      const int bi = p / nc, c = cand[p % nc];
+      const int bi = p / nc, c = cand[c_lo + p % nc];
       const Beam& s = beams[bi];
       unsigned long long key = s.key;
       if (!(c == V || c == s.last)) {
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 #pragma unroll 1
     for (int p = tid; p < nb * nc; p += kThreads) {
       const int i = pair_slot[p];
-      const double score = beams[p / nc].logit + lp[cand[p % nc]];
+      const double score = beams[p / nc].logit + lp[cand[c_lo + p % nc]];
       // exp(score - max) through the hardware 2^x (v_exp_f32, 1 ulp): the library's fp64 exp was most of this phase
       // (150+ fp64 instructions per pair, three rounds of them per frame at 1434 pairs), and the sum only has to carry
       // the 1e-7 a float term gives -- the log of it is compared at 1e-3.  exp2(0) is exactly 1, so a slot with a
@@ -419,9 +446,12 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     lds_barrier();
     BEAM_TICK(1)
     // ---- 3. the thread's own slots move into registers; LM scoring of committed words, combined score ----
-    long long tot[kSpt];      // ordered bits of the combined score
-    long long lgt[kSpt];      // bits of the merged logit
-    unsigned live = 0;        // bit j: slot j is occupied (later: and survives the prune)
+    long long tot[kSel];      // ordered bits of the combined score
+    long long lgt[kSel];      // bits of the merged logit
+    unsigned live = 0;        // bit j: slot j is occupied (later: and survives the prune); bit kSpt: the carried survivor
+    tot[kSpt] = tid < n_sel ? c_tot : ord64(-1e300);
+    lgt[kSpt] = c_lgt;
+    if (tid < n_sel) live |= 1u << kSpt;
     {
       unsigned long long k8[kSpt], s8[kSpt];
       long long m8[kSpt];
@@ -475,9 +505,9 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     BEAM_TICK(2)
     // ---- 4. prune (max + beam_prune_logp) and radix-select the top beam_width by combined score ----
     const long long thr_prune = ord64(unord64(*best) + (double)beam_prune_logp);
-    unsigned long long u8[kSpt];   // keys as unsigned radix digits
+    unsigned long long u8[kSel];   // keys as unsigned radix digits
 #pragma unroll
-    for (int j = 0; j < kSpt; ++j) {
+    for (int j = 0; j < kSel; ++j) {
       if (tot[j] < thr_prune) live &= ~(1u << j);
       u8[j] = (unsigned long long)tot[j] ^ 0x8000000000000000ull;
     }
@@ -490,7 +520,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
       const unsigned long long ubest = (unsigned long long)*best ^ 0x8000000000000000ull;
       unsigned long long d = 0;
 #pragma unroll
-      for (int j = 0; j < kSpt; ++j) d |= (live >> j & 1) ? (u8[j] ^ ubest) : 0ull;
+      for (int j = 0; j < kSel; ++j) d |= (live >> j & 1) ? (u8[j] ^ ubest) : 0ull;
       d = ((unsigned long long)wave_or_u32((unsigned)(d >> 32)) << 32) | wave_or_u32((unsigned)d);
       if ((tid & 63) == 0 && d) atomicOr(reinterpret_cast<unsigned long long*>(best + 1), d);
       int tot_live;
@@ -504,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
         // and every thread re-zeroes its own bin right after reading it
         for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
 #pragma unroll
-          for (int j = 0; j < kSpt; ++j)
+          for (int j = 0; j < kSel; ++j)
             if ((live >> j & 1) && (u8[j] & mask) == prefix) atomicAdd(&hist[(int)((u8[j] >> shift) & 255)], 1);
           lds_barrier();
           // the bucket holding the want-th largest key, searched from the top by all threads at once: thread tid owns
@@ -529,7 +559,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     // selected: key > threshold prefix, plus the first `want` (in thread-major slot order) equal to it
     unsigned gt = 0, eq = 0;
 #pragma unroll
-    for (int j = 0; j < kSpt; ++j) {
+    for (int j = 0; j < kSel; ++j) {
       if (!(live >> j & 1)) continue;
       const unsigned long long u = u8[j] & mask;
       if (mask == 0 || u > prefix) gt |= 1u << j; else if (u == prefix) eq |= 1u << j;
@@ -541,20 +571,34 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     const int n_new = min(kMaxBeams, tot_gt + take_eq);
     BEAM_TICK(6)
     {
-      // survivors publish (slot, merged logit) at their rank; the new beams are then built one per thread
+      // survivors publish their record at their rank (nobody reads the records while they are written: the carried
+      // ones live in registers); after the last pass the new beams are built from them, one per thread
       int ig = off_gt, ie = off_eq;
 #pragma unroll
-      for (int j = 0; j < kSpt; ++j) {
+      for (int j = 0; j < kSel; ++j) {
         int dst = -1;
         if (gt >> j & 1) dst = ig++;
         else if (eq >> j & 1) { if (ie < take_eq) dst = tot_gt + ie; ++ie; }
-        if (dst >= 0 && dst < kMaxBeams) { sel_slot[dst] = (unsigned short)(tid + kThreads * j); sel_lgt[dst] = lgt[j]; }
+        if (dst >= 0 && dst < kMaxBeams) {
+          if (j < kSpt) {
+            const int i = tid + kThreads * j;
+            sel_src[dst] = sl.src[i]; sel_lmd[dst] = sl_lmd[i]; sel_wid[dst] = sl_wid[i];
+          } else {
+            sel_src[dst] = c_src; sel_lmd[dst] = c_lmd; sel_wid[dst] = c_wid;
+          }
+          sel_lgt[dst] = lgt[j]; sel_tot[dst] = tot[j];
+        }
       }
     }
+    n_sel = n_new;
     lds_barrier();
+    if (c_lo + cap < nc_all && tid < n_sel) {   // more candidates to come: this thread carries the survivor of its rank
+      c_tot = sel_tot[tid]; c_lgt = sel_lgt[tid]; c_src = sel_src[tid]; c_lmd = sel_lmd[tid]; c_wid = sel_wid[tid];
+    }
+    }   // passes
+    const int n_new = n_sel;
     if (tid < n_new) {
-      const int i = sel_slot[tid];
-      const int bi = sl.src[i] >> 8, c = sl.src[i] & 255;
+      const int bi = sel_src[tid] >> 8, c = sel_src[tid] & 255;
       const Beam& s = beams[bi];
       Beam n = s;
       const bool stay = (c == V || c == s.last);
@@ -565,9 +609,9 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
             n.key = hmix(s.key, (unsigned long long)c);
             appended = c + 1;
             if (use_lm) {
-              n.lm_text = s.lm_text + sl_lmd[i];
+              n.lm_text = s.lm_text + sel_lmd[tid];
               for (int q = 0; q < kMaxCtx - 1; ++q) n.ctx[q] = s.ctx[q + 1];
-              n.ctx[kMaxCtx - 1] = sl_wid[i];
+              n.ctx[kMaxCtx - 1] = sel_wid[tid];
             }
             n.wlen = 0; n.whash = kFnvOffset;
           }
@@ -579,6 +623,8 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
         }
       }
       n.last = c;
+      // same text and pending word as the parent: in the LM cache if the parent was, or if this frame put it there
+      n.cached = stay ? (s.cached | (has_space && s.wlen > 0)) : 0;
       if (c != V) misc[9] = 0;
       n.logit = __longlong_as_double(sel_lgt[tid]);
       nbeams[tid] = n;
@@ -599,6 +645,43 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best ----
   const int nb = misc[0];
+  // Is "text + pending word" in pyctcdecode's LM cache (then its cached score, WITHOUT </s>, is what the final pass uses)?
+  // Known for beams whose own lineage put it there (`cached`); the others look their hash up in eoslog: their hashes go
+  // into the (now idle) merge table, every thread walks a stride of the log and marks the hashes it meets.
+  int in_cache = 0;
+  if (use_lm) {
+    const int nlog = misc[11];
+    __syncthreads();   // the log's stores have left the CU
+#pragma unroll
+    for (int j = 0; j < kSpt; ++j) { const int i = tid + kThreads * j; sl.key[i] = 0; sl.src[i] = 0; }
+    lds_barrier();
+    int myslot = -1;
+    if (tid < nb && beams[tid].wlen > 0) {
+      in_cache = beams[tid].cached;
+      if (!in_cache && nlog > 0) {
+        const unsigned long long k = hmix(beams[tid].key, (unsigned long long)space_id) | 1ull;
+        int i = (int)((k >> 17) & (kSlots - 1));
+        while (true) {
+          const unsigned long long old = atomicCAS(&sl.key[i], 0ull, k);
+          if (old == 0ull || old == k) break;
+          i = (i + 1) & (kSlots - 1);
+        }
+        myslot = i;
+      }
+    }
+    lds_barrier();
+    for (int q = tid; q < nlog; q += kThreads) {
+      const unsigned long long k = __hip_atomic_load(&eoslog[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = (int)((k >> 17) & (kSlots - 1));; i = (i + 1) & (kSlots - 1)) {
+        const unsigned long long e = sl.key[i];
+        if (e == k) { sl.src[i] = 1; break; }
+        if (e == 0) break;
+      }
+    }
+    lds_barrier();
+    if (myslot >= 0) in_cache = sl.src[myslot];
+    lds_barrier();   // sl.key / sl.mx are reused below
+  }
   double* fin = lp;  // [kMaxBeams] combined score per beam
   unsigned long long* fkey = sl.key;  // [kMaxBeams]
   double* frank = reinterpret_cast<double*>(sl.mx);   // [kMaxBeams]
@@ -608,7 +691,7 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
     if (use_lm) {
       float lmv = s.lm_text;
       int wid;
-      if (s.wlen > 0) lmv += lm_word_score(lm, s.ctx, s.whash, true, &wid);
+      if (s.wlen > 0) lmv += lm_word_score(lm, s.ctx, s.whash, !in_cache, &wid);
       total += (double)lmv;
     }
     fin[tid] = total;
@@ -658,13 +741,14 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 
 size_t beam_lds_bytes() {
   return kSlotBytes + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 16 + 2 * kWaves) + 16 +
-         8 * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2 + kMaxBeams) + 16;
+         (8 + 8 + 4 + 4 + 4) * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2) + 16;
 }
 
 int launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
                         float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
                         int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                         const int32_t* row_frames) {
+  unsigned long long* eoslog = reinterpret_cast<unsigned long long*>(bp + (size_t)batch * frames * kMaxBeams);
   LmView v{};
   int use_lm = 0;
   if (lm) {
@@ -678,7 +762,7 @@ int launch_beam_search(const float* logp, int batch, int frames, int V1, int spa
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)beam_lds_bytes());
   if (attr != hipSuccess) return (int)attr;
   hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, row_frames, V1, space_id,
-                     beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, out_ids, out_len, out_score);
+                     beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len, out_score);
   return 0;
 }
 

@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void dw_conv_generic_kernel(const float* __res
 // MaskedConv1d.get_seq_len chain (jasper.py:108-111): lens.to(long) for the mask, then
 // (lens + 2p - d(K-1) - 1) / stride + 1 as a FLOAT tensor (quirk Q3).
 __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, const LenStep* __restrict__ steps,
-                                 int n_steps, int32_t* __restrict__ lens_tab, float* __restrict__ enc_len) {
+                                 int n_steps, int32_t* __restrict__ lens_tab, float* __restrict__ enc_len,
+                                 const int64_t* __restrict__ wav_len, int hop, int frames_cap) {
   // The chain is serial per utterance and one wavefront runs it alone, so its cost is the length of the dependent
   // instruction sequence of one iteration: the step table goes through LDS once (no dependent global load, and no
   // vector-memory wait inside the loop), the arithmetic is 32-bit (frame counts are far below 2^24, where the
@@ -537,6 +538,17 @@ __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, con
   for (int s = n_lds; s < n_steps; ++s) advance(s, steps[s]);
   lens_tab[(int64_t)n_steps * batch + b] = (int32_t)(int64_t)lf;
   if (enc_len) enc_len[b] = lf;
+  if (wav_len) {
+    // row n_steps + 1: the output frames an UNBATCHED call on this row would produce (row-independent mode) --
+    // torch.stft(center=True) gives 1 + L // hop frames, every conv floor((t + 2 p - d (K - 1) - 1) / stride) + 1;
+    // the same count ctc_collapse_kernel stops at
+    int64_t t = 1 + wav_len[b] / hop;
+    for (int s = 0; s < n_steps; ++s) {
+      const LenStep st = s < n_lds ? sh_steps[s] : steps[s];
+      t = (t + 2 * st.pad - st.dilation * (st.kernel - 1) - 1) / st.stride + 1;
+    }
+    lens_tab[(int64_t)(n_steps + 1) * batch + b] = (int32_t)(t < 0 ? 0 : (t < frames_cap ? t : frames_cap));
+  }
 }
 
 // [rows][frames] (pitch src_ld) -> [rows][dst_ld], zero filled past `frames`
@@ -661,9 +673,9 @@ void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t
 }
 
 void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
-                      float* enc_len, hipStream_t st) {
+                      float* enc_len, hipStream_t st, const int64_t* wav_len, int hop, int frames_cap) {
   hipLaunchKernelGGL(len_chain_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, seq, batch, d_steps, n_steps,
-                     lens_tab, enc_len);
+                     lens_tab, enc_len, wav_len, hop, frames_cap);
 }
 
 void launch_repad(const float* src, int64_t src_ld, int rows, int frames, float* dst, int64_t dst_ld,

@@ -202,7 +202,9 @@ void launch_t(const PwArgs& a, hipStream_t st) {
 }  // namespace
 
 void launch_pointwise(const PwArgs& a, hipStream_t st) {
-  // M % 128 == 0, K % 32 == 0 and ldx % 256 == 0 are guaranteed by vasr_finalize()/pad_frames().
+  // M % 128 == 0 and K % 64 == 0 are guaranteed by vasr_finalize() (and checked by vasr_bench_pointwise), ldx % 128 == 0
+  // by pad_frames().  The 128 x 256 tile (K % 32 shapes) assumes a 256-frame pitch, which pad_frames() stopped giving in
+  // round 2: it only runs when the pitch allows it, and no caller can reach it with K % 64 != 0 any more.
   // Tile choice: cover all of M with one workgroup where possible (each activation fetched once), and keep
   // >= 2 workgroups per CU in flight: 512 ch -> 512x64 tiles, 256 ch -> 256x64 (one m-tile per wave), else 128x128.
   static const int force = getenv("VASR_PW_TILE") ? atoi(getenv("VASR_PW_TILE")) : 0;
@@ -212,7 +214,7 @@ void launch_pointwise(const PwArgs& a, hipStream_t st) {
   else if (a.M % 256 == 0 && k128 && force != 42) launch_t<8, 1>(a, st);
   else if (a.M % 256 == 0 && k64) launch_t<4, 2>(a, st);
   else if (k64) launch_t<4, 1>(a, st);
-  else launch_t<2, 2>(a, st);
+  else launch_t<2, 2>(a, st);   // K % 32 shapes on a 256-frame pitch only (unreachable through the C ABI today)
 }
 
 // [cout][cin] row-major -> MFMA A-fragment order [m_pad/32][cin/8][64 lanes][4]:

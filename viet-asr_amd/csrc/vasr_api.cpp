@@ -427,7 +427,7 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
                                         : p.Tp1;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
-  p.lens_tab = take((h->steps.size() + 1) * (size_t)batch * 4);
+  p.lens_tab = take((h->steps.size() + 2) * (size_t)batch * 4);   // + the row-independent frame counts
   // maxima tables of the fp16-split arithmetic (AmaxTab): in flight at any time are the block input's, the current
   // kernel's input's and its output's -- kAmaxTabs = 4 rotate.  Capacity: the most slots any producer may use.
   p.amax_stride = 64;
@@ -524,10 +524,17 @@ static int run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStrea
 // output pitch), for the CTC head of the fused path; the table lives in the workspace until the next encoder pass.
 int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const int64_t* seq, int batch,
                 float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st,
-                AmaxTab* enc_amax = nullptr) {
+                AmaxTab* enc_amax = nullptr, const int64_t* wav_len = nullptr, const int32_t** own_frames = nullptr) {
   int32_t* lens_tab = reinterpret_cast<int32_t*>(ws + p.lens_tab);
   auto lens = [&](int step) { return lens_tab + (size_t)step * batch; };
-  launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st);
+  // row-independent mode (fused path): everything the CTC head sees of a row must depend on that row alone, also the
+  // fp16 scale of its input -- the encoder output's maxima are then taken over the frames an unbatched call on the row
+  // would produce, and the head zeroes the columns behind them (they are not decoded in this mode)
+  const bool own = h->row_independent && wav_len != nullptr;
+  launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st, own ? wav_len : nullptr,
+                   h->fe.hop_length, (int)p.T1);
+  const int32_t* own_tab = own ? lens((int)h->steps.size() + 1) : nullptr;
+  if (own_frames) *own_frames = own_tab;
   float* bufs[4] = {reinterpret_cast<float*>(ws + p.bufP), reinterpret_cast<float*>(ws + p.bufQ),
                     reinterpret_cast<float*>(ws + p.bufR), reinterpret_cast<float*>(ws + p.bufS)};
   float* D = reinterpret_cast<float*>(ws + p.bufD);
@@ -623,7 +630,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // (the encoder output's maxima are only wanted by the fused path's CTC head, which reads every column < T')
       if (want_amax && (!(last_block && last_sub) || enc_amax)) {
         a.amax_y = free_tab(gx_amax);
-        a.lens_y = (last_block && last_sub) ? nullptr : lens(S.pw.step + 1);
+        a.lens_y = (last_block && last_sub) ? own_tab : lens(S.pw.step + 1);
       }
       int published;
       {
@@ -640,10 +647,11 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
 }
 
 int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int batch, float* logits, float* logp,
-                int64_t* pred, hipStream_t st, AmaxTab enc_amax = AmaxTab{}) {
+                int64_t* pred, hipStream_t st, AmaxTab enc_amax = AmaxTab{}, const int32_t* own_frames = nullptr) {
   PwArgs a{};
   a.busy_cus = h->busy_cus;
-  a.wt = h->dec.d_w; a.x = encp; a.lens = nullptr; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
+  // own_frames (row-independent mode): columns past the row's own frame count are read as zero
+  a.wt = h->dec.d_w; a.x = encp; a.lens = own_frames; a.scale = h->dec.d_scale; a.shift = h->dec.d_shift;
   a.res = nullptr; a.y = logits; a.M = h->dec.m_pad; a.K = h->dec.cin; a.batch = batch;
   a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)T1; a.store_cols = (int)ld; a.m_store = h->num_classes;
   a.relu = 0;
@@ -861,9 +869,10 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
     launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
   }
   AmaxTab enc_amax{};
-  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st, &enc_amax);
+  const int32_t* own_frames = nullptr;
+  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st, &enc_amax, d_len, &own_frames);
   if (rc) return rc;
-  if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st, enc_amax))) return rc;
+  if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st, enc_amax, own_frames))) return rc;
   if (d_ids && d_id_len) {
     ProfScope ps(h, kProfHead, st);
     if (h->row_independent)
@@ -993,7 +1002,8 @@ int vasr_set_slices(vasr_handle* h, int slices) {
 }
 
 size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
-  return batch > 0 && frames > 0 ? (size_t)batch * frames * kBeamMax * sizeof(unsigned int) : 0;
+  // back-pointer rows [B][T][128] u32, then the LM-cache key log [B][T * 128] u64 (beam.hip: eoslog)
+  return batch > 0 && frames > 0 ? (size_t)batch * frames * kBeamMax * (sizeof(unsigned int) + sizeof(uint64_t)) : 0;
 }
 
 int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
@@ -1184,7 +1194,8 @@ int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h
 
 int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift, int batch,
                          int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
-  if (!d_x || !d_wt || !d_scale || !d_shift || !d_y || cout % 128 || cin % 32)
+  // in_channels % 64 like vasr_load_weight: the K % 32 tile (128 x 256) assumes a 256-frame pitch pad_frames() no longer gives
+  if (!d_x || !d_wt || !d_scale || !d_shift || !d_y || cout % 128 || cin % 64)
     return fail(VASR_ERR_INVALID, "bad argument");
   const int64_t ld = pad_frames(frames);
   PwArgs a{};

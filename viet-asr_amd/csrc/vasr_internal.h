@@ -77,9 +77,10 @@ void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch,
 // ---- encoder (encoder_dw.hip, encoder_pw.hip) ----
 struct LenStep { int32_t kernel, stride, dilation, pad; };
 // lens_tab[s][b] = mask length seen by the s-th MaskedConv1d of the main chain; row n_steps = after
-// the last one; enc_len[b] = the reference's float length (quirk Q3).
+// the last one; enc_len[b] = the reference's float length (quirk Q3).  wav_len (optional): row n_steps + 1 = the
+// output frames an unbatched call on the row would produce, capped at frames_cap (row-independent mode).
 void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
-                      float* enc_len, hipStream_t st);
+                      float* enc_len, hipStream_t st, const int64_t* wav_len = nullptr, int hop = 1, int frames_cap = 0);
 
 void launch_repad(const float* src, int64_t src_ld, int rows, int frames, float* dst, int64_t dst_ld,
                   hipStream_t st);
