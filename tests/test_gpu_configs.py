@@ -79,6 +79,36 @@ def test_config3_quartznet15x5_b64_10s_full_size(gpu):
     assert torch.equal(n2, r["id_len"]) and _prefix_equal(ids2, r["ids"], n2)
 
 
+def test_config2_quartznet12x1_vi_b32_10s_full_size(gpu):
+    """BASELINE configs[1] at its own size (QuartzNet12x1, Vietnamese head of 91 classes, 32 x 10 s), default GEMM
+    arithmetic: three sampled full-length rows against the oracle -- round 2 checked this size through properties only
+    -- and the properties on all 32."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    from oracle import quartznet_oracle as O
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    enc_sd, dec_sd = synth.encoder_state_dict(jas, 64, 2), synth.decoder_state_dict(1024, 91, 2)
+    eng = QuartzNetCTC(cfg, enc_sd, dec_sd)
+    sig, lens = synth.audio_batch(32, 160000, 2)
+    wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    r = eng.forward(wav, ln, want_logp=True)
+    r2 = eng.forward(wav, ln, want_logp=True)
+    assert torch.equal(r["logp"], r2["logp"]) and torch.equal(r["pred"], r2["pred"])
+    assert r["logp"].shape == (32, 501, 91) and bool(torch.isfinite(r["logp"]).all())
+    assert float(torch.logsumexp(r["logp"].double(), -1).abs().max()) < 1e-3
+    assert torch.equal(r["logp"].argmax(-1), r["pred"])
+    assert r["enc_len"].tolist() == [500.0] * 32
+    for b in (0, 13, 31):
+        ref = O.forward_all(sig[b:b + 1], lens[b:b + 1], enc_sd, dec_sd, jas)
+        _row_check(r, b, ref, "config2")
+        assert eng.texts(r["ids"][b:b + 1], r["id_len"][b:b + 1]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
+    pred = r["pred"].cpu().numpy()
+    ids, n = r["ids"].cpu().numpy(), r["id_len"].cpu().numpy()
+    for b in range(32):
+        assert ids[b, : n[b]].tolist() == O.ctc_collapse_ids(pred[b], 90)
+
+
 def _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag):
     from oracle import beam_oracle as BO
     for b in rows:

@@ -60,6 +60,26 @@ def test_quirks_are_in_the_goldens():
     assert g["pred"].shape[1] == int(max(g["enc_len"]))
 
 
+def test_torch_stft_restatement_is_the_periodic_window_dft():
+    """stft_conv=True (PARITY UNPINNED, torch_stft absent): the oracle restates the package as a conv1d with a windowed
+    Fourier basis; an independent formulation -- torch.stft with the periodic window -- must give the same magnitudes,
+    and the symmetric window (stft_conv=False) must not."""
+    import torch
+    from oracle import quartznet_oracle as O
+    x = torch.randn(3, 5000, generator=torch.Generator().manual_seed(0))
+    m = O.torch_stft_magnitude(x, 512, 160, 320)
+    per = torch.stft(x, 512, 160, 320, window=torch.hann_window(320, periodic=True), center=True, return_complex=True,
+                     pad_mode="reflect").abs()
+    sym = torch.stft(x, 512, 160, 320, window=torch.hann_window(320, periodic=False), center=True, return_complex=True,
+                     pad_mode="reflect").abs()
+    assert m.shape == per.shape == (3, 257, 32)
+    assert float((m - per).abs().max()) < 1e-4 * float(per.max())
+    assert float((m - sym).abs().max()) > 1e-3 * float(per.max())
+    a, _ = O.melspec_forward(x.numpy(), [5000, 4000, 3000], stft_conv=True)
+    b, _ = O.melspec_forward(x.numpy(), [5000, 4000, 3000], stft_conv=False)
+    assert a.shape == b.shape and float((a - b).abs().max()) > 1e-2
+
+
 def test_ctc_collapse_rules():
     blank = 5
     assert O.ctc_collapse_ids([5, 5, 1, 1, 5, 1, 2, 2, 5], blank) == [1, 1, 2]

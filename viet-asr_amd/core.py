@@ -346,30 +346,43 @@ _GATHER_DTYPES = [torch.float32, torch.int64, torch.int32, torch.float64, torch.
 
 
 def _gather_ragged(v, device):
-    """all_gather of one tensor per rank whose shapes may differ, as PtActions._infer does it (actions.py:774-807:
-    all_gather(shape) -> pad to max -> all_gather(padded) -> de-pad), extended by one case: ``v is None`` = this rank
-    has no batch left; its (empty) part is dropped.  Returns the de-padded parts of the ranks that had one, in rank
-    order, or None when no rank had a tensor."""
+    """all_gather of one port value per rank, as PtActions._infer does it for tensors (actions.py:774-807:
+    all_gather(shape) -> pad to max -> all_gather(padded) -> de-pad), extended by two cases: ``v is None`` = this rank
+    has no batch left (its empty part is dropped), and a non-tensor value (the batched beam decoder's list of
+    transcripts), which travels through all_gather_object.  EVERY rank calls this for EVERY port on EVERY step and all
+    decisions are taken from the descriptors all ranks hold after the first collective -- a rank may not decide from its
+    own value alone whether the port is gathered (round 2 did: a rank that still had a list skipped the call, a rank
+    that had run out entered it, and its all_gathers paired up with the other rank's next port).
+    Returns the parts of the ranks that had one, in rank order; [] when no rank had anything."""
     import torch.distributed as dist
     world = dist.get_world_size()
-    desc = torch.full((10,), -1, dtype=torch.int64, device=device)       # [ndim, dtype code, dims...]
-    if v is not None:
+    desc = torch.full((10,), -1, dtype=torch.int64, device=device)       # [ndim | -1 nothing | -2 object, dtype code, dims...]
+    is_tensor = isinstance(v, torch.Tensor)
+    if is_tensor:
         if v.dim() > 8:
             raise ValueError("tensors of more than 8 dimensions are not gathered")
         desc[0], desc[1] = v.dim(), _GATHER_DTYPES.index(v.dtype)
         if v.dim():
             desc[2 : 2 + v.dim()] = torch.tensor(v.shape, dtype=torch.int64)
+    elif v is not None:
+        desc[0] = -2
     descs = [torch.empty_like(desc) for _ in range(world)]
     dist.all_gather(descs, desc)
     descs = [d.tolist() for d in descs]
     have = [d for d in descs if d[0] >= 0]
+    if any(d[0] == -2 for d in descs):
+        if have:
+            raise ValueError("ranks returned a tensor and a non-tensor value for one port")
+        objs = [None] * world
+        dist.all_gather_object(objs, v)
+        return [o for o, d in zip(objs, descs) if d[0] == -2]
     if not have:
-        return None
+        return []
     ndim, dtype = have[0][0], _GATHER_DTYPES[have[0][1]]
     if any(d[0] != ndim or d[1] != have[0][1] for d in have):
         raise ValueError("ranks returned tensors of different rank / dtype for one port")
     mx = [max(d[2 + i] for d in have) for i in range(ndim)]
-    padded = _pad_to(v, mx) if v is not None else torch.zeros(mx, dtype=dtype, device=device)
+    padded = _pad_to(v, mx) if is_tensor else torch.zeros(mx, dtype=dtype, device=device)
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded)
     return [g[tuple(slice(0, int(n)) for n in d[2 : 2 + ndim])] for g, d in zip(gathered, descs) if d[0] >= 0]
@@ -460,17 +473,24 @@ class _Actions:
             # by itself (data_iterator) may leave ranks with different counts -- 5 utterances, 2 ranks, batch 2 gives 2
             # and 1 -- and the rank with more would wait in all_gather for ever.  Every rank therefore takes
             # max-over-ranks steps; a rank that has run out joins the collectives with an empty contribution.
-            if not hasattr(loader, "__len__"):
-                raise ValueError("AllGpu placement needs a data iterator with a length")
-            n = torch.tensor([len(loader)], dtype=torch.int64, device=dl._device)
+            # A loader without a length (the reference accepts a plain iterator / generator as data_iterator,
+            # actions.py:697-707) agrees on termination step by step instead: MAX over ranks of "I still have a batch".
+            n = torch.tensor([len(loader) if hasattr(loader, "__len__") else -1], dtype=torch.int64, device=dl._device)
+            lo = n.clone()
             dist.all_reduce(n, op=dist.ReduceOp.MAX)
-            n_steps = int(n.item())
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            n_steps = int(n.item()) if int(lo.item()) >= 0 else -1      # -1: some rank cannot tell -> per-step flag
         with torch.no_grad():
             it = iter(loader)
             step = 0
             while True:
                 data = next(it, None)
-                if data is None and (n_steps is None or step >= n_steps):
+                if n_steps == -1:
+                    more = torch.tensor([0 if data is None else 1], dtype=torch.int64, device=dl._device)
+                    dist.all_reduce(more, op=dist.ReduceOp.MAX)
+                    if int(more.item()) == 0:
+                        break
+                elif data is None and (n_steps is None or step >= n_steps):
                     break
                 step += 1
                 registered = None
@@ -482,14 +502,10 @@ class _Actions:
                     self.forward_pass(chain, registered)
                 for t in tensors:
                     v = registered[t.unique_name] if registered is not None else None
-                    if distributed and (v is None or isinstance(v, torch.Tensor)):
+                    if distributed:
                         parts = _gather_ragged(v, dl._device)
-                        if parts is None:             # no rank holds a tensor for this port (e.g. strings): keep local
-                            if v is not None:
-                                values[t.unique_name].append(v)
-                            continue
                         if offload_to_cpu:
-                            parts = [p.cpu() for p in parts]
+                            parts = [p.cpu() if isinstance(p, torch.Tensor) else p for p in parts]
                         if dist.get_rank() == 0:
                             values[t.unique_name] += parts
                     elif v is not None:

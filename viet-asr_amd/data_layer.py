@@ -5,8 +5,9 @@ parts/manifest.py:21-94 (JSON-lines entries with ``audio_filepath``, ``duration`
 parts/dataset.py:14-53 (``seq_collate_fn``: zero-pad signals and tokens to the batch maximum),
 parts/parsers.py (character parser: unknown characters dropped).  Decoding is PCM-WAV only (audio.py); files at
 another rate are resampled on the device by the caller (``VietASR`` / ``audio.resample``), so this layer tags
-every batch with its source rate.  With ``AllGpu`` placement the utterance list is sharded contiguously by rank
-(the reference shards with a DistributedSampler, data_layer.py:161-165).
+every batch with its source rate.  With ``AllGpu`` placement the utterance list is sharded by rank: by default in
+duration-balanced length buckets (``dist.balanced_shards``; ``shard_by="count"`` keeps contiguous equal-count shards
+in manifest order -- the reference shards with a DistributedSampler, data_layer.py:161-165, equal counts too).
 """
 import json
 
@@ -15,7 +16,7 @@ import torch
 
 from .audio import read_wav
 from .core import AudioSignal, DataLayerNM, DeviceType, LengthsType, NeuralType
-from .dist import shard_range
+from .dist import balanced_shards, shard_range
 
 
 class ChannelIndexType(LengthsType):
@@ -31,7 +32,7 @@ class AudioToTextDataLayer(DataLayerNM):
                 "transcript_length": NeuralType(tuple("B"), LengthsType())}
 
     def __init__(self, manifest_filepath, labels, batch_size, sample_rate=16000, min_duration=0.1, max_duration=None,
-                 shuffle=False, bucket_by_length=True, drop_last=False, pad_id=None, **_unused):
+                 shuffle=False, bucket_by_length=True, drop_last=False, pad_id=None, shard_by="duration", **_unused):
         super().__init__()
         self._sample_rate, self._batch_size, self._shuffle = sample_rate, batch_size, shuffle
         self.labels = list(labels)
@@ -48,14 +49,26 @@ class AudioToTextDataLayer(DataLayerNM):
                     if (min_duration and d and d < min_duration) or (max_duration and d > max_duration):
                         continue                       # manifest.py filters by duration the same way
                     items.append((e["audio_filepath"], d, e.get("text", "")))
+        if shard_by not in ("duration", "count"):
+            raise ValueError(f"shard_by must be 'duration' or 'count', got {shard_by!r}")
+        self.manifest_index = list(range(len(items)))        # position of every kept item in the (filtered) manifest
+        batches = None
         if self.placement == DeviceType.AllGpu and torch.distributed.is_available() and torch.distributed.is_initialized():
-            lo, hi = shard_range(len(items), torch.distributed.get_rank(), torch.distributed.get_world_size())
-            items = items[lo:hi]
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            if shard_by == "duration" and all(it[1] > 0 for it in items):
+                # length buckets of batch_size utterances dealt heaviest-first to the least loaded rank: the ranks'
+                # padded work (rows x longest row, summed over batches) ends up within a few percent of each other
+                batches = [sorted(b, key=lambda i: (items[i][1], i)) for b in balanced_shards([it[1] for it in items], world, batch_size)[rank]]
+                batches.sort(key=lambda b: items[b[0]][1])
+            else:
+                lo, hi = shard_range(len(items), rank, world)
+                self.manifest_index = self.manifest_index[lo:hi]
+                items = items[lo:hi]
         order = list(range(len(items)))
         if bucket_by_length and not shuffle:
             order.sort(key=lambda i: items[i][1])    # similar lengths share a batch: less padding work
         self._items, self._order = items, order
-        self._batches = [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
+        self._batches = batches if batches is not None else [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
         if drop_last and self._batches and len(self._batches[-1]) < batch_size:
             self._batches.pop()
 
@@ -74,8 +87,8 @@ class AudioToTextDataLayer(DataLayerNM):
         return _BatchIter(self)
 
     def utterance_order(self):
-        """Manifest indices in the order the batches deliver them."""
-        return [i for b in self._batches for i in b]
+        """Indices into the (duration-filtered) manifest, in the order the batches deliver them."""
+        return [self.manifest_index[i] for b in self._batches for i in b]
 
 
 class _BatchIter:

@@ -18,12 +18,44 @@ def shard_range(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_id_sequences(ids, id_len, group=None):
+def balanced_shards(durations, world_size, batch_size=None):
+    """Duration-balanced utterance shards: -> ``world_size`` lists of BATCHES (each a list of utterance indices).
+
+    The cost of a padded batch is rows x longest row (every row is computed at the batch's width), so utterances are
+    first bucketed by length -- sorted by duration, cut into batches of ``batch_size`` (None: one utterance per
+    "batch") -- and the batches are then dealt to the ranks longest-processing-time-first: heaviest batch to the least
+    loaded rank.  Contiguous count-based shards of a manifest in recording order can differ by the ratio of the longest
+    to the shortest recordings; this keeps the ranks' padded work within a few percent ("length-bucketing
+    matters more than the collective").  The reference shards with a DistributedSampler
+    (nemo/backends/pytorch/actions.py:669-693): equal COUNTS per rank, no notion of length.
+    Deterministic: ties go to the lower index / lower rank, so every rank computes the same assignment locally."""
+    import heapq
+    d = [float(x) for x in durations]
+    order = sorted(range(len(d)), key=lambda i: (-d[i], i))
+    bs = max(1, int(batch_size)) if batch_size else 1
+    batches = [order[i:i + bs] for i in range(0, len(order), bs)]
+    cost = [len(b) * d[b[0]] for b in batches]                  # b[0] is the longest row of its batch
+    heap = [(0.0, r) for r in range(world_size)]
+    shards = [[] for _ in range(world_size)]
+    for k in sorted(range(len(batches)), key=lambda k: (-cost[k], k)):
+        load, r = heapq.heappop(heap)
+        shards[r].append(batches[k])
+        heapq.heappush(heap, (load + cost[k], r))
+    return shards
+
+
+def shard_cost(shard, durations):
+    """Padded work of one rank's list of batches: sum of rows x longest row."""
+    return sum(len(b) * max(float(durations[i]) for i in b) for b in shard if b)
+
+
+def gather_id_sequences(ids, id_len, group=None, extra=None):
     """ids [B_loc, T] int32 (compacted rows), id_len [B_loc] int32 -> on every rank the concatenation over
-    ranks in rank order as (ids [B_tot, T_max], id_len [B_tot]).  Shards may differ in B_loc and T."""
+    ranks in rank order as (ids [B_tot, T_max], id_len [B_tot]).  Shards may differ in B_loc and T.
+    extra: optional [B_loc] integer tensor gathered alongside (e.g. the rows' manifest indices); returned third."""
     world = dist.get_world_size(group)
     if world == 1:
-        return ids, id_len
+        return (ids, id_len) if extra is None else (ids, id_len, extra)
     shape = torch.tensor(ids.shape, dtype=torch.int64, device=ids.device)
     shapes = [torch.empty_like(shape) for _ in range(world)]
     dist.all_gather(shapes, shape, group=group)
@@ -37,25 +69,51 @@ def gather_id_sequences(ids, id_len, group=None):
     dist.all_gather(all_ids, padded, group=group)
     dist.all_gather(all_len, plen, group=group)
     rows = [int(s[0]) for s in shapes]
-    return (torch.cat([a[:r] for a, r in zip(all_ids, rows)]), torch.cat([l[:r] for l, r in zip(all_len, rows)]))
+    out = (torch.cat([a[:r] for a, r in zip(all_ids, rows)]), torch.cat([l[:r] for l, r in zip(all_len, rows)]))
+    if extra is None:
+        return out
+    pex = extra.new_zeros((mx[0],))
+    pex[: extra.shape[0]] = extra
+    all_ex = [torch.empty_like(pex) for _ in range(world)]
+    dist.all_gather(all_ex, pex, group=group)
+    return out + (torch.cat([e[:r] for e, r in zip(all_ex, rows)]),)
 
 
-def transcribe_sharded(engine, signals, group=None):
-    """Each rank transcribes its contiguous shard of ``signals`` with the fused engine; every rank
-    returns the full list of transcripts in the original order."""
+def transcribe_sharded(engine, signals, group=None, balance=True, batch_size=None):
+    """Each rank transcribes its shard of ``signals`` with the fused engine; every rank returns the full list of
+    transcripts in the original order.  balance=True (default): duration-balanced shards (``balanced_shards``: length
+    buckets of ``batch_size`` utterances, dealt heaviest-first to the least loaded rank; batch_size=None = the whole
+    shard as one padded batch per rank, utterances dealt one by one); balance=False: contiguous shards by count, in
+    input order, one batch per rank (round 1-2 behaviour)."""
     import numpy as np
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_range(len(signals), rank, world)
-    mine = signals[lo:hi]
-    if mine:
-        lens = np.array([len(s) for s in mine], dtype=np.int64)
-        batch = np.zeros((len(mine), int(lens.max())), dtype=np.float32)
-        for i, s in enumerate(mine):
-            batch[i, : len(s)] = s
+    if balance:
+        mine = balanced_shards([len(s) for s in signals], world, batch_size)[rank]
+        if batch_size is None:                       # one padded batch per rank
+            mine = [[i for b in mine for i in b]] if mine else []
+    else:
+        lo, hi = shard_range(len(signals), rank, world)
+        mine = [list(range(lo, hi))] if hi > lo else []
+    parts_ids, parts_n, parts_idx = [], [], []
+    for idx in mine:
+        lens = np.array([len(signals[i]) for i in idx], dtype=np.int64)
+        batch = np.zeros((len(idx), int(lens.max())), dtype=np.float32)
+        for k, i in enumerate(idx):
+            batch[k, : lens[k]] = signals[i]
         r = engine.forward(torch.from_numpy(batch).to(engine.device), torch.from_numpy(lens).to(engine.device))
-        ids, n = r["ids"], r["id_len"]
+        parts_ids.append(r["ids"]); parts_n.append(r["id_len"])
+        parts_idx.append(torch.tensor(idx, dtype=torch.int32, device=engine.device))
+    if parts_ids:
+        width = max(p.shape[1] for p in parts_ids)
+        ids = torch.cat([torch.nn.functional.pad(p, (0, width - p.shape[1])) for p in parts_ids])
+        n, idx_t = torch.cat(parts_n), torch.cat(parts_idx)
     else:
         ids = torch.zeros((0, 1), dtype=torch.int32, device=engine.device)
         n = torch.zeros((0,), dtype=torch.int32, device=engine.device)
-    ids, n = gather_id_sequences(ids, n, group)
-    return engine.texts(ids, n)
+        idx_t = torch.zeros((0,), dtype=torch.int32, device=engine.device)
+    ids, n, idx_t = gather_id_sequences(ids, n, group, extra=idx_t)
+    texts = engine.texts(ids, n)
+    out = [None] * len(signals)
+    for t, i in zip(texts, idx_t.tolist()):
+        out[i] = t
+    return out
