@@ -366,14 +366,21 @@ def main():
         if r.get("done") is not None:
             r["done"].synchronize()
         hyp = eng.texts(r["ids"], r["id_len"])
-        pw_ms = prof["pointwise"]["ms"] / a.steps
+        # The GEMM family = the 1x1-conv GEMM launches + the fused depthwise -> pointwise launches (encoder_fused.hip), whose
+        # whole duration -- depthwise producers included -- is charged to the GEMM: work that ran / time it took, per class
+        # (vasr_profile_end sums the algorithmic flops / bytes of the launches it bracketed)
+        fu_ms = prof["fused"]["ms"] / a.steps
+        pw_ms = prof["pointwise"]["ms"] / a.steps + fu_ms
         dw_ms = prof["depthwise"]["ms"] / a.steps
-        pw_tflops = work["pointwise_flops"] / (pw_ms * 1e-3) / 1e12       # fp32-equivalent (algorithmic) rate
+        gemm_flops = (prof["pointwise"]["flops"] + prof["fused"]["flops"]) / a.steps
+        assert abs(gemm_flops - work["pointwise_flops"]) <= 1e-6 * work["pointwise_flops"], (gemm_flops, work["pointwise_flops"])
+        pw_tflops = gemm_flops / (pw_ms * 1e-3) / 1e12       # fp32-equivalent (algorithmic) rate
         terms, optype, dtype_str = GEMM_MODES[gemm]
         # a split kernel executes `terms` 16-bit MFMA products per fp32 multiply-add: that is the work the matrix pipe sees
         exec_tflops = pw_tflops * terms
         peak = PEAK_F32_MFMA_TFLOPS if gemm == "fp32" else PEAK_16BIT_MFMA_TFLOPS
-        dw_gbs = work["depthwise_bytes"] / (dw_ms * 1e-3) / 1e9
+        dw_bytes = prof["depthwise"]["bytes"] / a.steps      # of the depthwise layers that ran as kernels of their own
+        dw_gbs = dw_bytes / (dw_ms * 1e-3) / 1e9
         headline = a.config == 3 and not (a.model or a.batch or a.seconds or a.ragged)
         kname = "pw_gemm_kernel" if gemm == "fp32" else "pw_gemm_split_kernel"
         arith_tag = {"f16x2": ", 2>", "bf16x3": ", 0>", "bf16x2": ", 1>"}.get(gemm, "")
@@ -402,10 +409,16 @@ def main():
                          "traffic_note": "HBM bytes per launch from the committed PMC pass named in traffic_source (not measured in "
                                          "this run; null off the headline workload)", "traffic_source": traffic_src,
                          "flops_per_step": work["pointwise_flops"], "ms_per_step": round(pw_ms, 3),
-                         "launches_per_step": prof["pointwise"]["launches"] // a.steps},
+                         "launches_per_step": (prof["pointwise"]["launches"] + prof["fused"]["launches"]) // a.steps},
+            "fused": {"kernel": "dwpw_fused_kernel<K, DUAL> (depthwise + 1x1 conv + BN + residual + ReLU of a 256-channel sub-block in one "
+                                "launch; included in roofline above)", "launches_per_step": prof["fused"]["launches"] // a.steps,
+                      "ms_per_step": round(fu_ms, 3), "flops_per_step": prof["fused"]["flops"] / a.steps,
+                      "hbm_bytes_per_step": prof["fused"]["bytes"] / a.steps,
+                      "achieved_GBps": round(prof["fused"]["bytes"] / a.steps / (fu_ms * 1e-3) / 1e9, 1) if fu_ms else None,
+                      "achieved_TFLOPs_executed": round(prof["fused"]["flops"] / a.steps * terms / (fu_ms * 1e-3) / 1e12, 1) if fu_ms else None},
             "depthwise": {"kernel": "depthwise conv kernels (dw_toeplitz_kernel<K,DIL> on the matrix pipe; dw_conv_generic for the stride-2 prologue; dw_pair_kernel under --gemm fp32 | bf16x3 or VASR_DW_MFMA=0)", "bound": "hbm", "achieved": round(dw_gbs, 1),
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dw_gbs / PEAK_HBM_GBS, 4), "traffic": None,
-                          "traffic_offline": dw_traffic, "bytes_per_step": work["depthwise_bytes"], "ms_per_step": round(dw_ms, 3),
+                          "traffic_offline": dw_traffic, "bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 3),
                           "launches_per_step": prof["depthwise"]["launches"] // a.steps},
             "other_ms_per_step": {"frontend": round(prof["frontend"]["ms"] / a.steps, 3),
                                   "head": round(prof["head"]["ms"] / a.steps, 3)},

@@ -242,9 +242,11 @@ int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, doub
  * vasr_encoder_f32 / vasr_decoder_* is bracketed by an event pair; end() synchronises on the events
  * and returns the summed milliseconds and launch counts per class:
  *   [0] front end (seq_len + STFT/mel + CMVN)  [1] depthwise convs  [2] pointwise GEMMs
- *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse) */
+ *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse)  [4] fused depthwise + pointwise sub-blocks
+ * flops / bytes (optional, may be NULL): the algorithmic work of the launches of each class that actually ran --
+ * 2 M N K of every GEMM (class 2 and 4), HBM bytes read + written by every depthwise (1) and fused (4) layer. */
 int vasr_profile_begin(vasr_handle* h);
-int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]);
+int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double flops[5], double bytes[5]);
 /* What one event bracket adds to a bracketed launch: median elapsed time (microseconds) of n brackets around an empty
  * kernel, recorded back to back on `stream` exactly like the profiled launches.  A bracket measures "previous kernel
  * done -> this kernel done", i.e. the kernel plus its dispatch gap; bench.py reports class times both raw and with

@@ -318,7 +318,9 @@ print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
                                  {"VASR_PW3_TILE": "4"}, {"VASR_SLICES": "2"},
                                  {"VASR_GEMM": "f16x2", "VASR_DW_PAIR": "0"}, {"VASR_GEMM": "f16x2", "VASR_NO_FUSED_RESIDUAL": "1"},
                                  {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "2"}, {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "3"},
-                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "4"}, {"VASR_DW_MFMA": "0"}, {"VASR_DW_UPW": "3"}],
+                                 {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "4"}, {"VASR_DW_MFMA": "0"}, {"VASR_DW_UPW": "3"},
+                                 {"VASR_FUSED_MIN_TILES": "1"}, {"VASR_FUSED": "0"},
+                                 {"VASR_FUSED_MIN_TILES": "1", "VASR_NO_FUSED_RESIDUAL": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):
     """The kernels a default run does not pick (one-row depthwise, packed-FMA depthwise under the fp16-split GEMMs,

@@ -81,7 +81,7 @@ SIGNATURES = {
     "vasr_version": (C.c_char_p, []),
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "vasr_profile_begin": (C.c_int, [_P]),
-    "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vasr_profile_bracket_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "vasr_padded_frames": (C.c_int64, [C.c_int64]),
     "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
@@ -214,10 +214,10 @@ class Handle:
         check(lib().vasr_profile_begin(self.h))
 
     def profile_end(self):
-        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
-        check(lib().vasr_profile_end(self.h, ms, n))
-        names = ("frontend", "depthwise", "pointwise", "head")
-        return {k: dict(ms=ms[i], launches=int(n[i])) for i, k in enumerate(names)}
+        ms, n, fl, by = (C.c_double * 5)(), (C.c_int64 * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+        check(lib().vasr_profile_end(self.h, ms, n, fl, by))
+        names = ("frontend", "depthwise", "pointwise", "head", "fused")
+        return {k: dict(ms=ms[i], launches=int(n[i]), flops=fl[i], bytes=by[i]) for i, k in enumerate(names)}
 
     @staticmethod
     def profile_bracket_overhead_us(stream, n=256):

@@ -479,14 +479,31 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
     // The 67 MB output of a 512-channel layer is otherwise store-issue bound (4.8 TB/s against ~7.5 TB/s for a fill).
     float* stage = reinterpret_cast<float*>(Bs) + wave * (2 * 8 * BN);
     constexpr int F4 = 8 * BN / 4 / 64;   // float4 pieces per lane and pass
+    // Every pass's BN scale / shift is requested BEFORE the first store.  Stores count in vmcnt like loads and the counter
+    // retires in order: a load issued between two passes made its consumer wait -- vmcnt(0) -- for every store of the
+    // passes before it, i.e. the 4 TM passes ran as 4 TM store round trips in series (round 2's "12 us store-bound
+    // epilogue" of a 512-channel layer).
+#ifndef VASR_PW_EPI_PRELOAD
+#define VASR_PW_EPI_PRELOAD 1
+#endif
+    v4f scv[TM][4], shv[TM][4];
+    if (VASR_PW_EPI_PRELOAD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          scv[i][q] = *reinterpret_cast<const v4f*>(a.scale + m0 + wm + i * 32 + 8 * q + 4 * kh);
+          shv[i][q] = *reinterpret_cast<const v4f*>(a.shift + m0 + wm + i * 32 + 8 * q + 4 * kh);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float* buf = stage + ((i * 4 + q) & 1) * (8 * BN);
         const int mq = m0 + wm + i * 32 + 8 * q;
-        const v4f sc = *reinterpret_cast<const v4f*>(a.scale + mq + 4 * kh);
-        const v4f sh = *reinterpret_cast<const v4f*>(a.shift + mq + 4 * kh);
+        const v4f sc = VASR_PW_EPI_PRELOAD ? scv[i][q] : *reinterpret_cast<const v4f*>(a.scale + mq + 4 * kh);
+        const v4f sh = VASR_PW_EPI_PRELOAD ? shv[i][q] : *reinterpret_cast<const v4f*>(a.shift + mq + 4 * kh);
         wave_fence();   // LDS executes one wavefront's accesses in order: pass p+2's writes follow pass p's reads
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)

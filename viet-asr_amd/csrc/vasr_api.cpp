@@ -54,6 +54,8 @@ struct ConvLayer {
   unsigned int* d_taps = nullptr;  // depthwise, Toeplitz / MFMA form: [C][tap_tsz] (hi | lo << 16) fp16 tap tables
   float* d_tap_inv = nullptr;      // [C] 1 / (power-of-two scale of the channel's taps)
   int tap_tsz = 0;
+  float* d_ftaps = nullptr;        // depthwise, fused dw -> pw kernel (encoder_fused.hip): [C / 2][taps per pair][2]
+  float f_l1 = 0.f;                // max_c sum_k |w[c][k]|: bound of the depthwise output per unit of input
   float* d_scale = nullptr;  // [m_pad]
   float* d_shift = nullptr;  // [m_pad]
   int step = -1;             // index in the MaskedConv1d length chain
@@ -123,7 +125,7 @@ struct vasr_handle {
   // 3 = 2 x fp16 scaled split operands on v_mfma_f32_32x32x16_f16 (half the matrix work of mode 1, see vasr.h)
   int gemm_mode = parse_gemm_mode(getenv("VASR_GEMM"));
   bool profiling = false;
-  struct ProfRec { hipEvent_t a, b; int cls; };
+  struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -336,6 +338,11 @@ int build_encoder(vasr_handle* h) {
             inv[ch] = pack_depthwise_taps_f16x2(&w->data[(size_t)ch * k], k, d.dilation, S.dw.tap_tsz, &tab[(size_t)ch * S.dw.tap_tsz]);
           if ((rc = upload(h, tab, &S.dw.d_taps)) || (rc = upload(h, inv, &S.dw.d_tap_inv))) return rc;
         }
+        if (fused_dwpw_supported(c, d.filters, k, d.stride, d.dilation)) {
+          std::vector<float> ft((size_t)(c / 2) * fused_dwpw_taps_per_pair(k) * 2);
+          S.dw.f_l1 = pack_fused_taps(w->data.data(), c, k, ft.data());
+          if ((rc = upload(h, ft, &S.dw.d_ftaps))) return rc;
+        }
         snprintf(key, sizeof key, "encoder.%zu.mconv.%d.conv.weight", i, j + 1);
         if ((rc = pack_pointwise(h, key, d.filters, c, &S.pw))) return rc;
         S.pw.step = step++;
@@ -461,7 +468,7 @@ WsPlan plan_ws(const vasr_handle* h, int batch, int64_t T) {
 
 // Brackets one launch (or a short launch group) with HIP events on the launch stream.
 struct ProfScope {
-  vasr_handle* h; hipStream_t st; hipEvent_t a{}, b{}; int cls;
+  vasr_handle* h; hipStream_t st; hipEvent_t a{}, b{}; int cls; double flops, bytes;
   static hipEvent_t get(vasr_handle* h) {
     hipEvent_t e;
     if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
@@ -470,15 +477,18 @@ struct ProfScope {
   }
   // Single-launch classes (depthwise, pointwise) hand the event pair to the launch itself (g_probe: the dispatch
   // packet's begin / end timestamps); multi-launch groups (front end, head) are bracketed on the stream.
-  ProfScope(vasr_handle* h_, int cls_, hipStream_t st_) : h(h_), st(st_), cls(cls_) {
+  // flops / bytes: the ALGORITHMIC work of the bracketed launch (2 M N K of a GEMM; read x + write y of a depthwise or
+  // fused layer), summed per class by vasr_profile_end so that a rate is always work-that-ran over time-it-took
+  ProfScope(vasr_handle* h_, int cls_, hipStream_t st_, double flops_ = 0.0, double bytes_ = 0.0)
+      : h(h_), st(st_), cls(cls_), flops(flops_), bytes(bytes_) {
     if (!h->profiling) return;
     a = get(h); b = get(h);
-    if (cls == 1 || cls == 2) g_probe = LaunchProbe{a, b};
+    if (cls == 1 || cls == 2 || cls == 4) g_probe = LaunchProbe{a, b};
     else (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (!h->profiling) return;
-    if (cls == 1 || cls == 2) {
+    if (cls == 1 || cls == 2 || cls == 4) {
       if (g_probe.start) {   // no instrumented launch happened inside the scope
         g_probe = LaunchProbe{};
         (void)hipEventRecord(a, st);
@@ -487,10 +497,10 @@ struct ProfScope {
     } else {
       (void)hipEventRecord(b, st);
     }
-    h->prof.push_back({a, b, cls});
+    h->prof.push_back({a, b, cls, flops, bytes});
   }
 };
-enum { kProfFrontend = 0, kProfDepthwise = 1, kProfPointwise = 2, kProfHead = 3 };
+enum { kProfFrontend = 0, kProfDepthwise = 1, kProfPointwise = 2, kProfHead = 3, kProfFused = 4 };
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -573,7 +583,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
       a.m_store = B.res.m_pad; a.relu = 0;
       a.amax_x = blk_amax;
-      ProfScope ps(h, kProfPointwise, st);
+      ProfScope ps(h, kProfPointwise, st, 2.0 * B.res.cin * B.res.cout * (double)cur_T * batch);
       if (run_pointwise(h, a, B.res, st) < 0) return VASR_ERR_HIP;
     }
     int flip = 0;
@@ -584,10 +594,60 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       int64_t gx_ld = cur_ld, g_T = cur_T;
       const int32_t* g_lens = nullptr;
       AmaxTab gx_amax = cur_amax;
+      // ---- fused depthwise -> pointwise kernel (encoder_fused.hip): 256-channel sub-blocks in the fp16-split arithmetic, when
+      //      there are enough 128-frame tiles to fill the chip (one workgroup per tile, all channels); VASR_FUSED=0 is the
+      //      A/B switch ----
+      static const bool fused_on = !(getenv("VASR_FUSED") && atoi(getenv("VASR_FUSED")) == 0);
+      // One workgroup per CU (159 KB of LDS), one 128-frame tile each: it pays when the tiles fill whole rounds of the chip
+      // (measured, fused vs two kernels: 64 x 10 s = 256 tiles -3.4 % per step, 512 x 30 s = 6144 tiles -4 %; but 32 x 10 s = 128
+      // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  VASR_FUSED_MIN_TILES=n forces
+      // the fused form from n tiles on, whatever the fill (tests).
+      static const int fused_min_tiles = getenv("VASR_FUSED_MIN_TILES") ? atoi(getenv("VASR_FUSED_MIN_TILES")) : 0;
+      static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+      }();
+      const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile), f_rounds = (f_tiles + n_cu - 1) / n_cu;
+      const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles
+                                              : (f_tiles >= 3 * n_cu / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * n_cu));
+      const bool fuse_res = last_sub && B.fused_res;
+      const ConvLayer& WF = fuse_res ? B.fused : S.pw;
+      // (not in row-independent mode: whether a sub-block is fused depends on the batch's tile count, and the two forms
+      // round differently -- that mode promises bit-identical rows whatever the batch)
+      if (fused_on && !h->row_independent && S.separable && S.dw.d_ftaps && h->gemm_mode == 3 && want_amax && cur_amax.p && WF.d_w16 &&
+          !(last_sub && B.has_res && !B.fused_res) && (!fuse_res || (blk_amax.p && blk_ld == cur_ld)) &&
+          cur_ld % kTimeTile == 0 && f_fill &&
+          !(last_block && last_sub)) {
+        float* dst = free3[flip];
+        flip ^= 1;
+        FusedLaunch f{};
+        f.x = cur; f.ldx = cur_ld; f.lens_in = lens(S.dw.step); f.lens_out = lens(S.dw.step + 1);
+        f.taps = S.dw.d_ftaps; f.dw_l1 = S.dw.f_l1; f.amax_x = cur_amax;
+        f.wt = WF.d_w16; f.w_inv_scale = WF.w16_inv; f.scale = WF.d_scale; f.shift = WF.d_shift;
+        f.y = dst; f.ldy = cur_ld; f.frames = (int)cur_T; f.relu = 1;
+        f.amax_y = free_tab(cur_amax); f.lens_y = lens(S.pw.step + 1);
+        if (fuse_res) { f.x2 = blk_in; f.ldx2 = blk_ld; f.lens2 = lens(B.first_step); f.amax_x2 = blk_amax; }
+        f.batch = batch; f.kernel = S.dw.kernel;
+        int e;
+        {
+          ProfScope ps(h, kProfFused, st, 2.0 * WF.cin * WF.cout * (double)cur_T * batch,
+                       4.0 * (2.0 + (fuse_res ? 1.0 : 0.0)) * S.dw.cin * (double)cur_T * batch);
+          e = launch_fused_dwpw(f, st, &f.amax_y.n);
+        }
+        if (e > 0) return fail(VASR_ERR_HIP, "fused dw -> pw: %s", hipGetErrorString((hipError_t)e));
+        if (e == 0) {
+          cur = dst;
+          cur_amax = f.amax_y;
+          continue;
+        }
+        flip ^= 1;   // shape not covered after all: the two-kernel path below
+      }
       if (S.separable) {
         const int64_t t_out = conv_out_frames(cur_T, S.dw);
         const int64_t ld_out = pad_frames(t_out);
-        ProfScope ps(h, kProfDepthwise, st);
+        ProfScope ps(h, kProfDepthwise, st, 2.0 * S.dw.kernel * S.dw.cin * (double)t_out * batch,
+                     4.0 * ((double)S.dw.cin * cur_T + (double)S.dw.cin * t_out) * batch + 4.0 * S.dw.cin * S.dw.kernel);
         AmaxTab am = want_amax ? free_tab(AmaxTab{}) : AmaxTab{};
         // fp16-split mode with the input's maxima at hand: the Toeplitz form on the matrix pipe (in the pipeline, per
         // 512-channel layer: 22.8 / 23.7 / 23.8 / 28.1 us at K = 51 / 63 / 75 / 87 x 2 against 25.6 / 28.4 / 31.0 / 35.5 us
@@ -634,7 +694,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       }
       int published;
       {
-        ProfScope ps(h, kProfPointwise, st);
+        ProfScope ps(h, kProfPointwise, st, 2.0 * W.cin * W.cout * (double)g_T * batch);
         published = run_pointwise(h, a, W, st);
       }
       if (published < 0) return VASR_ERR_HIP;
@@ -1076,16 +1136,18 @@ int vasr_profile_begin(vasr_handle* h) {
   return 0;
 }
 
-int vasr_profile_end(vasr_handle* h, double ms[4], int64_t launches[4]) {
+int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double flops[5], double bytes[5]) {
   if (!h || !ms || !launches) return fail(VASR_ERR_INVALID, "bad argument");
   h->profiling = false;
-  for (int i = 0; i < 4; ++i) { ms[i] = 0.0; launches[i] = 0; }
+  for (int i = 0; i < 5; ++i) { ms[i] = 0.0; launches[i] = 0; if (flops) flops[i] = 0.0; if (bytes) bytes[i] = 0.0; }
   for (auto& r : h->prof) {
     HIP_TRY(hipEventSynchronize(r.b));
     float t = 0.f;
     HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
     ms[r.cls] += t;
     launches[r.cls] += 1;
+    if (flops) flops[r.cls] += r.flops;
+    if (bytes) bytes[r.cls] += r.bytes;
     h->ev_pool.push_back(r.a);
     h->ev_pool.push_back(r.b);
   }

@@ -153,6 +153,25 @@ float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad,
 void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, AmaxTab* amax,
                  hipStream_t st);
 
+// ---- fused depthwise + pointwise sub-block, 256 channels (encoder_fused.hip) ----
+struct FusedLaunch {
+  const float* x; int64_t ldx;                 // [B][256][ldx] depthwise input
+  const int32_t* lens_in; const int32_t* lens_out;
+  const float* taps; float dw_l1;              // pack_fused_taps
+  AmaxTab amax_x;
+  const void* wt; float w_inv_scale;           // f16x2 pack of the 1x1 conv (K = 256, or 512 with the residual folded in)
+  const float* scale; const float* shift;
+  float* y; int64_t ldy; int32_t frames, relu;
+  AmaxTab amax_y; const int32_t* lens_y;
+  const float* x2; int64_t ldx2; const int32_t* lens2; AmaxTab amax_x2;   // residual source (nullptr = none)
+  int32_t batch, kernel;
+};
+bool fused_dwpw_supported(int channels, int cout, int kernel, int stride, int dilation);
+int fused_dwpw_taps_per_pair(int kernel);
+// host: [C][K] -> [C / 2][taps_per_pair][2]; returns the bound max_c sum_k |w[c][k]| (rounded up)
+float pack_fused_taps(const float* w, int channels, int kernel, float* out);
+int launch_fused_dwpw(const FusedLaunch& f, hipStream_t st, int* amax_n);   // 0, a hipError_t, or -1 (shape not covered)
+
 // ---- CTC head / decode (decode.hip) ----
 // logits [B][ldm rows][ld] (row v, column t) -> logp [B][T][V] (optional), pred [B][T] (optional)
 void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
