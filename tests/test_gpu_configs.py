@@ -255,7 +255,7 @@ def test_bench_self_launch_matches_plain_run_and_refuses_missing_devices(gpu):
     gather in the loop): its value must equal the plain single-process run within 2 % (best of two each -- the two forms
     run the same kernels; the gather is asynchronous).  With more GPUs requested than the box has: a clear message and
     exit code 3, nothing run."""
-    common = ["--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-other-gemm"]
+    common = ["--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-other-gemm", "--no-side-configs"]
     plain, spawned = [], []
     for _ in range(2):
         rc, j, log = _bench(common)
@@ -270,6 +270,42 @@ def test_bench_self_launch_matches_plain_run_and_refuses_missing_devices(gpu):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1)], capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 3 and f"needs {have + 1} visible HIP devices" in out.stderr, (out.returncode, out.stderr[-500:])
+
+
+def test_bench_default_line_carries_every_baseline_config_and_the_latency_block(gpu):
+    """the driver only ever sees the default line, so it must carry configs 2, 4 and 5 (5 steps each) and the
+    batch-1 / batch-8 latency of the whole path next to the headline, with their roofline fractions."""
+    rc, j, log = _bench(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-other-gemm"])
+    assert rc == 0 and j is not None, log
+    assert "configs[2]" in j["config"]["workload"] and j["value"] > 2000
+    for cid, tag in (("2", "quartznet12x1_vi"), ("4", "beam"), ("5", "512x30s")):
+        c = j["configs"][cid]
+        assert "error" not in c, c
+        assert tag in c["workload"] and c["steps"] == 5 and c["value"] > 2000 and c["ms_per_step"] > 0
+        assert 0 < c["roofline"]["frac"] < 1 and 0 < c["depthwise"]["frac"] < 1 and 0 < c["depthwise"]["frac_of_achievable"] < 1.3
+    assert j["configs"]["4"]["lm"]["ngrams"] > 100000
+    lat = j["latency"]
+    assert 0 < lat["b1_2s_ms"] <= lat["b1_10s_ms"] <= lat["b8_10s_ms"] < 20
+    assert j["depthwise"]["frac_of_achievable"] > j["depthwise"]["frac"]
+    assert j["fused"]["launches_per_step"] == 30        # the 256-channel sub-blocks of 15x5 run as one kernel each
+
+
+def test_bench_job_mode_of_config5_in_a_world_of_one(gpu):
+    """`--gpus N --config 5` walks the whole 4096-clip job (strong scaling, per-rank min / max); the code path is run here
+    with the job shrunk to 256 clips on the one GPU there is (RCCL world of one via --spawn), equal-length and ragged."""
+    import json
+    env = dict(os.environ, VASR_BENCH_FORCE_JOB="1", VASR_BENCH_JOB_CLIPS="256")
+    for extra in ([], ["--ragged"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--spawn", "--batch", "128", "--steps",
+                              "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-gemm"] + extra, env=env, capture_output=True,
+                             text=True, timeout=900)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and lines, out.stdout[-1500:] + out.stderr[-1500:]
+        j = json.loads(lines[-1])
+        assert j["scaling"] == "strong" and j["config"]["clips_per_step_all_ranks"] == 256 and j["rccl_ranks"] == 1
+        assert "256-clip job" in j["config"]["workload"] and j["value"] > 2000
+        assert j["rank_ms_per_step"]["min"] == j["rank_ms_per_step"]["max"] > 0
+        assert ("padded_work_imbalance" in j["sharding"]) == bool(extra)
 
 
 @pytest.mark.parametrize("config", [2, 4, 5])
