@@ -15,8 +15,8 @@ from viet_asr_amd.core import (DeviceType, NeuralModuleFactory, NeuralPortNameMi
                                NeuralPortNmTensorMismatchError, NmTensor)
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "vasr.h")).read()
+def _header_functions(name="vasr.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vasr_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vasr.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     assert b"gfx950" in _lib.lib().vasr_version()
+    # the measurement / development entry points live in a second header and a second library: the product library
+    # exports none of them (and reads no kernel-selection switch from the environment), the devtools build all of both
+    dev_names = _header_functions("vasr_devtools.h")
+    assert set(dev_names) == set(_lib.DEV_SIGNATURES) and len(dev_names) >= 10, set(dev_names) ^ set(_lib.DEV_SIGNATURES)
+    assert not [n for n in dev_names if hasattr(lib, n)], "devtools symbols in the product library"
+    dev = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so"))
+    for n in names + dev_names:
+        assert hasattr(dev, n), f"{n} missing from libvasr_hip_dev.so"
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for switch in (b"VASR_DW_PAIR", b"VASR_PW3_TILE", b"VASR_FUSED", b"VASR_NO_FUSED_RESIDUAL", b"VASR_DEBUG_NO_EPILOGUE"):
+        assert switch not in blob, switch
+    assert b"VASR_GEMM" in blob and b"VASR_PW3_TILE" in open(os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so"), "rb").read()
 
 
 def test_create_validates_arguments_without_a_gpu():
@@ -49,17 +61,17 @@ def test_create_validates_arguments_without_a_gpu():
 
 
 def test_pointwise_weight_packing_layout():
-    L = _lib.lib()
+    L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     cout, cin, m_pad = 29, 64, 128
     w = np.arange(cout * cin, dtype=np.float32).reshape(cout, cin)
     out = np.empty(m_pad * cin, dtype=np.float32)
-    _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, cin, m_pad, out.ctypes.data))
+    _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, cin, m_pad, out.ctypes.data), L)
     p = out.reshape(m_pad // 32, cin // 8, 64, 4)
     for mt, g, lane, s in [(0, 0, 0, 0), (0, 3, 37, 2), (0, 7, 63, 3), (3, 1, 5, 1)]:
         m, k = mt * 32 + (lane & 31), g * 8 + 2 * s + (lane >> 5)
         assert p[mt, g, lane, s] == (w[m, k] if m < cout else 0.0)
     with pytest.raises(ValueError):
-        _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, 63, m_pad, out.ctypes.data))
+        _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, 63, m_pad, out.ctypes.data), L)
 
 
 @pytest.mark.parametrize("K,dil", [(33, 1), (39, 1), (51, 1), (63, 1), (75, 1), (87, 2)])
@@ -68,7 +80,7 @@ def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
     kernel builds its A fragments -- A[m][k] = table[15 - m + k], 16 output offsets x 32 NS window samples -- times
     windows of 16 consecutive outputs cut from the zero-padded row, B[k][n] = row[16 n - PADL + k], IS the "same"-padded
     depthwise convolution of jasper.py:60-65 / :119-132; hi + lo carries the scaled tap to 2^-22."""
-    L = _lib.lib()
+    L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     tsz = int(L.vasr_depthwise_mfma_table_size(K, dil))
     pad = (dil * K) // 2 - 1 if dil > 1 else K // 2
     padl = (pad + 3) & ~3
@@ -79,7 +91,7 @@ def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
     w = (rng.standard_normal((C_, K)) / np.sqrt(K)).astype(np.float32)
     w[1] *= 1e-4
     tab, inv = np.empty((C_, tsz), dtype=np.uint32), np.empty(C_, dtype=np.float32)
-    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, K, dil, tab.ctypes.data, inv.ctypes.data))
+    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, K, dil, tab.ctypes.data, inv.ctypes.data), L)
     hi = (tab & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64)
     lo = (tab >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
     T = 64                                                        # four windows of 16 outputs
@@ -98,7 +110,7 @@ def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
         assert np.abs(got - ref).max() <= 2.0 ** -20 * np.abs(w[c]).max() * np.abs(x[c]).sum()
     assert int(L.vasr_depthwise_mfma_table_size(35, 1)) == 0      # shapes without an instantiation
     with pytest.raises(ValueError):
-        _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, 35, 1, tab.ctypes.data, inv.ctypes.data))
+        _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, C_, 35, 1, tab.ctypes.data, inv.ctypes.data), L)
 
 
 def test_toeplitz_kernel_lane_algebra():
@@ -107,14 +119,14 @@ def test_toeplitz_kernel_lane_algebra():
     256 q + 16 n + 32 s + 8 kg + e; A fragment of lane (m = lane & 15, kg) = table[15 - m + 32 s + 8 kg + e];
     v_mfma_f32_16x16x32 D: lane n + 16 g holds rows 4 g + r of column n; after the rotation lane L (pulling from lane
     (L >> 2) + 16 (L & 3)) holds frames t0 + 256 q + 4 L + r -- which must be the convolution's."""
-    L = _lib.lib()
+    L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     K, pad = 75, 37
     padl, ns = (pad + 3) & ~3, 3
     tsz = int(L.vasr_depthwise_mfma_table_size(K, 1))
     rng = np.random.default_rng(5)
     w = (rng.standard_normal((1, K)) / np.sqrt(K)).astype(np.float32)
     tab, inv = np.empty((1, tsz), dtype=np.uint32), np.empty(1, dtype=np.float32)
-    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, 1, K, 1, tab.ctypes.data, inv.ctypes.data))
+    _lib.check(L.vasr_pack_depthwise_taps(w.ctypes.data, 1, K, 1, tab.ctypes.data, inv.ctypes.data), L)
     taps = ((tab[0] & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64) +
             (tab[0] >> 16).astype(np.uint16).view(np.float16).astype(np.float64)) * float(inv[0])
     T, t0 = 1200, 512                                              # second 512-frame tile of a 1200-frame row

@@ -232,7 +232,7 @@ def test_split_gemms_are_as_accurate_as_fp32_mfma(gpu, cin, kind):
     precision, where its error must stay below fp32 round-off of the LARGEST terms (absolute, not relative)."""
     from viet_asr_amd import _lib
     import ctypes as C
-    L = _lib.lib()
+    L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     B, T, cout = 2, 300, 512
     ld = int(L.vasr_padded_frames(T))
     g = torch.Generator().manual_seed(cin + len(kind))
@@ -247,19 +247,19 @@ def test_split_gemms_are_as_accurate_as_fp32_mfma(gpu, cin, kind):
     sc, sh = torch.ones(cout, device=gpu), torch.zeros(cout, device=gpu)
     st = torch.cuda.current_stream().cuda_stream
     pk = torch.empty(cout * cin)
-    _lib.check(L.vasr_pack_pointwise(w.data_ptr(), cout, cin, cout, pk.data_ptr()))
+    _lib.check(L.vasr_pack_pointwise(w.data_ptr(), cout, cin, cout, pk.data_ptr()), L)
     pk3 = torch.empty(cout * cin * 3, dtype=torch.int16)
-    _lib.check(L.vasr_pack_pointwise_bf16x3(w.data_ptr(), cout, cin, cout, pk3.data_ptr()))
+    _lib.check(L.vasr_pack_pointwise_bf16x3(w.data_ptr(), cout, cin, cout, pk3.data_ptr()), L)
     pk16 = torch.empty(cout * cin * 2, dtype=torch.int16)
     inv = C.c_float()
-    _lib.check(L.vasr_pack_pointwise_f16x2(w.data_ptr(), cout, cin, cout, pk16.data_ptr(), C.byref(inv)))
+    _lib.check(L.vasr_pack_pointwise_f16x2(w.data_ptr(), cout, cin, cout, pk16.data_ptr(), C.byref(inv)), L)
     y32, y3, y16 = (torch.empty(B, cout, ld, device=gpu) for _ in range(3))
     amax = torch.full((2, B, 256), -1, dtype=torch.int32, device=gpu)       # per-wavefront maxima tables (x, y)
     w32, w3, w16 = pk.to(gpu), pk3.to(gpu), pk16.to(gpu)
-    _lib.check(L.vasr_bench_pointwise(x.data_ptr(), w32.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y32.data_ptr(), st))
-    _lib.check(L.vasr_bench_pointwise_bf16x3(x.data_ptr(), w3.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y3.data_ptr(), st))
+    _lib.check(L.vasr_bench_pointwise(x.data_ptr(), w32.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y32.data_ptr(), st), L)
+    _lib.check(L.vasr_bench_pointwise_bf16x3(x.data_ptr(), w3.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, cin, cout, T, y3.data_ptr(), st), L)
     _lib.check(L.vasr_bench_pointwise_f16x2(x.data_ptr(), w16.data_ptr(), inv.value, sc.data_ptr(), sh.data_ptr(), B, cin, cout, T,
-                                            y16.data_ptr(), amax.data_ptr(), 256, st))
+                                            y16.data_ptr(), amax.data_ptr(), 256, st), L)
     ref = torch.relu(torch.einsum("mk,bkt->bmt", w.double().to(gpu), x[:, :, :T].double()))
     err = lambda y: [float((y[b, :, :T].double() - ref[b]).abs().max()) for b in range(B)]
     e32, e3, e16 = err(y32), err(y3), err(y16)
@@ -324,14 +324,19 @@ print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):
     """The kernels a default run does not pick (one-row depthwise, packed-FMA depthwise under the fp16-split GEMMs,
-    two-GEMM residual, latency GEMM tiles, batch slices on side streams) are selected by environment variables read
-    once per process: run each in a child process."""
+    two-GEMM residual, latency GEMM tiles, batch slices on side streams, the fused depthwise + pointwise kernel forced
+    onto small batches or switched off) are selected by environment variables that only the DEVTOOLS build of the
+    library reads (libvasr_hip_dev.so; the product library ignores them), once per process: each runs in a child
+    process on that build."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     code = _ALT_PATH_SNIPPET.format(tests=here, root=os.path.dirname(here))
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    from viet_asr_amd import _lib
+    dev = os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so")
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VASR_LIB_PATH": dev, **env}, capture_output=True,
+                         text=True, timeout=600)
     assert "ALT_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
@@ -540,7 +545,7 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
     (2e-6 of the largest output), which is run beside it where it exists (dilation 1); published maxima exact."""
     import ctypes as C_
     from viet_asr_amd import _lib
-    L = _lib.lib()
+    L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     ld = int(L.vasr_padded_frames(T))
     g = torch.Generator().manual_seed(K * 1000 + T)
     x = torch.randn(B, C, ld, generator=g)
@@ -556,14 +561,14 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
     tsz = int(L.vasr_depthwise_mfma_table_size(K, dil))
     assert tsz > 0
     tab, inv = torch.empty(C, tsz, dtype=torch.int32), torch.empty(C)
-    _lib.check(L.vasr_pack_depthwise_taps(w.data_ptr(), C, K, dil, tab.data_ptr(), inv.data_ptr()))
+    _lib.check(L.vasr_pack_depthwise_taps(w.data_ptr(), C, K, dil, tab.data_ptr(), inv.data_ptr()), L)
     y = torch.full((B, C, ld), float("nan"), device=gpu)
     stride = max(256, C * ((ld + 255) // 256) * 4)
     amax = torch.full((2, B, stride), -1, dtype=torch.int32, device=gpu)    # per-wavefront maxima tables (x, y)
     st = torch.cuda.current_stream().cuda_stream
     lens_d, tab_d, inv_d = lens.to(gpu), tab.to(gpu), inv.to(gpu)
     _lib.check(L.vasr_bench_depthwise_mfma(x.data_ptr(), tab_d.data_ptr(), inv_d.data_ptr(), lens_d.data_ptr(), B, C, T, K, dil,
-                                           y.data_ptr(), amax.data_ptr(), stride, st))
+                                           y.data_ptr(), amax.data_ptr(), stride, st), L)
     torch.cuda.synchronize()
     pad = (dil * K) // 2 - 1 if dil > 1 else K // 2
     t = torch.arange(ld, device=gpu)
@@ -585,7 +590,7 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
     if dil == 1:                                              # the packed-FMA kernel on the same layer, for the record
         y2 = torch.empty(B, C, ld, device=gpu)
         x0, w_d = torch.nan_to_num(x, nan=0.0), w.to(gpu)           # named: a temporary's storage may be reused before the launch
-        _lib.check(L.vasr_bench_depthwise(x0.data_ptr(), w_d.data_ptr(), lens_d.data_ptr(), B, C, T, K, y2.data_ptr(), st))
+        _lib.check(L.vasr_bench_depthwise(x0.data_ptr(), w_d.data_ptr(), lens_d.data_ptr(), B, C, T, K, y2.data_ptr(), st), L)
         torch.cuda.synchronize()
         assert float((y2[:, :, :t_out].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 

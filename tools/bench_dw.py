@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viet_asr_amd  # noqa
 from viet_asr_amd import _lib
-L = _lib.lib()
+L = _lib.dev_lib()
 dev = torch.device("cuda:0")
 B, T = int(os.environ.get("B", 64)), int(os.environ.get("T", 501))
 ld = int(L.vasr_padded_frames(T))

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viet_asr_amd  # noqa
 from viet_asr_amd import _lib
-L = _lib.lib()
+L = _lib.dev_lib()
 sink = torch.zeros(16, device="cuda")
 fl = ctypes.c_double()
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viet_asr_amd  # noqa
 from viet_asr_amd import _lib
-L = _lib.lib(); dev = torch.device("cuda:0"); T = 501
+L = _lib.dev_lib(); dev = torch.device("cuda:0"); T = 501
 ld = int(L.vasr_padded_frames(T)); st = lambda: torch.cuda.current_stream().cuda_stream
 def timeit(fn, iters=30):
     for _ in range(3): fn()

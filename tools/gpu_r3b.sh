@@ -4,6 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03b; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so   # the build that reads the VASR_* switches
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q --timeout 600 -p no:cacheprovider -x \
   -k "FUSED or config3 or config2" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm"

@@ -3,6 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r03c}; mkdir -p $O
 cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so   # the build that reads the VASR_* switches
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm"
 for v in "" "VASR_FUSED=0"; do
   n=${v:-default}; env $v $B > $O/bench_$n.json 2> $O/bench_$n.err

@@ -3,6 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r03e}; mkdir -p $O
 cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so   # the build that reads the VASR_* switches
 for cfg in "--config 5 --steps 3 --warmup 1" "--config 2 --steps 20 --warmup 5" "--seconds 10.3 --steps 20 --warmup 5" "--batch 16 --steps 20 --warmup 5" "--ragged --steps 20 --warmup 5"; do
 for v in "" "VASR_FUSED=0" "VASR_FUSED_MIN_TILES=1"; do
   n=$(echo "${v:-default}_$cfg" | tr ' =-' '___'); env $v python bench.py $cfg --no-cpu-baseline --no-other-gemm > $O/b_$n.json 2> $O/b_$n.err

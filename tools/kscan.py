@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import viet_asr_amd
 from viet_asr_amd import _lib
-L = _lib.lib(); dev = torch.device("cuda:0"); B, T = 64, 501; ld = 512
+L = _lib.dev_lib(); dev = torch.device("cuda:0"); B, T = 64, 501; ld = 512
 st = lambda: torch.cuda.current_stream().cuda_stream
 mode = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 def timeit(fn, iters=20):

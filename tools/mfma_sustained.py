@@ -2,7 +2,7 @@ import sys, ctypes, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import viet_asr_amd
 from viet_asr_amd import _lib
-L = _lib.lib(); sink = torch.zeros(16, device="cuda"); fl = ctypes.c_double()
+L = _lib.dev_lib(); sink = torch.zeros(16, device="cuda"); fl = ctypes.c_double()
 st = torch.cuda.current_stream().cuda_stream
 run = lambda: _lib.check(L.vasr_bench_mfma_bf16_sustained(256, 4000, sink.data_ptr(), ctypes.byref(fl), st))
 run(); torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""ctypes binding of libvasr_hip.so (include/vasr.h).
+"""ctypes binding of libvasr_hip.so (include/vasr.h) and, for tests / tools, of libvasr_hip_dev.so (vasr_devtools.h).
 
 The library is the product: there is NO CPU fallback.  If the shared object is missing, or a
 compute entry point is called without a HIP device, this module raises -- it never routes
@@ -14,6 +14,8 @@ import torch  # noqa: F401  -- must be imported BEFORE the .so: torch ships its 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VASR_LIB_PATH") or os.path.join(_HERE, "lib", "libvasr_hip.so")   # override: dev builds
+# the -DVASR_DEVTOOLS build: + include/vasr_devtools.h, and the only build that reads the VASR_* kernel-selection switches
+DEV_LIB_PATH = os.environ.get("VASR_LIB_PATH") or os.path.join(_HERE, "lib", "libvasr_hip_dev.so")
 
 
 class VasrError(RuntimeError):
@@ -58,12 +60,6 @@ SIGNATURES = {
     "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
     "vasr_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "vasr_get_gemm_mode": (C.c_int, [_P]),
-    "vasr_pack_pointwise_f16x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
-    "vasr_bench_pointwise_f16x2": (C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P,
-                                             C.c_int, _P]),
-    "vasr_depthwise_mfma_table_size": (C.c_int, [C.c_int, C.c_int]),
-    "vasr_pack_depthwise_taps": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
-    "vasr_bench_depthwise_mfma": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vasr_set_slices": (C.c_int, [_P, C.c_int]),
     "vasr_set_row_independent": (C.c_int, [_P, C.c_int]),
     "vasr_set_busy_cus": (C.c_int, [_P, C.c_int]),
@@ -82,8 +78,18 @@ SIGNATURES = {
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "vasr_profile_begin": (C.c_int, [_P]),
     "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "vasr_profile_bracket_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "vasr_padded_frames": (C.c_int64, [C.c_int64]),
+}
+
+# include/vasr_devtools.h: exported by libvasr_hip_dev.so only (isolated layers, weight packers, bracket overhead)
+DEV_SIGNATURES = {
+    "vasr_pack_pointwise_f16x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
+    "vasr_bench_pointwise_f16x2": (C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P,
+                                             C.c_int, _P]),
+    "vasr_depthwise_mfma_table_size": (C.c_int, [C.c_int, C.c_int]),
+    "vasr_pack_depthwise_taps": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "vasr_bench_depthwise_mfma": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "vasr_profile_bracket_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_pack_pointwise_bf16x3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_bench_pointwise_bf16x3": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
@@ -93,30 +99,50 @@ SIGNATURES = {
 }
 
 _lib = None
+_dev = None
+
+
+def _load(path, tables):
+    if not os.path.exists(path):
+        raise VasrError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C viet-asr_amd/csrc`). There is no CPU fallback for this path.")
+    l = C.CDLL(path)
+    for table, required in tables:
+        for name, (res, args) in table.items():
+            fn = getattr(l, name, None)
+            if fn is None:
+                if required:
+                    raise VasrError(f"{path} does not export {name}")
+                continue
+            fn.restype, fn.argtypes = res, args
+    return l
 
 
 def lib():
-    """Load the shared object once; raise loudly when it has not been built."""
+    """The product library, loaded once; raises loudly when it has not been built.  (A VASR_LIB_PATH override may name a
+    devtools build: its extra symbols get their signatures too.)"""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise VasrError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(or `make -C viet-asr_amd/csrc`). There is no CPU fallback for this path.")
-        l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = l
+        _lib = _load(LIB_PATH, ((SIGNATURES, True), (DEV_SIGNATURES, False)))
     return _lib
+
+
+def dev_lib():
+    """libvasr_hip_dev.so (tests and tools only): everything the product library has + include/vasr_devtools.h."""
+    global _dev
+    if _dev is None:
+        _dev = lib() if DEV_LIB_PATH == LIB_PATH else _load(DEV_LIB_PATH, ((SIGNATURES, True), (DEV_SIGNATURES, True)))
+    return _dev
 
 
 _ERR_TYPES = {-1: ValueError, -5: NotImplementedError}
 
 
-def check(rc):
+def check(rc, l=None):
+    """l: the library the failing call went to (its error string lives there); default the product library."""
     if rc != 0:
-        msg = lib().vasr_last_error().decode("utf-8", "replace")
+        msg = (l or lib()).vasr_last_error().decode("utf-8", "replace")
         raise _ERR_TYPES.get(rc, VasrError)(f"libvasr_hip: {msg} (status {rc})")
 
 
@@ -222,7 +248,7 @@ class Handle:
     @staticmethod
     def profile_bracket_overhead_us(stream, n=256):
         out = C.c_double()
-        check(lib().vasr_profile_bracket_overhead(stream, n, C.byref(out)))
+        check(dev_lib().vasr_profile_bracket_overhead(stream, n, C.byref(out)), dev_lib())
         return out.value
 
     def close(self):

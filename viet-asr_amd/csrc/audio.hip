@@ -177,7 +177,7 @@ void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int b
       p = (int)((int64_t)rn / g);
     }
   }
-  static const bool generic_only = getenv("VASR_RESAMPLE_GENERIC") && atoi(getenv("VASR_RESAMPLE_GENERIC")) != 0;
+  static const bool generic_only = dev_env("VASR_RESAMPLE_GENERIC") && atoi(dev_env("VASR_RESAMPLE_GENERIC")) != 0;
   if (p > 0 && !generic_only) {
     const double scale = ratio < 1.0 ? ratio : 1.0;
     const int index_step = (int)(scale * num_table);

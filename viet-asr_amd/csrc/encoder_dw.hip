@@ -438,8 +438,8 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
 template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
                     int channels, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
-  static const int lds_pad = getenv("VASR_DW_LDSPAD") ? atoi(getenv("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  static const bool tail = !(getenv("VASR_DW_TAIL") && atoi(getenv("VASR_DW_TAIL")) == 0);   // A/B switch
+  static const int lds_pad = dev_env("VASR_DW_LDSPAD") ? atoi(dev_env("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
+  static const bool tail = !(dev_env("VASR_DW_TAIL") && atoi(dev_env("VASR_DW_TAIL")) == 0);   // A/B switch
   const int n_pairs = (batch + 1) / 2;
   // full 512-frame tiles, then a tail of 128 or 256 columns (the pitch is a multiple of 128; 384 runs as a full tile)
   int nt_main = (int)(ldy / kTile);
@@ -565,7 +565,7 @@ void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li,
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
   unsigned* ap = amax ? amax->p : nullptr;
   const int as = amax ? amax->stride : 0;
-  static const int rows_env = getenv("VASR_DW_ROWS") ? atoi(getenv("VASR_DW_ROWS")) : 1;
+  static const int rows_env = dev_env("VASR_DW_ROWS") ? atoi(dev_env("VASR_DW_ROWS")) : 1;
   if (channels % 32 == 0 && rows_env == 8) {
     dim3 grid(channels / 32, batch, tiles);
     if (amax) amax->n = grid.x * 4 * tiles;
@@ -609,7 +609,7 @@ static int launch_depthwise_impl(const float* x, int64_t ldx, int frames_in, con
                                  int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-  static const bool pair = !(getenv("VASR_DW_PAIR") && atoi(getenv("VASR_DW_PAIR")) == 0);
+  static const bool pair = !(dev_env("VASR_DW_PAIR") && atoi(dev_env("VASR_DW_PAIR")) == 0);
   if (pair && aligned && stride == 1) {
     if (dilation == 2 && kernel == 87 && pad == 86)
       { launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }

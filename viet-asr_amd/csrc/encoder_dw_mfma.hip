@@ -105,8 +105,10 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
                                                           const unsigned* __restrict__ amax_x, int amax_x_stride,
                                                           int amax_x_n, int channels, int batch,
                                                           float* __restrict__ y, int64_t ldy,
-                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int upw) {
+                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int upw_nt) {
   using G = TzGeom<K, DIL>;
+  const int upw = upw_nt & 0xff;           // utterances one wavefront walks
+  const bool nt = (upw_nt & 0x100) != 0;   // non-temporal output stores
   constexpr int NS = G::NS, NLD = G::NLD, kStages = G::STAGES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -313,9 +315,11 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
         o.w = nv > 3 ? o.w : 0.f;
       }
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-      if (!(VASR_TZ_ABLATE & 2))
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 0);
-      else
+      if (!(VASR_TZ_ABLATE & 2)) {
+        // (wave-uniform) non-temporal when the layer's output cannot stay in the Infinity Cache: vasr_internal.h stream_stores
+        if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 0);
+      } else
         asm volatile("" :: "v"(o));
     };
     finish(o0, 0);
@@ -397,7 +401,7 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
   constexpr int lds = 4 * G::LDS_WAVE;
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
   // utterances one wavefront walks with its channel's A fragments: as many as leave >= 4096 wavefronts (4 per SIMD)
-  static const int upw_env = getenv("VASR_DW_UPW") ? atoi(getenv("VASR_DW_UPW")) : 0;
+  static const int upw_env = dev_env("VASR_DW_UPW") ? atoi(dev_env("VASR_DW_UPW")) : 0;
   int upw = kUttPerWave;
   if (upw_env >= 1 && upw_env <= kUttPerWave) upw = upw_env;
   else
@@ -408,7 +412,8 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
     if (amax_y->n > amax_y->stride) return -1;
   }
   VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x.p, amax_x.stride, amax_x.n, channels, batch,
-              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0, upw);
+              y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0,
+              upw | (stream_stores((size_t)batch * channels * ldy * 4) ? 0x100 : 0));
   return 0;
 }
 

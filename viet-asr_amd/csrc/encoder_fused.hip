@@ -123,6 +123,7 @@ struct FusedArgs {
   const int32_t* lens2;
   AmaxTab amax_x2;
   int32_t batch;
+  int32_t nt_store;
 };
 
 // LDS-only workgroup barrier: __syncthreads() would also drain the vector-memory counter, i.e. make the producers wait
@@ -314,7 +315,11 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           v4f v = *reinterpret_cast<const v4f*>(buf + row * FBN + 4 * c4);
           const int m = mq + row, t = t0 + 4 * c4;
           if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
-          if (!(VASR_FUSED_ABLATE & 4)) *reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t) = v;
+          if (!(VASR_FUSED_ABLATE & 4)) {
+            v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t);
+            if (a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) vasr_internal.h stream_stores
+            else *dstp = v;
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned u = abs_bits(v[e]);
@@ -554,6 +559,7 @@ int launch_fused_dwpw(const FusedLaunch& f, hipStream_t st, int* amax_n) {
   a.amax_x = f.amax_x; a.wt = reinterpret_cast<const uint4*>(f.wt); a.w_inv_scale = f.w_inv_scale; a.scale = f.scale;
   a.shift = f.shift; a.y = f.y; a.ldy = f.ldy; a.frames = f.frames; a.relu = f.relu; a.amax_y = f.amax_y;
   a.lens_y = f.lens_y; a.x2 = f.x2; a.ldx2 = f.ldx2; a.lens2 = f.lens2; a.amax_x2 = f.amax_x2; a.batch = f.batch;
+  a.nt_store = f.nt_store;
   const bool dual = f.x2 != nullptr;
   if (f.kernel == 33) return dual ? launch_fused_t<33, true>(a, st, amax_n) : launch_fused_t<33, false>(a, st, amax_n);
   if (f.kernel == 39) return dual ? launch_fused_t<39, true>(a, st, amax_n) : launch_fused_t<39, false>(a, st, amax_n);

@@ -367,9 +367,17 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
     const int cn = c + 1;
     // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
-    uint4 bf[2][PL];
+#ifndef VASR_PW_BDEPTH
+#define VASR_PW_BDEPTH 1   // n-tiles a B fragment is requested ahead of its MFMAs (2: three fragment sets, reads pinned per n-tile)
+#endif
+    constexpr int BD = (VASR_PW_BDEPTH == 2 && PL == 2 && TN == 4) ? 2 : 1;
+    uint4 bf[BD + 1][PL];
 #pragma unroll
     for (int p = 0; p < PL; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
+    if constexpr (BD == 2) {
+#pragma unroll
+      for (int p = 0; p < PL; ++p) bf[1][p] = bs(c & 1, p, 0, kh, 32 + l31);
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if constexpr (WSETS == 2) {
@@ -384,8 +392,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
       uint4 (&cw)[TM][PL] = aw[WSETS == 2 ? 0 : s % WSETS];   // this k-step's weight fragments
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int cur_f = (s * TN + j) & 1, nxt_f = cur_f ^ 1;
-        if (!(VASR_ABLATE & 2)) {
+        const int g = s * TN + j;
+        const int cur_f = BD == 2 ? g % 3 : (g & 1), nxt_f = BD == 2 ? (g + 2) % 3 : (cur_f ^ 1);
+        if constexpr (BD == 2) {
+          if (g + 2 < STEPS * TN) {
+#pragma unroll
+            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, (g + 2) / TN, kh, ((g + 2) % TN) * 32 + l31);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to two MFMAs before their use)
+        } else if (!(VASR_ABLATE & 2)) {
           if (j + 1 < TN) {
 #pragma unroll
             for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
@@ -521,7 +536,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
           const int m = mq + row, t = t0 + 4 * c4;
           if (RES) v += *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m) * a.ldr + t);
           if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
-          *reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t) = v;
+          v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t);
+          if (a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) output too large for the Infinity Cache: stream_stores
+          else *dstp = v;
           if (a.amax_y.p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) track(v[e], t + e);
@@ -617,8 +634,8 @@ bool pointwise_split_supported(int M, int K, int K1) {
 int pointwise_amax_slots(int M, int64_t ld) { return (int)((int64_t)(M / 64) * ((ld + 31) / 32) * 2); }
 
 int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* amax_n) {
-  static const int force = getenv("VASR_PW3_TILE") ? atoi(getenv("VASR_PW3_TILE")) : 0;   // 1..5 pins a tile shape
-  static const bool no_skip = getenv("VASR_NO_TILE_SKIP") && atoi(getenv("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
+  static const int force = dev_env("VASR_PW3_TILE") ? atoi(dev_env("VASR_PW3_TILE")) : 0;   // 1..5 pins a tile shape
+  static const bool no_skip = dev_env("VASR_NO_TILE_SKIP") && atoi(dev_env("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
   PwArgs a = args;
   if (no_skip) a.zero_from = nullptr;
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:

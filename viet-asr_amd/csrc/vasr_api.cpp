@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vasr.h"
+#include "vasr_devtools.h"
 #include "vasr_internal.h"
 
 using namespace vasr;
@@ -374,7 +375,7 @@ int build_encoder(vasr_handle* h) {
       const SubBlock& last = B.subs.back();
       const int k1 = last.pw.cin, k2 = cin;
       const int chunk = d.filters % 512 == 0 ? 128 : (d.filters % 256 == 0 ? 64 : 32);
-      if (d.stride == 1 && k1 % chunk == 0 && k2 % chunk == 0 && !getenv("VASR_NO_FUSED_RESIDUAL")) {
+      if (d.stride == 1 && k1 % chunk == 0 && k2 % chunk == 0 && !dev_env("VASR_NO_FUSED_RESIDUAL")) {
         char w1[160], bn1[160], w2[160], bn2[160];
         const int jl = j - (last.separable ? 3 : 2);
         snprintf(w1, sizeof w1, "encoder.%zu.mconv.%d.conv.weight", i, jl + (last.separable ? 1 : 0));
@@ -502,6 +503,13 @@ struct ProfScope {
 };
 enum { kProfFrontend = 0, kProfDepthwise = 1, kProfPointwise = 2, kProfHead = 3, kProfFused = 4 };
 
+}  // namespace
+bool vasr::stream_stores(size_t out_bytes) {
+  static const long mb = dev_env("VASR_NT_MB") ? atol(dev_env("VASR_NT_MB")) : 0;   // off: measured, no gain in the pipeline
+  return mb > 0 && out_bytes >= (size_t)mb * 1000000u;
+}
+namespace {
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(VASR_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
@@ -597,12 +605,12 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // ---- fused depthwise -> pointwise kernel (encoder_fused.hip): 256-channel sub-blocks in the fp16-split arithmetic, when
       //      there are enough 128-frame tiles to fill the chip (one workgroup per tile, all channels); VASR_FUSED=0 is the
       //      A/B switch ----
-      static const bool fused_on = !(getenv("VASR_FUSED") && atoi(getenv("VASR_FUSED")) == 0);
+      static const bool fused_on = !(dev_env("VASR_FUSED") && atoi(dev_env("VASR_FUSED")) == 0);
       // One workgroup per CU (159 KB of LDS), one 128-frame tile each: it pays when the tiles fill whole rounds of the chip
       // (measured, fused vs two kernels: 64 x 10 s = 256 tiles -3.4 % per step, 512 x 30 s = 6144 tiles -4 %; but 32 x 10 s = 128
       // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  VASR_FUSED_MIN_TILES=n forces
       // the fused form from n tiles on, whatever the fill (tests).
-      static const int fused_min_tiles = getenv("VASR_FUSED_MIN_TILES") ? atoi(getenv("VASR_FUSED_MIN_TILES")) : 0;
+      static const int fused_min_tiles = dev_env("VASR_FUSED_MIN_TILES") ? atoi(dev_env("VASR_FUSED_MIN_TILES")) : 0;
       static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -629,6 +637,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         f.amax_y = free_tab(cur_amax); f.lens_y = lens(S.pw.step + 1);
         if (fuse_res) { f.x2 = blk_in; f.ldx2 = blk_ld; f.lens2 = lens(B.first_step); f.amax_x2 = blk_amax; }
         f.batch = batch; f.kernel = S.dw.kernel;
+        f.nt_store = stream_stores((size_t)batch * WF.cout * cur_ld * 4);
         int e;
         {
           ProfScope ps(h, kProfFused, st, 2.0 * WF.cin * WF.cout * (double)cur_T * batch,
@@ -653,7 +662,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         // 512-channel layer: 22.8 / 23.7 / 23.8 / 28.1 us at K = 51 / 63 / 75 / 87 x 2 against 25.6 / 28.4 / 31.0 / 35.5 us
         // of packed FMAs; 256 channels, K = 33 / 39: 12.8 / 12.6 against 13.3 / 13.4), else packed FMAs.
         // VASR_DW_MFMA=0 keeps the packed-FMA kernels.
-        static const bool dw_mfma = !(getenv("VASR_DW_MFMA") && atoi(getenv("VASR_DW_MFMA")) == 0);
+        static const bool dw_mfma = !(dev_env("VASR_DW_MFMA") && atoi(dev_env("VASR_DW_MFMA")) == 0);
         int e = -1;
         if (want_amax && dw_mfma && cur_amax.p && S.dw.d_taps)
           e = launch_depthwise_mfma(cur, cur_ld, S.dw.d_taps, S.dw.d_tap_inv, lens(S.dw.step), lens(S.dw.step + 1), cur_amax,
@@ -686,6 +695,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
       a.amax_x = gx_amax;
       a.amax_x2 = fuse ? blk_amax : AmaxTab{};
+      a.nt_store = !(last_block && last_sub) && stream_stores((size_t)batch * W.m_pad * dst_ld * 4);
       // this GEMM's output is masked at lens(S.pw.step + 1) by whatever reads it next
       // (the encoder output's maxima are only wanted by the fused path's CTC head, which reads every column < T')
       if (want_amax && (!(last_block && last_sub) || enc_amax)) {
@@ -1044,7 +1054,7 @@ int vasr_get_gemm_mode(const vasr_handle* h) { return h ? h->gemm_mode : -1; }
 
 int vasr_set_busy_cus(vasr_handle* h, int cus) {
   if (!h || cus < 0) return fail(VASR_ERR_INVALID, "busy compute units must be >= 0");
-  static const bool off = getenv("VASR_NO_BUSY_CUS") && atoi(getenv("VASR_NO_BUSY_CUS")) != 0;   // A/B switch
+  static const bool off = dev_env("VASR_NO_BUSY_CUS") && atoi(dev_env("VASR_NO_BUSY_CUS")) != 0;   // A/B switch
   h->busy_cus = off ? 0 : cus;
   return 0;
 }
@@ -1155,6 +1165,7 @@ int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double f
   return 0;
 }
 
+#ifdef VASR_DEVTOOLS
 __global__ void vasr_noop_kernel() {}
 
 int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us) {
@@ -1175,6 +1186,8 @@ int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us) {
   *out_us = 1e3 * (double)t[n / 2];
   return 0;
 }
+
+#endif  // VASR_DEVTOOLS
 
 int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]) {
   if (!h || !h->finalized || !out) return fail(VASR_ERR_INVALID, "bad argument");
@@ -1202,6 +1215,7 @@ int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, doub
   return 0;
 }
 
+#ifdef VASR_DEVTOOLS   // ---- include/vasr_devtools.h: isolated layers and weight packers, libvasr_hip_dev.so only ----
 int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
                          int64_t frames, int kernel, float* d_y, vasr_stream stream) {
   if (!d_x || !d_w || !d_lens || !d_y) return fail(VASR_ERR_INVALID, "bad argument");
@@ -1230,7 +1244,7 @@ int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   AmaxTab ax{d_amax, amax_stride, 0}, ay{d_amax + (size_t)batch * amax_stride, amax_stride, 0};
   // timing runs (tools/bench_dw.py): VASR_BENCH_KEEP_AMAX=1 reuses the input maxima a previous call left in d_amax
-  static const bool keep = getenv("VASR_BENCH_KEEP_AMAX") != nullptr;
+  static const bool keep = dev_env("VASR_BENCH_KEEP_AMAX") != nullptr;
   static int kept_n = 0;
   if (keep && kept_n) ax.n = kept_n;
   else launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
@@ -1263,7 +1277,7 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   PwArgs a{};
   a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
   launch_pointwise(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise");
 }
@@ -1296,7 +1310,7 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   if (amax_stride < 256 || amax_stride < pointwise_amax_slots(cout, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   AmaxTab ax{d_amax, amax_stride, 0};
-  static const bool keep = getenv("VASR_BENCH_KEEP_AMAX") != nullptr;   // timing runs: see vasr_bench_depthwise_mfma
+  static const bool keep = dev_env("VASR_BENCH_KEEP_AMAX") != nullptr;   // timing runs: see vasr_bench_depthwise_mfma
   static int kept_n = 0;
   if (keep && kept_n) ax.n = kept_n;
   else launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, &ax, st);
@@ -1304,7 +1318,7 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w16); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
   a.amax_x = ax; a.w_inv_scale = w_inv_scale;
   a.amax_y = AmaxTab{d_amax + (size_t)batch * amax_stride, amax_stride, 0};   // second table: maxima of y
   int n_y = 0;
@@ -1328,10 +1342,12 @@ int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const fl
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = getenv("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
-  const int e = launch_pointwise_split(a, getenv("VASR_BENCH_BF16X2") ? 1 : 0, static_cast<hipStream_t>(stream));
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  const int e = launch_pointwise_split(a, dev_env("VASR_BENCH_BF16X2") ? 1 : 0, static_cast<hipStream_t>(stream));
   if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
   return check_launch("bench_pointwise_bf16x3");
 }
+
+#endif  // VASR_DEVTOOLS
 
 }  // extern "C"

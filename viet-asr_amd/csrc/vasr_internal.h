@@ -3,8 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace vasr {
+
+// Kernel-selection / A-B switches (VASR_DW_*, VASR_PW3_TILE, VASR_FUSED*, VASR_NO_*, ...) are read from the environment by
+// the DEVTOOLS build only (libvasr_hip_dev.so: tests of the alternate kernel paths, tools/); the product library never
+// looks at them.  VASR_GEMM and VASR_SLICES -- documented modes with API equivalents -- stay plain getenv in vasr_api.cpp.
+#ifdef VASR_DEVTOOLS
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 // Kernel-duration probe for vasr_profile_begin/end.  When armed, the next VASR_LAUNCH goes out through
 // hipExtLaunchKernelGGL with (start, stop) events that take the dispatch packet's own begin / end timestamps, i.e. the
@@ -43,6 +53,13 @@ extern thread_local LaunchProbe g_probe;
 // epilogues over T' = 512; at 128 it costs 640.)
 constexpr int kTimeTile = 128;
 static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
+
+// Non-temporal ("nt") stores for a layer's output: right when the tensor cannot stay in the 256 MiB Infinity Cache anyway.
+// Measured (tools/probes/hbm_probe.py, read + write of the same size): at 403 MB -- one 512-channel layer of 512 x 30 s --
+// a copy runs at 5.9 TB/s with plain stores and 6.9-7.3 TB/s with nt stores; at 134 MB (64 x 10 s) both run at 6.5-6.7 TB/s
+// and the NEXT kernel finds a plainly stored tensor in the cache (round 1: nt stores there cost +0.16 / +0.26 ms per step).
+// VASR_NT_MB overrides the threshold (0 = never).
+bool stream_stores(size_t out_bytes);
 
 // Per-utterance maxima for the fp16-split arithmetic (encoder_pw_split.hip kF16x2, encoder_dw_mfma.hip): every kernel
 // that produces a tensor such a kernel will read publishes max |y| over each utterance's valid frames, one plain store
@@ -131,6 +148,7 @@ struct PwArgs {
   AmaxTab amax_x;
   AmaxTab amax_x2;
   float w_inv_scale;
+  int32_t nt_store;       // output stored with non-temporal hints (stream_stores)
   // any split arithmetic: publish max |y| over columns < lens_y[b] (nullptr: < frames) into amax_y (p == nullptr: off);
   // launch_pointwise_split reports the slots it used through its amax_n argument
   AmaxTab amax_y;
@@ -165,6 +183,7 @@ struct FusedLaunch {
   AmaxTab amax_y; const int32_t* lens_y;
   const float* x2; int64_t ldx2; const int32_t* lens2; AmaxTab amax_x2;   // residual source (nullptr = none)
   int32_t batch, kernel;
+  int32_t nt_store;                            // output stored with non-temporal hints (stream_stores)
 };
 bool fused_dwpw_supported(int channels, int cout, int kernel, int stride, int dilation);
 int fused_dwpw_taps_per_pair(int kernel);
