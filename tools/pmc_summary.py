@@ -11,7 +11,8 @@ import sys
 
 
 def short(name):
-    for key in ("pw_gemm_split_kernel", "pw_gemm_bf16x3_kernel", "pw_gemm_kernel", "dw_conv_kernel", "dw_pair_kernel", "dw_toeplitz_kernel"):
+    for key in ("pw_gemm_split_kernel", "pw_gemm_bf16x3_kernel", "pw_gemm_kernel", "dw_conv_kernel", "dw_pair_kernel", "dw_toeplitz_kernel",
+                "dwpw_fused_kernel"):
         if key + "<" in name:
             return key + "<" + name.split(key + "<")[1].split(">")[0] + ">"
     for key in ("dw_conv_generic", "stft_logmel", "normalize_kernel", "logsoftmax_argmax", "ctc_collapse",
