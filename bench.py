@@ -566,7 +566,8 @@ def main():
     if rate != 16000 and rank == 0:
         ms_rs = timed(lambda: audio.resample(passes[0][0], passes[0][1], rate, 16000), max(3, a.steps // 4))
         in_b, out_b = passes[0][0].numel() * 4, wav16.numel() * 4
-        extra["resample"] = {"kernel": "resample_poly_kernel (windowed-sinc, wings in LDS)", "ms_per_batch": round(ms_rs, 3),
+        extra["resample"] = {"kernel": "resample_up_kernel (integer up-sampling: both wings as one fp64 filter in LDS, 8 outputs "
+                                       "per lane over a sliding register window)", "ms_per_batch": round(ms_rs, 3),
                              "bound": "hbm", "achieved": round((in_b + out_b) / (ms_rs * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round((in_b + out_b) / (ms_rs * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 

@@ -156,6 +156,83 @@ __global__ __launch_bounds__(256) void resample_phase_kernel(const float* __rest
   }
 }
 
+// Integer up-sampling (ratio = p / 1: 8 -> 16 kHz is p = 2), the BASELINE configs[4] case.  The phase kernel above spends
+// ~6 instructions per tap and output (two LDS reads, fp32 multiply, conversion, fp64 add, loop) on 128 taps: 4.4 ms for
+// 512 x 30 s -- 0.05 of its HBM roofline.  Here both wings of a phase are ONE filter h[ph][m] over x[n + m]
+// (m = -(il - 1) .. ir), stored in LDS as fp64, and a lane produces R = 8 consecutive same-phase outputs, whose inputs
+// are consecutive samples (q = 1): a sliding window of R + 7 fp64 samples in registers, per block of 8 taps 8 new
+// samples (one LDS read + one conversion each), 8 weights (LDS broadcast reads) and 64 v_fma_f64 -- 1.4 instructions per
+// tap and output.  Arithmetic: the same fp32 interpolated weights, fp64 accumulation of the EXACT products (the phase
+// kernel rounds every product to fp32 first; the difference is 2^-24 of a term, the oracle comparison is at 2e-6).
+constexpr int kUpR = 8, kUpTB = 8;
+// grid (ceil(ld_out / tile), B), block 256; tile = 8 p floor(256 / p) outputs.  Dynamic LDS: double h[p][mpad], float xs[span]
+__global__ __launch_bounds__(256) void resample_up_kernel(const float* __restrict__ x, int64_t ld_in,
+                                                          const int64_t* __restrict__ len_in,
+                                                          const float2* __restrict__ table, int nwin, int num_table, int p,
+                                                          int wmax, int mpad, int span, int tile,
+                                                          float* __restrict__ y, int64_t ld_out,
+                                                          int64_t* __restrict__ len_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* h = reinterpret_cast<double*>(lds_raw);                 // [p][mpad]: taps m = u - (wmax - 1), u = 0 .. mpad - 1
+  float* xs = reinterpret_cast<float*>(h + (size_t)p * mpad);     // [span]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * tile;                  // a multiple of p: output t0 + ph has phase ph
+  const int64_t n_orig = len_in[b];
+  const int64_t n_out = n_orig * p;                               // int(n_orig * ratio), ratio = p exactly
+  if (blockIdx.x == 0 && tid == 0) len_out[b] = n_out;
+  const float* xi = x + (int64_t)b * ld_in;
+  const int index_step = num_table;                               // scale = 1 for up-sampling
+  // ---- the p filters (same expressions as the generic kernel at t = ph: time_register = ph / p, n = 0) ----
+  for (int i = tid; i < p * mpad; i += 256) {
+    const int ph = i / mpad, u = i - ph * mpad, m = u - (wmax - 1);
+    const double fl = (double)ph / (double)p, fr = 1.0 - fl;
+    const double ifl = fl * num_table, ifr = fr * num_table;
+    const int ol = (int)ifl, orr = (int)ifr;
+    const float el = (float)(ifl - ol), er = (float)(ifr - orr);
+    const int il = (nwin - ol) / index_step, ir = (nwin - orr) / index_step;
+    float w = 0.f;
+    if (m <= 0 && -m < il) { const float2 tw = table[ol + (-m) * index_step]; w = tw.x + el * tw.y; }
+    else if (m >= 1 && m - 1 < ir) { const float2 tw = table[orr + (m - 1) * index_step]; w = tw.x + er * tw.y; }
+    h[i] = (double)w;
+  }
+  // ---- input span of the tile: x[n_lo + j], zero outside [0, n_orig) (what the wings' bounds amount to) ----
+  const int64_t n_lo = t0 / p - (wmax - 1);
+  for (int j = tid; j < span; j += 256) {
+    const int64_t g = n_lo + j;
+    xs[j] = (g >= 0 && g < n_orig) ? xi[g] : 0.f;
+  }
+  __syncthreads();
+  const int units = (tile / p) / kUpR * p;
+  if (tid >= units) return;
+  const int ph = tid % p, k = tid / p;
+  // outputs t_j = t0 + ph + p (R k + j), inputs n_j = t0 / p + R k + j; tap u reads xs[R k + j + u]
+  const double* hp = h + (size_t)ph * mpad;
+  const float* xp = xs + kUpR * k;
+  double acc[kUpR], xr[kUpR + kUpTB - 1];
+#pragma unroll
+  for (int j = 0; j < kUpR; ++j) acc[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < kUpR - 1; ++j) xr[j] = (double)xp[j];
+  for (int u0 = 0; u0 < mpad; u0 += kUpTB) {
+#pragma unroll
+    for (int e = 0; e < kUpTB; ++e) xr[kUpR - 1 + e] = (double)xp[u0 + kUpR - 1 + e];
+#pragma unroll
+    for (int e = 0; e < kUpTB; ++e) {
+      const double w = hp[u0 + e];
+#pragma unroll
+      for (int j = 0; j < kUpR; ++j) acc[j] = __builtin_fma(w, xr[e + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kUpR - 1; ++j) xr[j] = xr[j + kUpTB];
+  }
+  float* yo = y + (int64_t)b * ld_out;
+#pragma unroll
+  for (int j = 0; j < kUpR; ++j) {
+    const int64_t t = t0 + ph + (int64_t)p * (kUpR * k + j);
+    if (t < ld_out) yo[t] = t < n_out ? (float)acc[j] : 0.f;
+  }
+}
+
 int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
 
 }  // namespace
@@ -168,16 +245,29 @@ void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st)
 void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int batch, const float* table, int nwin,
                      int num_table, double ratio, float* y, int64_t ld_out, int64_t* len_out, hipStream_t st) {
   // ratio as p/q: sample rates are integers, so ratio * 48000 * 44100 / ... is overkill -- try denominators up to 1000
-  int p = 0;   // numerator of the reduced ratio (the phase count); 0 = no small rational found
+  int p = 0, q = 0;   // the reduced ratio p / q (p = the phase count); 0 = no small rational found
   for (int d = 1; d <= 1000 && !p; ++d) {
     const double num = ratio * d;
     const double rn = (double)(int64_t)(num + 0.5);
     if (rn >= 1.0 && rn < 1e6 && (num > rn ? num - rn : rn - num) <= 1e-12 * rn) {
       const int64_t g = gcd64((int64_t)rn, d);
       p = (int)((int64_t)rn / g);
+      q = (int)(d / g);
     }
   }
   static const bool generic_only = dev_env("VASR_RESAMPLE_GENERIC") && atoi(dev_env("VASR_RESAMPLE_GENERIC")) != 0;
+  static const bool no_up = dev_env("VASR_RESAMPLE_NO_UP") && atoi(dev_env("VASR_RESAMPLE_NO_UP")) != 0;   // A/B: the phase kernel
+  if (p >= 2 && p <= 16 && q == 1 && !generic_only && !no_up) {   // integer up-sampling: 8 -> 16 kHz
+    const int wmax = nwin / num_table + 2;                              // >= taps of either wing
+    const int mpad = (2 * wmax + kUpTB - 1) / kUpTB * kUpTB;
+    const int tile = kUpR * p * (256 / p);
+    const int span = tile / p + mpad + kUpR + kUpTB;
+    const size_t lds = sizeof(double) * (size_t)p * mpad + sizeof(float) * span;
+    dim3 grid((unsigned)((ld_out + tile - 1) / tile), batch);
+    hipLaunchKernelGGL(resample_up_kernel, grid, dim3(256), lds, st, x, ld_in, len_in, reinterpret_cast<const float2*>(table),
+                       nwin, num_table, p, wmax, mpad, span, tile, y, ld_out, len_out);
+    return;
+  }
   if (p > 0 && !generic_only) {
     const double scale = ratio < 1.0 ? ratio : 1.0;
     const int index_step = (int)(scale * num_table);
