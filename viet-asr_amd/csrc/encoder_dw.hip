@@ -532,10 +532,20 @@ __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, con
     lf += 1.0f;
   };
   // two loops, not one with `s < 256 ? sh_steps[s] : steps[s]`: that select becomes a flat load, whose wait
-  // (vmcnt(0)) also waits for the previous iteration's store to complete -- 660 cycles per step instead of ~60
+  // (vmcnt(0)) also waits for the previous iteration's store to complete -- 660 cycles per step instead of ~60.
+  // The LDS loop takes its steps EIGHT at a time: the eight table reads are in flight together, then eight links of the
+  // chain run back to back (one LDS round trip per link was ~2/3 of the kernel's 15 us: 86 links for QuartzNet15x5).
   const int n_lds = n_steps < 256 ? n_steps : 256;
-  for (int s = 0; s < n_lds; ++s) advance(s, sh_steps[s]);
-  for (int s = n_lds; s < n_steps; ++s) advance(s, steps[s]);
+  int s = 0;
+  for (; s + 8 <= n_lds; s += 8) {
+    LenStep blk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) blk[k] = sh_steps[s + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) advance(s + k, blk[k]);
+  }
+  for (; s < n_lds; ++s) advance(s, sh_steps[s]);
+  for (s = n_lds; s < n_steps; ++s) advance(s, steps[s]);
   lens_tab[(int64_t)n_steps * batch + b] = (int32_t)(int64_t)lf;
   if (enc_len) enc_len[b] = lf;
   if (wav_len) {
@@ -543,7 +553,7 @@ __global__ void len_chain_kernel(const int64_t* __restrict__ seq, int batch, con
     // torch.stft(center=True) gives 1 + L // hop frames, every conv floor((t + 2 p - d (K - 1) - 1) / stride) + 1;
     // the same count ctc_collapse_kernel stops at
     int64_t t = 1 + wav_len[b] / hop;
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = 0; s < n_steps; ++s) {   // (integer arithmetic, no conversions: its loads pipeline on their own)
       const LenStep st = s < n_lds ? sh_steps[s] : steps[s];
       t = (t + 2 * st.pad - st.dilation * (st.kernel - 1) - 1) / st.stride + 1;
     }

@@ -616,9 +616,12 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
       }();
-      const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile), f_rounds = (f_tiles + n_cu - 1) / n_cu;
+      // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- take no workgroups: 256 tiles on the
+      // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
+      const int f_cus = h->busy_cus > 0 && h->busy_cus < n_cu - 32 ? n_cu - h->busy_cus : n_cu;
+      const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile), f_rounds = (f_tiles + f_cus - 1) / f_cus;
       const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles
-                                              : (f_tiles >= 3 * n_cu / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * n_cu));
+                                              : (f_tiles >= 3 * f_cus / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * f_cus));
       const bool fuse_res = last_sub && B.fused_res;
       const ConvLayer& WF = fuse_res ? B.fused : S.pw;
       // (not in row-independent mode: whether a sub-block is fused depends on the batch's tile count, and the two forms
