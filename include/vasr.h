@@ -159,7 +159,12 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
  *                measured against fp64 it is not less accurate than modes 0 and 1 (tests/test_gpu_parity.py::
  *                test_split_gemms_are_as_accurate_as_fp32_mfma) and all reference fixtures hold with the same
  *                tolerances.  A GEMM whose input has no published maxima (port tensors of the per-module entry points,
- *                the CTC head) runs as mode 1.
+ *                the CTC head) runs as mode 1.  In this mode the 256-channel separable sub-blocks (depthwise K = 33 / 39 +
+ *                1x1 conv + BN + residual + ReLU) run as ONE fused kernel when the batch's 128-frame tiles fill the chip
+ *                (encoder_fused.hip; its operand scale comes from a bound -- max |x| times the layer's largest tap sum --
+ *                instead of the measured maximum, same tolerances).  Whether a sub-block is fused depends on the batch
+ *                shape, and the two forms round differently: bit-identical rows across batch compositions are promised by
+ *                vasr_set_row_independent (which never fuses), not by the default mode.
  * Layers whose shape the split kernel does not cover keep mode 0.
  * The environment variable VASR_GEMM=fp32 / bf16x3 / bf16x2 / f16x2 sets the initial mode of new handles. */
 int vasr_set_gemm_mode(vasr_handle* h, int mode);
@@ -190,8 +195,10 @@ int vasr_set_slices(vasr_handle* h, int slices);
  * treat row b as if it were alone: reflect padding at length[b], ids / id_len collapsed over the 1 + length[b] / hop mel
  * frames (taken through the conv chain) an unbatched call would have produced.  Everything in between is already
  * row-local (masks at the row's length, eval-mode BN), so ids / id_len equal those of batch-1 calls bit for bit
- * whatever the other rows are.  Every length[b] must exceed n_fft / 2 (an unbatched torch.stft refuses shorter input);
- * pred / logp keep their [B, T'] shapes, frames past a row's own count are unspecified. */
+ * whatever the other rows are -- also in ragged batches in the fp16-split arithmetic: the encoder output's maxima (the
+ * CTC head's operand scale) are taken over the row's own frames and the head reads zeros behind them.  Every length[b]
+ * must exceed n_fft / 2 (an unbatched torch.stft refuses shorter input); pred / logp keep their [B, T'] shapes, frames
+ * past a row's own count are unspecified. */
 int vasr_set_row_independent(vasr_handle* h, int on);
 /* Compute units that another kernel of the caller's keeps busy while this handle's kernels run -- e.g. the beam search of
  * the previous batch on a side stream, one workgroup per utterance (engine.forward_beam).  The GEMM tile choice then
