@@ -121,6 +121,47 @@ def _worker(rank, world, port, q):
         for kw in (dict(), dict(batch_size=2), dict(balance=False)):       # duration-balanced (default) and by count
             assert vdist.transcribe_sharded(FakeEngine(), sigs, **kw) == want, kw
         assert vdist.transcribe_sharded(FakeEngine(), sigs[:1]) == want[:1]      # fewer utterances than ranks
+
+        # -- the manifest data layer under AllGpu placement: duration-balanced shards (default) cover every utterance
+        #    exactly once across the ranks, in whole length buckets; shard_by="count" gives contiguous equal-count shards
+        import json, tempfile
+        from viet_asr_amd import audio
+        from viet_asr_amd.data_layer import AudioToTextDataLayer
+
+        class _Factory:          # stands in for NeuralModuleFactory(local_rank=...), which needs a HIP device
+            placement = DeviceType.AllGpu
+        NeuralModuleFactory.set_default_factory(_Factory())
+        tmp = tempfile.mkdtemp(prefix=f"vasr_dl_{rank}_")
+        durs = [0.30, 0.05, 0.21, 0.12, 0.40, 0.08, 0.33, 0.17, 0.26, 0.11, 0.37]
+        man = os.path.join(tmp, "m.json")
+        with open(man, "w") as f:
+            for i, d in enumerate(durs):
+                p = os.path.join(tmp, f"u{i}.wav")
+                audio.write_wav(p, np.full(int(d * 16000), 0.01 * (i + 1), dtype=np.float32), 16000)
+                f.write(json.dumps({"audio_filepath": p, "duration": d, "text": "ab"}) + "\n")
+        labels = [" ", "a", "b"]
+        mine, cost = {}, {}
+        for mode in ("duration", "count"):
+            dl = AudioToTextDataLayer(man, labels, batch_size=2, min_duration=0.01, shard_by=mode)
+            order = dl.utterance_order()
+            got = []
+            for a_sig, a_len, toks, t_len in dl.data_iterator:
+                assert a_sig.shape[0] <= 2 and toks.shape[0] == a_sig.shape[0]
+                got += [round(int(n) / 16000, 2) for n in a_len]
+            assert got == [durs[i] for i in order]                   # batches deliver what utterance_order() says
+            mine[mode] = order
+            cost[mode] = sum(len(b) * max(durs[i] for i in b) for b in [order[j:j + 2] for j in range(0, len(order), 2)])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, cost))
+        for mode in ("duration", "count"):
+            every = sorted(i for m, _ in gathered for i in m[mode])
+            assert every == list(range(len(durs))), (mode, every)      # exact cover across the ranks
+        lo, hi = vdist.shard_range(len(durs), rank, world)
+        assert sorted(mine["count"]) == list(range(lo, hi))
+        if world == 2:
+            costs = [c["duration"] for _, c in gathered]
+            assert (max(costs) - min(costs)) / max(costs) < 0.2, costs      # 6 buckets over 2 ranks: within one small bucket
+        NeuralModuleFactory.reset_default_factory()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
