@@ -149,6 +149,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VASR_PW_PRIO
+  if (VASR_PW_PRIO == 2 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   const int wm = wave * 32 * TM;
   const int kh = lane >> 5, l31 = lane & 31;
   const int len = MASK ? a.lens[b] : 0;
@@ -412,6 +415,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
 #pragma unroll
           for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bf[cur_f][p];
         }
+#ifndef VASR_PW_PRIO
+#define VASR_PW_PRIO 0   // 1: s_setprio 1 around every n-tile's MFMA cluster; 2: static s_setprio 1 for wavefronts 4-7 (dev experiments)
+#endif
+        if (VASR_PW_PRIO == 1) __builtin_amdgcn_s_setprio(1);
         // cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
         if constexpr (ARITH == kBf16x3) {
 #pragma unroll
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
+        if (VASR_PW_PRIO == 1) __builtin_amdgcn_s_setprio(0);
 #if VASR_PW_FILLER
         // dev-only experiment (dw -> pw fusion budget): VASR_PW_FILLER independent v_fma_f32 per MFMA of this n-tile group,
         // the VALU work a fused depthwise would have to co-issue (8.5 per MFMA at K = 51, 12.5 at K = 75 for kF16x2)
