@@ -37,8 +37,11 @@ namespace {
 constexpr int kThreads = VASR_BEAM_THREADS;   // workgroup size: 256, 512 or 1024
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxBeams = 128;
-constexpr int kSlots = 2048;
-constexpr int kMaxFill = 1434;  // 70 % of kSlots
+#ifndef VASR_BEAM_SLOTS
+#define VASR_BEAM_SLOTS 2048
+#endif
+constexpr int kSlots = VASR_BEAM_SLOTS;          // merge-table slots (a power of two, a multiple of the workgroup size)
+constexpr int kMaxFill = kSlots * 7 / 10;        // pairs per pass: the table stays <= 70 % full (1433 at 2048 slots)
 constexpr int kMaxClasses = 128;
 constexpr int kMaxCtx = 4;      // LM order <= 5
 constexpr unsigned long long kFnvOffset = 1469598103934665603ull, kFnvPrime = 1099511628211ull;
