@@ -263,3 +263,28 @@ def test_synthetic_audio_is_padded_like_the_collate():
     assert torch.equal(a, torch.from_numpy(sig)) and l.tolist() == lens.tolist()
     with pytest.raises(StopIteration):
         next(dl)
+
+
+def test_bench_rate_arithmetic_and_core_count_without_a_gpu():
+    """bench.py's per-class rates are work-that-ran over time-it-took: the dominant kernel (plain GEMM launches) under
+    `roofline`, fused launches on their own, both together as the conservative family figure; cpu_baseline counts the
+    CPUs the process can really use (affinity cut down by the cgroup quota), not os.cpu_count()."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vasr_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    steps = 10
+    prof = {"frontend": dict(ms=1.0, launches=30, flops=0.0, bytes=0.0),
+            "depthwise": dict(ms=10.0, launches=470, flops=0.0, bytes=10 * 6.0e9),
+            "pointwise": dict(ms=28.0, launches=480, flops=10 * 9.42e11, bytes=0.0),
+            "head": dict(ms=0.7, launches=30, flops=0.0, bytes=0.0),
+            "fused": dict(ms=9.4, launches=300, flops=10 * 1.51e11, bytes=10 * 2.17e9)}
+    cr = bench.class_rates(prof, steps, "f16x2")
+    assert abs(cr["exec_tflops"] - 3 * 9.42e11 / 2.8e-3 / 1e12) < 1e-6                   # plain GEMMs only
+    assert abs(cr["fam_exec_tflops"] - 3 * (9.42e11 + 1.51e11) / 3.74e-3 / 1e12) < 1e-6   # + fused, whole duration
+    assert cr["fam_exec_tflops"] < cr["exec_tflops"] and cr["peak"] == bench.PEAK_16BIT_MFMA_TFLOPS
+    assert abs(cr["dw_gbs"] - 6.0e9 / 1e-3 / 1e9) < 1e-6 and abs(cr["fu_gbs"] - 2.17e9 / 0.94e-3 / 1e9) < 1e-6
+    assert bench.class_rates(prof, steps, "fp32")["peak"] == bench.PEAK_F32_MFMA_TFLOPS
+    n, how = bench.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0)) and "affinity" in how
+    assert set(bench.WORKLOADS) == {2, 3, 4, 5} and bench.WORKLOADS[5][1] * 8 == bench.JOB_CLIPS
