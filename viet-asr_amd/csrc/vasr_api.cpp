@@ -627,7 +627,9 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // (not in row-independent mode: whether a sub-block is fused depends on the batch's tile count, and the two forms
       // round differently -- that mode promises bit-identical rows whatever the batch)
       if (fused_on && !h->row_independent && S.separable && S.dw.d_ftaps && h->gemm_mode == 3 && want_amax && cur_amax.p && WF.d_w16 &&
-          !(last_sub && B.has_res && !B.fused_res) && (!fuse_res || (blk_amax.p && blk_ld == cur_ld)) &&
+          !(last_sub && B.has_res && !B.fused_res) &&
+          // a folded residual must come from a 256-channel block input (K = 256 + 256): the kernel's second K range is 4 chunks
+          (fuse_res ? (blk_amax.p && blk_ld == cur_ld && WF.cin == 2 * S.dw.cin && B.fused_k1 == S.dw.cin) : WF.cin == S.dw.cin) &&
           cur_ld % kTimeTile == 0 && f_fill &&
           !(last_block && last_sub)) {
         float* dst = free3[flip];
