@@ -51,6 +51,7 @@ using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 enum { kBf16x3 = 0, kBf16x2 = 1, kF16x2 = 2 };
 
 constexpr int BKC = 64;   // K rows per LDS buffer
+
 #ifndef VASR_ABLATE
 #define VASR_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no weight reloads, 2 no LDS fragment reads,
 #endif                  // 4 no activation staging, 8 no per-chunk barrier
@@ -348,6 +349,19 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
         sstore_half(0, 0, S0{}, p, 1);
       }
       if constexpr (SSETS == 2) gload(BKC, S0{});   // chunk 1: converted during chunk 0
+    }
+  }
+  // Dev experiment (VASR_PW3_TILE=6 VASR_PW_PHASE=ticks): two 4-wavefront workgroups share a compute unit (the hardware's
+  // TG_ID tells them apart: tools/probes/place_probe.hip -- blockIdx i and i + 256 land on one unit, TG_ID 0 and 1); the
+  // second one holds back for `phase_delay` ticks of the 100 MHz clock so that its store-only epilogue runs under the
+  // other's MFMAs and vice versa.  Measured null: a delay of 2-6 us neither costs nor gains anything,
+  // i.e. one wavefront per SIMD runs its latency-bound stream no faster when it has the matrix pipe to itself.
+  if (NW == 4 && a.phase_delay > 0 && wave == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if ((hw >> 16) & 1u) {
+      const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t_start < (uint64_t)a.phase_delay) __builtin_amdgcn_s_sleep(16);
     }
   }
   __syncthreads();
@@ -649,7 +663,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[6] = {0, 512, 256, 128, 64, 256};
+  const int rows[7] = {0, 512, 256, 128, 64, 256, 256};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
@@ -673,11 +687,14 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     const int64_t n1 = blocks(512, 128), rounds = (n1 + cus - 1) / cus;
     if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
-  if (force >= 1 && force <= 5 && a.M % rows[force] == 0) tile = force;
+  if (force >= 1 && force <= 6 && a.M % rows[force] == 0) tile = force;
+  static const int phase_delay = dev_env("VASR_PW_PHASE") ? atoi(dev_env("VASR_PW_PHASE")) : 0;   // 10 ns ticks (dev)
+  a.phase_delay = phase_delay;
   switch (tile) {
     case 1: return launch_t<8, 2, 4>(a, arith, st, amax_n);
     case 2: return launch_t<8, 1, 4>(a, arith, st, amax_n);
     case 5: return launch_t<8, 1, 2>(a, arith, st, amax_n);
+    case 6: return launch_t<4, 2, 4>(a, arith, st, amax_n);   // 256 x 128 on four wavefronts, two workgroups per CU (dev)
     // (256 x 128 on FOUR wavefronts, two workgroups per CU -- possible with the 64 KB of the two-plane arithmetics -- measured
     // slower than one 512 x 128 workgroup: 57.5 vs 54.6 us on a 512-channel layer; one wavefront per SIMD and workgroup does
     // not cover its own waits, and every workgroup converts the whole activation tile again)

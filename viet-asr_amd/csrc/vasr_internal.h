@@ -144,6 +144,7 @@ struct PwArgs {
   // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
   const int32_t* zero_from;
   int32_t busy_cus;       // compute units held by a concurrent kernel of the caller's (vasr_set_busy_cus); tile choice only
+  int32_t phase_delay;    // 4-wavefront tiles: ticks (10 ns) the second workgroup of a compute unit holds back (0 = off)
   // kF16x2 only: maxima tables of x / x2 (inputs) and 1 / (weight scale) of the fp16 pack
   AmaxTab amax_x;
   AmaxTab amax_x2;
