@@ -284,6 +284,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
     // ---- epilogue: BN affine + ReLU, rows transposed through the (now idle) producer windows into float4 stores ----
     const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
     unsigned ymax = 0;
+    const float relu_floor = (a.relu & 1) ? 0.f : -__builtin_inff();
     float* stage = reinterpret_cast<float*>(wins + wave * kWWave);   // 2 x 8 rows x 128 columns = 8 KB of 13 KB
     // every pass's BN scale / shift BEFORE the first store: stores count in vmcnt like loads, so a load issued between
     // two passes makes its consumer wait (vmcnt(0)) for every store before it -- eight store round trips in series
@@ -309,17 +310,20 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           for (int j = 0; j < 4; ++j)
             buf[(4 * kh + rr) * FBN + 32 * j + l31] = fmaf(acc[i][j][4 * q + rr] * out_scale, sc[rr], sh[rr]);
         wave_fence();
+        // straight-line pass (no uniform branch per piece: see encoder_pw_split.hip's epilogue): all row pieces requested
+        // together, ReLU as a maximum with a uniform floor
+        v4f pv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int f = lane + 64 * k, row = f / (FBN / 4), c4 = f % (FBN / 4);
-          v4f v = *reinterpret_cast<const v4f*>(buf + row * FBN + 4 * c4);
+          pv[k] = *reinterpret_cast<const v4f*>(buf + row * FBN + 4 * c4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int f = lane + 64 * k, row = f / (FBN / 4), c4 = f % (FBN / 4);
           const int m = mq + row, t = t0 + 4 * c4;
-          if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
-          if (!(VASR_FUSED_ABLATE & 4)) {
-            v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t);
-            if (a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) vasr_internal.h stream_stores
-            else *dstp = v;
-          }
+          const v4f v = __builtin_elementwise_max(pv[k], v4f{relu_floor, relu_floor, relu_floor, relu_floor});
+          if (!(VASR_FUSED_ABLATE & 4)) *reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t) = v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned u = abs_bits(v[e]);

@@ -507,6 +507,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
     const unsigned u = __float_as_uint(v) & 0x7fffffffu;
     ymax = (t < ylen && u > ymax) ? u : ymax;
   };
+  const float relu_floor = (a.relu & 1) ? 0.f : -__builtin_inff();   // max(v, floor): ReLU or nothing, without a branch
   const bool full = (t0 + BN <= a.store_cols) && (m0 + BM <= a.m_store);
   const bool vec = full && ((a.ldy | a.ldr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
   if (vec) {
@@ -551,20 +552,32 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
             buf[(4 * kh + rr) * BN + 32 * j + l31] = fmaf(v, sc[rr], sh[rr]);
           }
         wave_fence();
+        // The pass is straight-line code: all of its row pieces (and residual pieces) are requested together, the ReLU is a
+        // maximum with a uniform floor and the maxima are tracked unconditionally (ylen = 0 without a table).  With a
+        // uniform BRANCH per piece (relu / table / store kind) every piece was its own basic block -- LDS read, wait,
+        // arithmetic, store, branch -- and the pass paid one LDS round trip per piece in series.
+#ifndef VASR_PW_NT
+#define VASR_PW_NT 0   // dev: honour PwArgs::nt_store (measured: no gain -- off)
+#endif
+        v4f pv[F4], rv[F4];
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
           const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
-          v4f v = *reinterpret_cast<const v4f*>(buf + row * BN + 4 * c4);
-          const int m = mq + row, t = t0 + 4 * c4;
-          if (RES) v += *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m) * a.ldr + t);
-          if (a.relu & 1) v = __builtin_elementwise_max(v, v4f{0.f, 0.f, 0.f, 0.f});
-          v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t);
-          if (a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) output too large for the Infinity Cache: stream_stores
-          else *dstp = v;
-          if (a.amax_y.p) {
+          pv[k] = *reinterpret_cast<const v4f*>(buf + row * BN + 4 * c4);
+          if (RES) rv[k] = *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + mq + row) * a.ldr + t0 + 4 * c4);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) track(v[e], t + e);
-          }
+        for (int k = 0; k < F4; ++k) {
+          const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
+          const int m = mq + row, t = t0 + 4 * c4;
+          v4f v = pv[k];
+          if (RES) v += rv[k];
+          v = __builtin_elementwise_max(v, v4f{relu_floor, relu_floor, relu_floor, relu_floor});
+          v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t);
+          if (VASR_PW_NT && a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) stream_stores
+          else *dstp = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) track(v[e], t + e);
         }
       }
     }
