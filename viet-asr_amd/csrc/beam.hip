@@ -25,6 +25,9 @@
 // barriers (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() also waits for the back-pointer stores and the
 // log-prob prefetch), per-thread slots in registers between phases, and a loop body kept at 32 KB of code -- fully
 // unrolled it was 68 KB, more than the instruction cache two CUs share.  B = 64 x 501 frames, beam 128: 10.7 -> 4.0 ms.
+#include <cstdlib>
+#include <type_traits>
+
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -37,11 +40,10 @@ namespace {
 constexpr int kThreads = VASR_BEAM_THREADS;   // workgroup size: 256, 512 or 1024
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxBeams = 128;
-#ifndef VASR_BEAM_SLOTS
-#define VASR_BEAM_SLOTS 2048
-#endif
-constexpr int kSlots = VASR_BEAM_SLOTS;          // merge-table slots (a power of two, a multiple of the workgroup size)
-constexpr int kMaxFill = kSlots * 7 / 10;        // pairs per pass: the table stays <= 70 % full (1433 at 2048 slots)
+// Merge-table slots: a template parameter of the kernel (a power of two, a multiple of the workgroup size), chosen per
+// launch from the beam width -- clearing and sweeping the table is a fixed cost per frame, so a narrow beam is faster with a
+// small table and a wide one with few passes (launch_beam_search).  kMaxFill(slots) pairs per pass keep it <= 70 % full.
+constexpr int max_fill(int slots) { return slots * 7 / 10; }   // 1433 at 2048 slots
 constexpr int kMaxClasses = 128;
 constexpr int kMaxCtx = 4;      // LM order <= 5
 constexpr unsigned long long kFnvOffset = 1469598103934665603ull, kFnvPrime = 1099511628211ull;
@@ -79,7 +81,7 @@ struct Beam {
 struct Slots {
   unsigned long long* key; long long* mx; unsigned long long* sum; int* src;
 };
-constexpr size_t kSlotBytes = kSlots * (8 + 8 + 8 + 4);
+constexpr size_t slot_bytes(int slots) { return (size_t)slots * (8 + 8 + 8 + 4); }
 
 struct LmView {
   const unsigned long long* vkey; const int* vid; int vcap;
@@ -253,6 +255,7 @@ __device__ inline int block_scan_excl(int v, int* scratch, int* total, int& flip
 }
 
 // grid (B), block kThreads
+template <int kSlots>
 __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __restrict__ logp, int frames_ld,
                                                           const int32_t* __restrict__ row_frames, int V1,
                                                           int space_id, int beam_width, float token_min_logp,
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
                                                           unsigned long long* __restrict__ eoslog_all,
                                                           int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
                                                           float* __restrict__ out_score) {
+  constexpr int kMaxFill = max_fill(kSlots);
+  constexpr size_t kSlotBytes = slot_bytes(kSlots);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Slots sl;
   sl.key = reinterpret_cast<unsigned long long*>(smem);
@@ -742,9 +747,18 @@ __global__ __launch_bounds__(kThreads) void beam_search_kernel(const float* __re
 
 }  // namespace
 
-size_t beam_lds_bytes() {
-  return kSlotBytes + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 16 + 2 * kWaves) + 16 +
-         (8 + 8 + 4 + 4 + 4) * kMaxBeams + 8 * kSlots + 2 * (kMaxFill + 2) + 16;
+size_t beam_lds_bytes(int slots) {
+  return slot_bytes(slots) + sizeof(Beam) * 2 * kMaxBeams + sizeof(double) * kMaxClasses + sizeof(int) * (kMaxClasses + 256 + 16 + 2 * kWaves) + 16 +
+         (8 + 8 + 4 + 4 + 4) * kMaxBeams + 8 * slots + 2 * (max_fill(slots) + 2) + 16;
+}
+
+// Measured (MI355X, 64 x 501 frames, tools/gpu_beamslots.sh): CTC-like posteriors, beam 20 / 50 / 100 / 128:
+// 2.22 / 2.56 / 3.55 / 4.34 ms at 1024 slots, 2.63 / 2.99 / 3.83 / 4.50 at 2048; peaked ones 2.90 / 3.45 / 5.63 / 7.20 against
+// 3.43 / 3.91 / 5.20 / 6.28.  (512 slots: another 5-7 % at beam <= 20, but 1.5x slower there on flat posteriors.)
+int beam_slots_for(int beam_width) {
+  static const int forced = dev_env("VASR_BEAM_SLOTS") ? atoi(dev_env("VASR_BEAM_SLOTS")) : 0;
+  if (forced == 1024 || forced == 2048) return forced;
+  return beam_width > 64 ? 2048 : 1024;
 }
 
 int launch_beam_search(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
@@ -760,13 +774,18 @@ int launch_beam_search(const float* logp, int batch, int frames, int V1, int spa
     v.nval = reinterpret_cast<const float2*>(lm->nval); v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
     v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
   }
-  const size_t lds = beam_lds_bytes();
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)beam_lds_bytes());
-  if (attr != hipSuccess) return (int)attr;
-  hipLaunchKernelGGL(beam_search_kernel, dim3(batch), dim3(kThreads), lds, st, logp, frames, row_frames, V1, space_id,
-                     beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len, out_score);
-  return 0;
+  auto go = [&](auto slots_tag) -> int {
+    constexpr int slots = decltype(slots_tag)::value;
+    auto kern = beam_search_kernel<slots>;
+    const size_t lds = beam_lds_bytes(slots);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(kThreads), lds, st, logp, frames, row_frames, V1, space_id, beam_width,
+                       token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len, out_score);
+    return 0;
+  };
+  if (beam_slots_for(beam_width) == 1024) return go(std::integral_constant<int, 1024>{});
+  return go(std::integral_constant<int, 2048>{});
 }
 
 unsigned long long beam_hash_step(unsigned long long h, unsigned long long v) { return hmix(h, v); }
