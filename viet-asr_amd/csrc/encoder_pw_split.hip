@@ -500,6 +500,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
 #endif
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
   if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
+  if (a.relu & 4) {        // debug: the second workgroup of a compute unit skips it (is the epilogue bandwidth- or latency-bound?)
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if ((hw >> 16) & 1u) return;
+  }
   // max |y| over the utterance's VALID output frames, for the split of the next kF16x2 consumer of y
   const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
   unsigned ymax = 0;

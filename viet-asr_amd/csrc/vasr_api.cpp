@@ -1282,7 +1282,7 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   PwArgs a{};
   a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
   launch_pointwise(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise");
 }
@@ -1323,7 +1323,7 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w16); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
   a.amax_x = ax; a.w_inv_scale = w_inv_scale;
   a.amax_y = AmaxTab{d_amax + (size_t)batch * amax_stride, amax_stride, 0};   // second table: maxima of y
   int n_y = 0;
@@ -1347,7 +1347,7 @@ int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const fl
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = dev_env("VASR_DEBUG_NO_EPILOGUE") ? 3 : 1;
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
   const int e = launch_pointwise_split(a, dev_env("VASR_BENCH_BF16X2") ? 1 : 0, static_cast<hipStream_t>(stream));
   if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
   return check_launch("bench_pointwise_bf16x3");
