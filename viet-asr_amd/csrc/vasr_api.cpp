@@ -1339,6 +1339,29 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   return check_launch("bench_pointwise_f16x2");
 }
 
+int vasr_pack_p4(const float* h_x, int rows, int64_t ld, float scale, uint16_t* h_out) {
+  if (!h_x || !h_out || rows <= 0 || ld <= 0 || ld % 4) return fail(VASR_ERR_INVALID, "bad argument");
+  pack_p4_reference(h_x, rows, ld, scale, h_out);
+  return 0;
+}
+
+int vasr_bench_pointwise_p4(const uint16_t* d_x_p4, const float* d_x_inv, const uint16_t* d_w16, float w_inv_scale,
+                            const float* d_scale, const float* d_shift, int batch, int cin, int cout, int64_t frames,
+                            float* d_y, uint32_t* d_amax_y, int amax_stride, vasr_stream stream) {
+  if (!d_x_p4 || !d_x_inv || !d_w16 || !d_scale || !d_shift || !d_y) return fail(VASR_ERR_INVALID, "bad argument");
+  const int64_t ld = pad_frames(frames);
+  PwP4Args a{};
+  a.wt = reinterpret_cast<const uint4*>(d_w16); a.x = reinterpret_cast<const uint4*>(d_x_p4); a.x_inv_scale = d_x_inv;
+  a.scale = d_scale; a.shift = d_shift; a.y = d_y; a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld;
+  a.frames = (int)frames; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? 2 : 0); a.w_inv_scale = w_inv_scale;
+  if (d_amax_y) a.amax_y = AmaxTab{d_amax_y, amax_stride, 0};
+  int n_y = 0;
+  const int e = launch_pointwise_p4(a, static_cast<hipStream_t>(stream), &n_y);
+  if (e < 0) return fail(VASR_ERR_UNSUPPORTED, "shape not covered by the pre-split GEMM");
+  if (e) return fail(VASR_ERR_HIP, "pointwise GEMM (P4): %s", hipGetErrorString((hipError_t)e));
+  return check_launch("bench_pointwise_p4");
+}
+
 int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
                                 int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream) {
   if (!d_x || !d_w3 || !d_scale || !d_shift || !d_y || !pointwise_split_supported(cout, cin, 0))

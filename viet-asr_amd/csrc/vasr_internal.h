@@ -172,6 +172,26 @@ float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad,
 void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, AmaxTab* amax,
                  hipStream_t st);
 
+// ---- 1x1 conv on pre-split ("P4") activations (encoder_pw_p4.hip) ----
+// P4 tensor: same pitch as the fp32 tensor, row (b, c) = ld / 4 groups of 16 bytes: frames 4 g .. 4 g + 3 as
+// [4 x fp16 hi | 4 x fp16 lo] of scale_b * x (halves swapped on channels with c & 2); 1 / scale_b in a [B] float table.
+struct PwP4Args {
+  const uint4* wt;            // f16x2 fragment pack (pack_pointwise_weights_f16x2)
+  const uint4* x;             // [B][K][ldx / 4] groups
+  const float* x_inv_scale;   // [B]
+  const float* scale; const float* shift;   // [M] folded BN
+  float* y;                   // [B][M][ldy] fp32
+  int32_t M, K, batch;
+  int64_t ldx, ldy;
+  int32_t frames, relu;
+  const int32_t* zero_from;   // as PwArgs
+  float w_inv_scale;
+  AmaxTab amax_y; const int32_t* lens_y;
+};
+bool pointwise_p4_supported(int M, int K, int64_t ldx, int64_t ldy);
+int launch_pointwise_p4(const PwP4Args& a, hipStream_t st, int* amax_n);   // 0, a hipError_t, or -1 (shape not covered)
+void pack_p4_reference(const float* x, int rows, int64_t ld, float scale, unsigned short* out);   // host restatement of the layout
+
 // ---- fused depthwise + pointwise sub-block, 256 channels (encoder_fused.hip) ----
 struct FusedLaunch {
   const float* x; int64_t ldx;                 // [B][256][ldx] depthwise input
