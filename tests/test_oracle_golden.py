@@ -86,3 +86,22 @@ def test_ctc_collapse_rules():
     assert O.ctc_collapse_ids([], blank) == []
     assert O.ctc_collapse_ids([0, 0, 0], blank) == [0]
     assert O.ctc_decode_strings(np.array([[0, 1, 1, 2, 0, 2]]), ["a", "b"]) == ["aba"]
+
+
+def test_mel_filterbank_against_the_values_librosa_documents():
+    """A4 (librosa.filters.mel, third party, absent here) has no fixture in the reference; the only published numbers are
+    the two arrays printed in librosa's own documentation of filters.mel (cited from memory of the public docs, to the two
+    significant digits they print): mel(sr=22050, n_fft=2048)[0, 1] = 0.016 and, with fmax=8000, 0.02; both first columns
+    and the last columns are 0.  A weak pin -- it fixes the Slaney scale, the area normalisation and the bin grid, not the
+    last bits -- and the restatement the library ships (frontend_tables) must equal the oracle's bit for bit."""
+    from viet_asr_amd import frontend_tables as F
+    m = np.asarray(O.slaney_mel_filterbank(sr=22050, n_fft=2048, n_mels=128))
+    assert m.shape == (128, 1025) and m.dtype == np.float32
+    assert round(float(m[0, 1]), 3) == 0.016 and m[0, 0] == 0 and m[0, -1] == 0 and m[-1, 0] == 0 and m[-1, -1] == 0
+    m8 = np.asarray(O.slaney_mel_filterbank(sr=22050, n_fft=2048, n_mels=128, fmax=8000))
+    assert round(float(m8[0, 1]), 2) == 0.02 and not m8[:, 800:].any()          # nothing above 8 kHz (bin 743)
+    # Slaney area normalisation: every triangle integrates to ~1 over its band in Hz (2 / (f[i+2] - f[i]) peak scaling)
+    hz_per_bin = 22050 / 2048
+    assert np.allclose(m.sum(axis=1) * hz_per_bin, 1.0, atol=0.06)
+    assert np.array_equal(np.asarray(F.mel_filterbank(sr=22050, n_fft=2048, n_mels=128)), m)
+    assert np.array_equal(np.asarray(F.mel_filterbank()), np.asarray(O.slaney_mel_filterbank()))
