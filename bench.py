@@ -23,7 +23,9 @@ Workloads (BASELINE.json `configs`, 0-based):
                                     lengths in [15 s, 30 s] and deals them to the ranks with dist.balanced_shards.
 
 The default invocation (config 3, N = 1) also runs 5 steps each of configs 2, 4 and 5 after the headline and adds them
-as "configs": {"2": {...}, "4": {...}, "5": {...}} to the SAME JSON line, and a "latency" block (batch 1 / 8).
+as "configs": {"2": {...}, "3r": {...}, "4": {...}, "5": {...}} to the SAME JSON line ("3r" = the headline shape with ragged
+lengths U[L/2, L]), a "latency" block (batch 1 / 8 of 15x5, and the reference's own serving shape: batch 1, 12x1_vi, beam
+50 / 100 + LM, split into acoustic pass and search) and a "sol" block (speed-of-light floors of the headline step).
 
 `python bench.py --gpus N` with N > 1 starts its own N ranks (re-executes itself under torch.distributed.run on a free
 port of 127.0.0.1); launched by torchrun / the driver it uses the ranks it is given.  One process per GPU, backend
@@ -206,7 +208,7 @@ _LM = {}
 
 def beam_decoder_for(cfg, no_lm, seed=3):
     from viet_asr_amd.beam import BeamSearchDecoder
-    key = bool(no_lm)
+    key = (bool(no_lm), len(cfg["labels"]))
     if key not in _LM:
         lm_path = None
         if not no_lm:        # every rank writes its own copy (deterministic, < 1 s)
@@ -245,12 +247,13 @@ def class_rates(prof, steps, gemm):
                 fu_gbs=(prof["fused"]["bytes"] / steps / (fu_ms * 1e-3) / 1e9 if fu_ms else 0.0))
 
 
-def side_workload(cfg_id, dev, gemm, steps, warmup, a):
+def side_workload(cfg_id, dev, gemm, steps, warmup, a, ragged=False):
     """One of the other BASELINE workloads, short: timed steps + the per-class pass; the compact record that goes under
-    "configs" in the default line."""
+    "configs" in the default line.  ragged: SURVEY section 8(d)'s ragged variant -- lengths uniform in [L/2, L], zero-padded to
+    the longest row like the reference's collate (parts/dataset.py:14-53); value counts the REAL audio seconds."""
     model, batch, seconds, rate, decoder = WORKLOADS[cfg_id]
     cfg, eng = engine_for(model, dev, gemm)
-    sig, lens = synth.audio_batch(batch, int(seconds * rate), 3, ragged=False)
+    sig, lens = synth.audio_batch(batch, int(seconds * rate), 3, ragged=ragged)
     wav_in, ln_in = torch.from_numpy(sig).to(dev), torch.from_numpy(lens).to(dev)
     if rate != 16000:
         from viet_asr_amd import audio
@@ -285,7 +288,8 @@ def side_workload(cfg_id, dev, gemm, steps, warmup, a):
     torch.cuda.synchronize()
     cr = class_rates(eng.handle.profile_end(), steps, gemm)
     audio_s = float(lens.sum()) / rate
-    out = {"workload": f"BASELINE configs[{cfg_id - 1}]: {model} {decoder}, batch={batch}x{seconds:g}s {rate // 1000}kHz",
+    out = {"workload": f"BASELINE configs[{cfg_id - 1}]: {model} {decoder}, batch={batch}x{seconds:g}s {rate // 1000}kHz"
+                       + (" with ragged lengths U[L/2, L], zero-padded to the longest row" if ragged else ""),
            "steps": steps, "value": round(audio_s * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "utts_per_sec": round(batch * steps / dt, 1),
            "roofline": {"frac": round(cr["exec_tflops"] / cr["peak"], 4), "achieved": round(cr["exec_tflops"], 1),
@@ -294,31 +298,144 @@ def side_workload(cfg_id, dev, gemm, steps, warmup, a):
            "depthwise": {"frac": round(cr["dw_gbs"] / PEAK_HBM_GBS, 4), "frac_of_achievable": round(cr["dw_gbs"] / ACHIEVABLE_HBM_GBS, 4),
                          "achieved": round(cr["dw_gbs"], 1), "ms_per_step": round(cr["dw_ms"], 3)},
            "fused_ms_per_step": round(cr["fu_ms"], 3)}
+    if ragged:
+        # padded-work efficiency of the padded batch the reference's collate builds: real frames / (rows x longest row)
+        out["padded_work_efficiency"] = round(float(lens.sum()) / (batch * float(lens.max())), 4)
+        out["value_note"] = "real audio-seconds (sum of the rows' own lengths) per wall-second; the kernels run the padded batch"
     if decoder == "beam":
         out["beam_width"], out["lm"] = a.beam_width, lm_info
+        lp = eng.forward(wav16, ln16, want_logp=True, want_pred=False)["logp"]
+        ms_beam = timed_ms(lambda: beam_dec.decode_ids(lp, a.beam_width), 3)
+        ms_ac = timed_ms(lambda: eng.forward(wav16, ln16, want_logp=True, want_pred=False), 3)
+        # a job's LAST batch has no following acoustic pass to hide its search under
+        out["beam"] = {"search_ms_per_batch_alone": round(ms_beam, 3), "acoustic_ms_per_batch_alone": round(ms_ac, 3),
+                       "last_batch_tail_ms": round(max(0.0, ms_beam + ms_ac - out["ms_per_step"]), 3)}
     del wav_in, wav16
     return out
 
 
-def latency_block(dev, gemm):
-    """Small-batch latency of the whole path (wav in HBM -> collapsed ids on the device, synchronised per call): the
-    reference serves batch 1 (infer.py:167-171, app.py:66-67).  Median of 30 calls after 5 warm-ups."""
+def timed_ms(fn, n):
+    """Mean milliseconds of n back-to-back calls on the current stream (one untimed call first)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def sync_latency_ms(fn, n=30, warm=5):
+    """Median wall milliseconds of one synchronised call (host launch overhead included)."""
+    ts = []
+    for i in range(n + warm):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if i >= warm:
+            ts.append(time.perf_counter() - t0)
+    return round(float(np.median(ts)) * 1e3, 3)
+
+
+def latency_block(dev, gemm, a):
+    """Small-batch latency of the whole path (wav in HBM -> collapsed ids / best hypothesis on the device, synchronised per
+    call).  The reference serves exactly this shape: batch 1, QuartzNet12x1 with the Vietnamese head, beam search with the
+    3-gram LM at width 100 (CLI, infer.py:181-192) or 50 (app.py:22-28, 66-67) -- the `vi12x1_b1_*` entries, each split into
+    the acoustic pass and the search.  Median of 30 calls after 5 warm-ups."""
     cfg, eng = engine_for("quartznet15x5", dev, gemm)
     out = {}
     for name, b, seconds in (("b1_10s_ms", 1, 10.0), ("b1_2s_ms", 1, 2.0), ("b8_10s_ms", 8, 10.0)):
         sig, lens = synth.audio_batch(b, int(seconds * 16000), 5, ragged=False)
         wav, ln = torch.from_numpy(sig).to(dev), torch.from_numpy(lens).to(dev)
-        ts = []
-        for i in range(35):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.forward(wav, ln, want_logp=False, want_pred=False)
-            torch.cuda.synchronize()
-            if i >= 5:
-                ts.append(time.perf_counter() - t0)
-        out[name] = round(float(np.median(ts)) * 1e3, 3)
+        out[name] = sync_latency_ms(lambda: eng.forward(wav, ln, want_logp=False, want_pred=False))
     out["note"] = "quartznet15x5 greedy, one synchronised call per measurement (host launch overhead included), median of 30"
+    # ---- the reference's own serving shape ----
+    vcfg, veng = engine_for("quartznet12x1_vi", dev, gemm)
+    dec, lm_path, lm_info = beam_decoder_for(vcfg, a.no_lm)
+    words = None
+    if lm_path:
+        from viet_asr_amd.beam import read_arpa
+        words = sorted(w[0] for w in read_arpa(lm_path)[1] if len(w) == 1 and not w[0].startswith("<"))
+    vi = {"model": "quartznet12x1_vi (91 classes incl. blank), batch 1", "lm": lm_info,
+          "note": "greedy_ms = wav -> collapsed ids; beamW_lm_ms = wav -> log-probs -> beam search (width W, 3-gram LM, alpha 0.5, "
+                  "beta 1.5) -> best hypothesis, serial on one stream as a batch-1 server runs it; acoustic_ms = the log-prob "
+                  "pass alone; search_ms = the search alone on this model's posteriors (a random-weight model is nearly "
+                  "deterministic) and on CTC-like posteriors of the same shape that spell words of the LM (beams branch and "
+                  "merge, the LM re-ranks at word boundaries)"}
+    for seconds in (2.0, 6.6, 10.0):
+        tag = f"vi12x1_b1_{seconds:g}s"
+        sig, lens = synth.audio_batch(1, int(seconds * 16000), 5, ragged=False)
+        wav, ln = torch.from_numpy(sig).to(dev), torch.from_numpy(lens).to(dev)
+        e = {"greedy_ms": sync_latency_ms(lambda: veng.forward(wav, ln, want_logp=False, want_pred=False)),
+             "acoustic_ms": sync_latency_ms(lambda: veng.forward(wav, ln, want_logp=True, want_pred=False))}
+        lp = veng.forward(wav, ln, want_logp=True, want_pred=False)["logp"]
+        lp_ctc = None
+        if words:
+            lp_ctc = torch.from_numpy(synth.ctc_like_log_probs(1, lp.shape[1], vcfg["labels"], words, seed=5)).to(dev)
+        for width in (50, 100):
+            e[f"beam{width}_lm_ms"] = sync_latency_ms(
+                lambda: dec.decode_ids(veng.forward(wav, ln, want_logp=True, want_pred=False)["logp"], width))
+            e[f"beam{width}_search_ms"] = sync_latency_ms(lambda: dec.decode_ids(lp, width))
+            if lp_ctc is not None:
+                e[f"beam{width}_search_ctc_like_ms"] = sync_latency_ms(lambda: dec.decode_ids(lp_ctc, width))
+        vi[tag] = e
+    out["vi12x1_b1"] = vi
     return out
+
+
+def model_traffic_bytes(jas, feat_in, classes, batch, T):
+    """Algorithmic HBM bytes of one pass of the encoder + head over [batch, feat_in, T] fp32, two ways:
+    `unfused` -- every layer reads its input and writes its output (depthwise, 1x1 conv with the residual folded in as a
+    second source, head), weights once; `fused` -- every depthwise + 1x1 sub-block as ONE kernel (the depthwise output
+    never leaves the CU) and the CTC head + log-softmax + argmax folded into the last GEMM's consumer."""
+    unf = fus = w = 0.0
+    c, t = feat_in, T
+    for blk in jas:
+        k = blk["kernel"][0] if isinstance(blk["kernel"], (list, tuple)) else blk["kernel"]
+        stride = blk["stride"][0] if isinstance(blk["stride"], (list, tuple)) else blk["stride"]
+        cin_blk, t_blk = c, t
+        for r in range(blk["repeat"]):
+            last = r + 1 == blk["repeat"]
+            res = blk.get("residual", False) and last
+            to = (t - 1) // stride + 1 if stride > 1 else t
+            if blk.get("separable", False):
+                unf += 4.0 * batch * (c * t + c * to)                      # depthwise: read x, write d
+                w += 4.0 * c * k
+            unf += 4.0 * batch * (c * to + blk["filters"] * to + (cin_blk * t_blk if res else 0))   # 1x1 conv (+ residual source)
+            fus += 4.0 * batch * (c * t + blk["filters"] * to + (cin_blk * t_blk if res else 0))
+            w += 4.0 * c * blk["filters"] + (4.0 * cin_blk * blk["filters"] if res else 0)
+            c, t = blk["filters"], to
+    unf += 4.0 * batch * (c * t + classes * t) + 4.0 * batch * classes * t * 2     # head GEMM, log-softmax
+    fus += 4.0 * batch * c * t + 8.0 * batch * t
+    w += 4.0 * c * classes
+    return unf + w, fus + w
+
+
+def sol_block(cfg, work, batch, samples, step_ms, launches_b1):
+    """Speed-of-light table of the headline step, so that the measured step can be read against its floors without redoing
+    the arithmetic.  MFMA floor: 3 fp16 products per multiply at the nominal 2.5 PFLOP/s and at the
+    ~1.75 PFLOP/s the part sustains under dense MFMA load (power-limited: DESIGN section 4, profiles/r02_clock_probe.txt
+    1.83 PF bare stream, 1.66 PF with realistic operands).  HBM floors at the guide's achievable 6.3 TB/s."""
+    jas = cfg["JasperEncoder"]["jasper"]
+    T = 1 + samples // 160
+    unf, fus = model_traffic_bytes(jas, 64, len(cfg["labels"]) + 1, batch, T)
+    unf += 4.0 * batch * samples + 4.0 * batch * 64 * T * 3        # front end: wav in, mel out, normalise read + write
+    fus += 4.0 * batch * samples + 4.0 * batch * 64 * T
+    exec_flops = 3.0 * (work["pointwise_flops"] + work["decoder_flops"])
+    return {"step_ms_measured": round(step_ms, 3),
+            "mfma_floor_ms_at_2500_tflops": round(exec_flops / 2.5e15 * 1e3, 3),
+            "mfma_floor_ms_at_sustained_1750_tflops": round(exec_flops / 1.75e15 * 1e3, 3),
+            "hbm_floor_ms_unfused_graph_at_6300_gbs": round(unf / 6.3e12 * 1e3, 3),
+            "hbm_floor_ms_fully_fused_graph_at_6300_gbs": round(fus / 6.3e12 * 1e3, 3),
+            "bytes_unfused_graph": unf, "bytes_fully_fused_graph": fus, "executed_mfma_flops": exec_flops,
+            "b1_launches": launches_b1,
+            "b1_launch_floor_ms": round(launches_b1 * 1.45e-3, 3) if launches_b1 else None,
+            "step_over_mfma_floor_sustained": round(step_ms / (exec_flops / 1.75e15 * 1e3), 2),
+            "note": "floors are not additive (MFMA and HBM phases can overlap); b1_launch_floor = launches of a batch-1 call x the "
+                    "1.45 us dependent-kernel boundary of MI355X_MICROARCH.md's price list"}
 
 
 def main():
@@ -678,14 +795,27 @@ def main():
             out["other_gemm_arithmetic"] = other
         if headline and world == 1 and not a.no_side_configs:
             side = {}
-            for cid in (2, 4, 5):
+            for key, cid, rag in (("2", 2, False), ("3r", 3, True), ("4", 4, False), ("5", 5, False)):
                 try:
-                    side[str(cid)] = side_workload(cid, dev, gemm, 5, 2, a)
+                    side[key] = side_workload(cid, dev, gemm, 5, 2, a, ragged=rag)
                 except Exception as e:  # noqa: BLE001 -- a side workload must not take the headline line down
-                    side[str(cid)] = {"error": repr(e)[:200]}
+                    side[key] = {"error": repr(e)[:200]}
                 torch.cuda.empty_cache()
             out["configs"] = side
-            out["latency"] = latency_block(dev, gemm)
+            try:
+                out["latency"] = latency_block(dev, gemm, a)
+            except Exception as e:  # noqa: BLE001
+                out["latency"] = {"error": repr(e)[:300]}
+            # launches of a batch-1 call of the headline model (per-class pass of one call)
+            sig1, len1 = synth.audio_batch(1, samples, 5, ragged=False)
+            w1, l1 = torch.from_numpy(sig1).to(dev), torch.from_numpy(len1).to(dev)
+            eng.handle.profile_begin()
+            eng.forward(w1, l1, want_logp=False, want_pred=False)
+            torch.cuda.synchronize()
+            p1 = eng.handle.profile_end()
+            # front end = 3 launches, head = GEMM + log-softmax/argmax + collapse, + the length chain
+            launches_b1 = sum(p1[k]["launches"] for k in ("depthwise", "pointwise", "fused")) + 3 + 3 + 1
+            out["sol"] = sol_block(cfg, work, batch, samples, elapsed / a.steps * 1e3, launches_b1)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, seed, decoder, lm_path)
         if dist is not None:
