@@ -541,36 +541,22 @@ def main():
             return p[0], p[1]
         return audio.resample(p[0], p[1], rate, 16000)
 
-    gathered, inflight, n_calls = {}, [None, None], 0
-
-    def drain(slot):
-        if inflight[slot] is not None:
-            for w in inflight[slot][:2]:
-                w.wait()
-            inflight[slot] = None
+    ring = None
+    if dist is not None:
+        from viet_asr_amd import dist as vdist
+        ring = vdist.AsyncIdGather(world, dev)      # double-buffered async all_gather_into_tensor (viet-asr_amd/dist.py)
 
     def one_pass(p):
-        nonlocal n_calls
         wav, ln = acoustic_input(p)
         if decoder == "beam":
             r = eng.forward_beam(wav, ln, beam_dec, a.beam_width, overlap=not a.no_overlap)
         else:
             r = eng.forward(wav, ln, want_logp=False, want_pred=False)
-        if dist is not None and not (job and a.ragged):
-            # Result gather, one collective per returned tensor like actions.py:774-807.  Issued asynchronously on
-            # RCCL's own stream into one of two buffers: the next batch's kernels do not wait for the other ranks, a
-            # buffer is reused only after its previous gather has been waited for, and sync() drains both.
-            shape = tuple(r["ids"].shape)
-            if shape not in gathered:
-                gathered[shape] = [(torch.empty((world,) + shape, dtype=torch.int32, device=dev),
-                                    torch.empty((world, shape[0]), dtype=torch.int32, device=dev)) for _ in range(2)]
-            slot = n_calls % 2
-            n_calls += 1
-            drain(slot)
+        if ring is not None and not (job and a.ragged):
+            # Result gather, one collective per returned tensor like actions.py:774-807, asynchronous and double-buffered
             if r.get("done") is not None:
                 torch.cuda.current_stream().wait_event(r["done"])     # the gather reads what the side stream wrote
-            inflight[slot] = (dist.all_gather_into_tensor(gathered[shape][slot][0], r["ids"], async_op=True),
-                              dist.all_gather_into_tensor(gathered[shape][slot][1], r["id_len"], async_op=True), r, shape, slot)
+            ring.submit(r["ids"], r["id_len"])
         return r
 
     def step():
@@ -590,8 +576,7 @@ def main():
 
     def sync():
         if dist is not None:
-            drain(0)
-            drain(1)
+            ring.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -608,8 +593,7 @@ def main():
     rccl = None
     if dist is not None:
         if not (job and a.ragged):
-            last = (n_calls - 1) % 2       # the gathered copy of this rank's last batch must be what the engine returned
-            g = gathered[tuple(r["ids"].shape)][last]
+            g = ring.last()                # the gathered copy of this rank's last batch must be what the engine returned
             if not (torch.equal(g[0][rank], r["ids"]) and torch.equal(g[1][rank], r["id_len"])):
                 raise RuntimeError("result gather returned something else than this rank's own shard at its index")
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -24,6 +24,18 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the functions marked VASR_API are its ONLY dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#define VASR_API __attribute__((visibility("default")))
+#else
+#define VASR_API
+#endif
+
+/* Binary interface number of this header; vasr_abi_version() returns the one the library was built from.  Bumped whenever
+ * a signature or struct layout changes (4: vasr_profile_end reports five kernel classes with flops / bytes per class --
+ * a caller built against the four-class form would be written past its arrays). */
+#define VASR_ABI_VERSION 4
+
 typedef struct vasr_handle vasr_handle;
 typedef void* vasr_stream; /* hipStream_t */
 
@@ -74,29 +86,29 @@ typedef struct {
 } vasr_model_desc;
 
 /* ---- life cycle ------------------------------------------------------------------- */
-int vasr_create(const vasr_model_desc* desc, vasr_handle** out);
-void vasr_destroy(vasr_handle* h);
+VASR_API int vasr_create(const vasr_model_desc* desc, vasr_handle** out);
+VASR_API void vasr_destroy(vasr_handle* h);
 
 /* Replaces TrainableNM.restore_from -> load_state_dict (nemo/backends/pytorch/nm.py:97-103):
  * feed every float tensor of the module state_dict under its reference key, e.g.
  * "encoder.3.mconv.1.conv.weight", "encoder.3.mconv.2.running_var",
  * "encoder.3.res.0.0.conv.weight", "decoder_layers.0.bias".
  * Keys ending in "num_batches_tracked" are accepted and ignored. */
-int vasr_load_weight(vasr_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim);
+VASR_API int vasr_load_weight(vasr_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim);
 
 /* Checks that every tensor arrived, folds eval-mode BatchNorm1d(eps=1e-3)
  * (parts/jasper.py:392) into per-channel (scale, shift), packs the 1x1-conv weights
  * K-major for the MFMA kernels and uploads everything.  Needed before any compute call. */
-int vasr_finalize(vasr_handle* h);
+VASR_API int vasr_finalize(vasr_handle* h);
 
 /* ---- shapes ------------------------------------------------------------------------ */
 /* T = 1 + L / hop (torch.stft center=True, parts/features.py:181-188). */
-int64_t vasr_mel_frames(const vasr_handle* h, int64_t samples);
+VASR_API int64_t vasr_mel_frames(const vasr_handle* h, int64_t samples);
 /* T' after every strided block: floor((T + 2p - d(K-1) - 1)/s) + 1 (parts/jasper.py:108-111). */
-int64_t vasr_encoded_frames(const vasr_handle* h, int64_t mel_frames);
+VASR_API int64_t vasr_encoded_frames(const vasr_handle* h, int64_t mel_frames);
 /* Scratch needed by vasr_encoder_f32 / vasr_decoder_* / vasr_transcribe_greedy_f32 for a
  * batch of B utterances padded to `samples` (or, if samples == 0, to mel_frames). */
-size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, int64_t mel_frames);
+VASR_API size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, int64_t mel_frames);
 
 /* ---- the path, stage by stage (each = one NeuralModule forward) ---------------------- */
 
@@ -104,30 +116,30 @@ size_t vasr_workspace_bytes(const vasr_handle* h, int batch, int64_t samples, in
  * (audio_preprocessing.py:78-87, parts/features.py:245-301).
  *   d_wav [B][L] f32 (rows zero padded), d_len [B] i64
  *   -> d_mel [B][n_mels][T] f32 contiguous, d_seq [B] i64 = ceil(len/hop) */
-int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+VASR_API int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
                      float* d_mel, int64_t* d_seq, vasr_stream stream);
 
 /* JasperEncoder.forward (jasper.py:198-204; JasperBlock.forward parts/jasper.py:408-448;
  * MaskedConv1d.forward parts/jasper.py:113-132).
  *   d_mel [B][feat_in][T] f32 contiguous, d_seq [B] i64
  *   -> d_enc [B][C_last][T'] f32 contiguous, d_enc_len [B] f32 (quirk Q3: float lengths) */
-int vasr_encoder_f32(vasr_handle* h, const float* d_mel, const int64_t* d_seq, int batch, int64_t mel_frames,
+VASR_API int vasr_encoder_f32(vasr_handle* h, const float* d_mel, const int64_t* d_seq, int batch, int64_t mel_frames,
                      float* d_enc, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                      vasr_stream stream);
 
 /* JasperDecoderForCTC.forward (jasper.py:253-254): conv1x1+bias -> transpose -> log_softmax.
  *   d_enc [B][dec_feat_in][T'] f32 contiguous -> d_logp [B][T'][V+1] f32 */
-int vasr_decoder_logsoftmax_f32(vasr_handle* h, const float* d_enc, int batch, int64_t enc_frames,
+VASR_API int vasr_decoder_logsoftmax_f32(vasr_handle* h, const float* d_enc, int batch, int64_t enc_frames,
                                 float* d_logp, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
 
 /* GreedyCTCDecoder.forward (greedy_ctc_decoder.py:33-36): argmax(-1), first max wins.
  *   d_logp [B][T'][V+1] f32 -> d_pred [B][T'] i64 */
-int vasr_greedy_argmax(const float* d_logp, int batch, int64_t frames, int num_classes, int64_t* d_pred,
+VASR_API int vasr_greedy_argmax(const float* d_logp, int batch, int64_t frames, int num_classes, int64_t* d_pred,
                        vasr_stream stream);
 
 /* __ctc_decoder_predictions_tensor inner loop (helpers.py:20-31): drop repeats and blanks over
  * ALL frames (quirk Q4).  d_pred [B][T'] i64 -> d_ids [B][T'] i32 (compacted), d_id_len [B] i32 */
-int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blank_id, int32_t* d_ids,
+VASR_API int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blank_id, int32_t* d_ids,
                       int32_t* d_id_len, vasr_stream stream);
 
 /* ---- the whole path in one call (the fast path bench.py times) ------------------------ */
@@ -136,7 +148,7 @@ int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blan
  *   d_pred   [B][T'] i64  (may be NULL)          d_ids [B][T'] i32, d_id_len [B] i32
  *   d_logp   [B][T'][V+1] f32 (may be NULL: greedy only needs the argmax)
  *   d_enc_len [B] f32 (may be NULL) */
-int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch,
+VASR_API int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch,
                                int64_t samples, int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len,
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
@@ -167,18 +179,18 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
  *                vasr_set_row_independent (which never fuses), not by the default mode.
  * Layers whose shape the split kernel does not cover keep mode 0.
  * The environment variable VASR_GEMM=fp32 / bf16x3 / bf16x2 / f16x2 sets the initial mode of new handles. */
-int vasr_set_gemm_mode(vasr_handle* h, int mode);
-int vasr_get_gemm_mode(const vasr_handle* h);
+VASR_API int vasr_set_gemm_mode(vasr_handle* h, int mode);
+VASR_API int vasr_get_gemm_mode(const vasr_handle* h);
 
 /* ---- audio ingest (callers of the path: infer.py:200 librosa.load(sr=16000); parts/segment.py:19-32,61-74) ---- */
 /* int16 PCM -> float32 scaled by 2^-15 (AudioSegment._convert_samples_to_float32). n = total samples. */
-int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream);
+VASR_API int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream);
 /* Band-limited sample-rate conversion of a zero-padded batch (interpolated windowed-sinc, the scheme of resampy's
  * kaiser_best that librosa.load uses by default; third-party => parity unpinned).  d_table = [nwin][2] floats
  * (window value, delta to the next entry) with num_table entries per zero crossing, built on the host
  * (viet-asr_amd/audio.py::sinc_table); ratio = sr_out / sr_in; d_len_out[b] = int(d_len_in[b] * ratio);
  * rows of d_out are zero past that length.  ld_out >= max output length. */
-int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in, int batch, const float* d_table,
+VASR_API int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in, int batch, const float* d_table,
                       int nwin, int num_table, double ratio, float* d_out, int64_t ld_out, int64_t* d_len_out,
                       vasr_stream stream);
 
@@ -186,7 +198,7 @@ int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in,
  * measured slower: 11.7 -> 13.5 ms at 2 slices) and run each on its own
  * internal HIP stream, forked from / joined to `stream` with events: one part's HBM-bound kernels (depthwise,
  * GEMM epilogue stores) then overlap another part's MFMA-bound GEMM main loops.  Results do not depend on it. */
-int vasr_set_slices(vasr_handle* h, int slices);
+VASR_API int vasr_set_slices(vasr_handle* h, int slices);
 
 /* Row-independent batching (net-new; default off = the reference's batched semantics).  The reference's results
  * depend on the padded batch a signal sits in: torch.stft reflects at the end of the PADDED row (parts/features.py:
@@ -199,12 +211,12 @@ int vasr_set_slices(vasr_handle* h, int slices);
  * CTC head's operand scale) are taken over the row's own frames and the head reads zeros behind them.  Every length[b]
  * must exceed n_fft / 2 (an unbatched torch.stft refuses shorter input); pred / logp keep their [B, T'] shapes, frames
  * past a row's own count are unspecified. */
-int vasr_set_row_independent(vasr_handle* h, int on);
+VASR_API int vasr_set_row_independent(vasr_handle* h, int on);
 /* Compute units that another kernel of the caller's keeps busy while this handle's kernels run -- e.g. the beam search of
  * the previous batch on a side stream, one workgroup per utterance (engine.forward_beam).  The GEMM tile choice then
  * fills whole rounds of the REMAINING units: with 64 of 256 taken, 512 x 128 workgroups (one per CU) would need two
  * rounds, the second a third full; 256 x 64 ones quantise four times finer.  0 (default) = the whole device. */
-int vasr_set_busy_cus(vasr_handle* h, int cus);
+VASR_API int vasr_set_busy_cus(vasr_handle* h, int cus);
 
 /* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */
 /* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,
@@ -214,36 +226,37 @@ int vasr_set_busy_cus(vasr_handle* h, int cus);
  *      d_score [B] f32 combined (acoustic + LM) natural-log score of that hypothesis.
  * beam_width <= 128, V+1 <= 128.  token_min_logp / beam_prune_logp: pyctcdecode defaults are -5 / -10. */
 typedef struct vasr_lm vasr_lm;
-size_t vasr_beam_workspace_bytes(int batch, int64_t frames);
-int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
+VASR_API size_t vasr_beam_workspace_bytes(int batch, int64_t frames);
+VASR_API int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
                          int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_workspace,
                          size_t workspace_bytes, vasr_stream stream);
 /* Same with a frame count per row: d_row_frames [B] i32 (device), row b is searched over its first
  * min(d_row_frames[b], frames) frames -- for batches of utterances of different lengths whose rows must come out as
  * batch-1 calls would (vasr_set_row_independent); NULL = all frames for every row (the call above). */
-int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, int batch, int64_t frames,
+VASR_API int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, int batch, int64_t frames,
                               int num_classes, int space_id, int beam_width, float token_min_logp,
                               float beam_prune_logp, const vasr_lm* lm, int32_t* d_ids, int32_t* d_id_len,
                               float* d_score, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
 /* Back-off n-gram model as two open-addressing hash tables (keys built with vasr_beam_hash_*; 0 = empty slot,
  * stored keys have bit 0 set): word-hash -> word id, and hash(n, id_1..id_n) -> (log10 p, log10 back-off).
  * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel. */
-int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
+VASR_API int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
                    const float* h_nval, int ncap, int order, int bos_id, int eos_id, int unk_id, float alpha,
                    float beta, float unk_offset, vasr_lm** out);
-void vasr_lm_destroy(vasr_lm* lm);
-uint64_t vasr_beam_hash_init(void);
-uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v);
+VASR_API void vasr_lm_destroy(vasr_lm* lm);
+VASR_API uint64_t vasr_beam_hash_init(void);
+VASR_API uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v);
 
 /* ---- introspection -------------------------------------------------------------------- */
-const char* vasr_last_error(void);
-const char* vasr_version(void);
+VASR_API const char* vasr_last_error(void);
+VASR_API const char* vasr_version(void);
+VASR_API int vasr_abi_version(void);
 /* Algorithmic work of one call at (batch, samples): flops of the 1x1-conv GEMMs, flops and
  * minimum HBM bytes (read input + write output + weights, fp32) of the depthwise layers.
  * out[0]=pointwise_flops out[1]=depthwise_flops out[2]=depthwise_bytes out[3]=decoder_flops
  * out[4]=frontend_flops (2.5 N log2 N per frame + mel) */
-int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]);
+VASR_API int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, double out[5]);
 /* Per-kernel-class timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures).  Between begin and end every launch of vasr_transcribe_greedy_f32 /
  * vasr_encoder_f32 / vasr_decoder_* is bracketed by an event pair; end() synchronises on the events
@@ -252,10 +265,10 @@ int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samples, doub
  *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse)  [4] fused depthwise + pointwise sub-blocks
  * flops / bytes (optional, may be NULL): the algorithmic work of the launches of each class that actually ran --
  * 2 M N K of every GEMM (class 2 and 4), HBM bytes read + written by every depthwise (1) and fused (4) layer. */
-int vasr_profile_begin(vasr_handle* h);
-int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double flops[5], double bytes[5]);
+VASR_API int vasr_profile_begin(vasr_handle* h);
+VASR_API int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double flops[5], double bytes[5]);
 /* Row pitch of the library's padded activation buffers: frames rounded up to the 128-frame tile. */
-int64_t vasr_padded_frames(int64_t frames);
+VASR_API int64_t vasr_padded_frames(int64_t frames);
 
 #ifdef __cplusplus
 }

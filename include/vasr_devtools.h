@@ -16,54 +16,54 @@ extern "C" {
  * kernel, recorded back to back on `stream` exactly like the profiled launches.  A bracket measures "previous kernel
  * done -> this kernel done", i.e. the kernel plus its dispatch gap; bench.py reports class times both raw and with
  * launches x this value removed (the latter is what rocprofv3 --kernel-trace reports as kernel duration). */
-int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us);
+VASR_API int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us);
 /* Run ONE encoder layer kind in isolation for benchmarking/roofline measurement:
  * kind 0 = depthwise (K, stride 1, dilation 1), 1 = pointwise GEMM (+BN+ReLU epilogue).
  * Buffers are caller provided [B][C][Tp] with Tp = vasr_padded_frames(T). */
-int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
+VASR_API int vasr_bench_depthwise(const float* d_x, const float* d_w, const int32_t* d_lens, int batch, int channels,
                          int64_t frames, int kernel, float* d_y, vasr_stream stream);
 /* Depthwise convolution on the matrix pipe (Toeplitz form, fp16-split arithmetic; stride 1, the (kernel, dilation) pairs
  * of the shipped models): vasr_depthwise_mfma_table_size = dwords per channel of the tap table (0 = shape not covered),
  * vasr_pack_depthwise_taps fills [channels][size] tables and [channels] inverse scales on the host; the bench call runs
  * one layer on [B][C][vasr_padded_frames(T)] buffers (dilation > 1: "same" padding as jasper.py:60-65).  d_amax as in
  * vasr_bench_pointwise_f16x2, amax_stride >= 256 and >= channels * ceil(padded frames / 256) * 4. */
-int vasr_depthwise_mfma_table_size(int kernel, int dilation);
-int vasr_pack_depthwise_taps(const float* h_w, int channels, int kernel, int dilation, uint32_t* h_table, float* h_inv);
-int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const float* d_tap_inv, const int32_t* d_lens,
+VASR_API int vasr_depthwise_mfma_table_size(int kernel, int dilation);
+VASR_API int vasr_pack_depthwise_taps(const float* h_w, int channels, int kernel, int dilation, uint32_t* h_table, float* h_inv);
+VASR_API int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const float* d_tap_inv, const int32_t* d_lens,
                               int batch, int channels, int64_t frames, int kernel, int dilation, float* d_y,
                               uint32_t* d_amax, int amax_stride, vasr_stream stream);
 /* Host helper: [cout][cin] row-major weights -> the MFMA fragment order the pointwise kernel streams
  * ([m_pad/32][cin/8][64 lanes][4], rows past cout zero); h_out holds m_pad*cin floats. */
-int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out);
-int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
+VASR_API int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad, float* h_out);
+VASR_API int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
                          int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 
 /* Reference point for the GEMM roofline: launches `workgroups` x 8 wavefronts that do nothing but
  * v_mfma_f32_32x32x16_bf16 on register operands (the pointwise kernel's MFMA stream without loads, LDS or barriers),
  * `steps` x 48 per wavefront; *flops = bf16 flops issued.  Timed by the caller; what it sustains is the rate the chip
  * holds under its power limit, against which bench.py also quotes the GEMM (roofline.sustained_peak). */
-int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
+VASR_API int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
 
 /* 2 x fp16 scaled split variants (fragments: [m_pad/32][cin/16][2][64 lanes][8] fp16 bits; *inv_scale = 1 / the power
  * of two the weights were scaled by).  d_amax: [2][batch][amax_stride] u32 scratch (amax_stride >= 256 and >= cout *
  * frames / 1024) -- table 0 receives per-wavefront maxima of |x| per utterance (the call computes them), table 1 those of
  * |y|; unused slots are zeroed, so max over the last axis is the utterance's maximum. */
-int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out, float* inv_scale);
-int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
+VASR_API int vasr_pack_pointwise_f16x2(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out, float* inv_scale);
+VASR_API int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_inv_scale, const float* d_scale,
                                const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
                                uint32_t* d_amax, int amax_stride, vasr_stream stream);
 
 /* The same layer on a PRE-SPLIT ("P4") input tensor (csrc/encoder_pw_p4.hip): vasr_pack_p4 is the host restatement of the
  * layout for one utterance -- x [rows][ld] fp32, `scale` a power of two -> [rows][ld / 4][8] fp16 bit patterns; d_x_inv
  * holds 1 / scale per utterance.  d_amax_y: one maxima table [B][amax_stride] (or NULL). */
-int vasr_pack_p4(const float* h_x, int rows, int64_t ld, float scale, uint16_t* h_out);
-int vasr_bench_pointwise_p4(const uint16_t* d_x_p4, const float* d_x_inv, const uint16_t* d_w16, float w_inv_scale,
+VASR_API int vasr_pack_p4(const float* h_x, int rows, int64_t ld, float scale, uint16_t* h_out);
+VASR_API int vasr_bench_pointwise_p4(const uint16_t* d_x_p4, const float* d_x_inv, const uint16_t* d_w16, float w_inv_scale,
                             const float* d_scale, const float* d_shift, int batch, int cin, int cout, int64_t frames,
                             float* d_y, uint32_t* d_amax_y, int amax_stride, vasr_stream stream);
 
 /* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
-int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);
-int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
+VASR_API int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);
+VASR_API int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,
                                 int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 
 #ifdef __cplusplus

@@ -21,6 +21,27 @@ def _header_functions(name="vasr.h"):
     return sorted(set(re.findall(r"\b(vasr_[a-z0-9_]+)\s*\(", src)))
 
 
+def _dynamic_symbols(path):
+    """Defined symbols of the shared object's dynamic table, read from the ELF itself (no binutils needed on the box)."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"\x7fELF" and b[4] == 2 and b[5] == 1          # ELF64, little endian
+    shoff, = struct.unpack_from("<Q", b, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", b, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+    out = set()
+    for (_n, typ, _f, _a, off, size, link, _i, _al, entsize) in secs:
+        if typ != 11:                                               # SHT_DYNSYM
+            continue
+        stroff = secs[link][4]
+        for k in range(1, size // entsize):
+            name, info, _other, shndx, _val, _sz = struct.unpack_from("<IBBHQQ", b, off + k * entsize)
+            if shndx != 0 and (info >> 4) in (1, 2):                # defined, GLOBAL or WEAK
+                end = b.index(b"\0", stroff + name)
+                out.add(b[stroff + name:end].decode())
+    return out
+
+
 def test_library_exports_every_declared_symbol():
     names = _header_functions()
     assert len(names) >= 20 and "vasr_transcribe_greedy_f32" in names
@@ -37,6 +58,12 @@ def test_library_exports_every_declared_symbol():
     dev = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so"))
     for n in names + dev_names:
         assert hasattr(dev, n), f"{n} missing from libvasr_hip_dev.so"
+    # ... and NOTHING else: the libraries are linked with -fvisibility=hidden + a version script (csrc/vasr.map), so the
+    # dynamic symbol table is exactly the C ABI -- no mangled vasr::launch_* internals, no devtools probe
+    assert _dynamic_symbols(_lib.LIB_PATH) == set(names)
+    assert _dynamic_symbols(os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so")) == set(names + dev_names)
+    assert _lib.lib().vasr_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VASR_ABI_VERSION (\d+)", open(
+        os.path.join(ROOT, "include", "vasr.h")).read()).group(1))
     blob = open(_lib.LIB_PATH, "rb").read()
     for switch in (b"VASR_DW_PAIR", b"VASR_PW3_TILE", b"VASR_FUSED", b"VASR_NO_FUSED_RESIDUAL", b"VASR_DEBUG_NO_EPILOGUE"):
         assert switch not in blob, switch

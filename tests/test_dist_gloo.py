@@ -161,6 +161,35 @@ def _worker(rank, world, port, q):
         if world == 2:
             costs = [c["duration"] for _, c in gathered]
             assert (max(costs) - min(costs)) / max(costs) < 0.2, costs      # 6 buckets over 2 ranks: within one small bucket
+        # -- the bench loop's result gather (dist.AsyncIdGather: double-buffered async all_gather_into_tensor): seven steps of
+        #    a fixed-shape batch, ranks deliberately out of step (rank r sleeps r x 5 ms before each submit), two shapes;
+        #    every gathered buffer must hold every rank's batch of THAT step when it is read after the next submit
+        ring = vdist.AsyncIdGather(world, torch.device("cpu"))
+        import time as _t
+        seen = []
+        for step in range(7):
+            b, t = (4, 9) if step < 5 else (3, 6)
+            ids = torch.full((b, t), 1000 * step + rank, dtype=torch.int32) + torch.arange(t, dtype=torch.int32)
+            n = torch.full((b,), step + rank, dtype=torch.int32)
+            _t.sleep(0.005 * rank)
+            ring.submit(ids, n)
+            g_ids, g_n = ring.last()
+            seen.append((g_ids.clone(), g_n.clone()))
+        ring.drain()
+        for step, (g_ids, g_n) in enumerate(seen):
+            b, t = (4, 9) if step < 5 else (3, 6)
+            assert g_ids.shape == (world, b, t) and g_n.shape == (world, b)
+            for r in range(world):
+                assert g_ids[r, 0].tolist() == [1000 * step + r + k for k in range(t)] and g_n[r].tolist() == [step + r] * b
+        # un-waited pipelining: submit two steps back to back, read the first only after the second is in flight
+        x0 = torch.full((2, 3), 10 + rank, dtype=torch.int32); n0 = torch.full((2,), rank, dtype=torch.int32)
+        x1 = torch.full((2, 3), 20 + rank, dtype=torch.int32); n1 = torch.full((2,), 7 + rank, dtype=torch.int32)
+        s0 = ring.submit(x0, n0)
+        s1 = ring.submit(x1, n1)
+        assert s0 != s1
+        ring.drain()
+        assert ring._bufs[(2, 3)][s0][0][:, 0, 0].tolist() == [10 + r for r in range(world)]
+        assert ring._bufs[(2, 3)][s1][1][:, 0].tolist() == [7 + r for r in range(world)]
         NeuralModuleFactory.reset_default_factory()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -1,0 +1,364 @@
+#!/bin/bash
+# GPU-box tasks, one parameterised script (run through gpurun):  bash tools/gpu.sh <task> [args...]
+# Every task was a one-off tools/gpu_<task>.sh in rounds 1-3 (DESIGN.md cites them as `tools/gpu.sh <task>`); the bodies
+# are unchanged.  `bash tools/gpu.sh list` prints the tasks with their one-line purpose.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+
+# ---- abl: run a timing tool against the default library and every ablation build: tools/gpu_abl.sh <tag> <MACRO> "<tool + args>"
+task_abl() {
+# run a timing tool against the default library and every ablation build: tools/gpu_abl.sh <tag> <MACRO> "<tool + args>"
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; MACRO=$2; TOOL=$3
+O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+echo "== default" > $O/abl.txt; $TOOL >> $O/abl.txt 2>&1
+for f in $R/viet-asr_amd/lib/abl_${MACRO}_*.so; do echo "== $(basename $f)" >> $O/abl.txt; VASR_LIB_PATH=$f $TOOL >> $O/abl.txt 2>&1; done
+cat $O/abl.txt
+}
+
+# ---- b1: 
+task_b1() {
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-b1}; mkdir -p $O; cd $R
+python bench.py --batch 1 --steps 50 --warmup 10 --no-cpu-baseline --no-other-gemm --no-side-configs > $O/b1.json 2>$O/b1.err
+python - <<PY
+import json
+j=json.loads([l for l in open("$O/b1.json").read().splitlines() if l.startswith("{")][-1])
+print("B=1: %.3f ms/step gemm %.3f (%d launches) dw %.3f (%d) fused %.3f other %s" % (j["ms_per_step"], j["roofline"]["ms_per_step"], j["roofline"]["launches_per_step"], j["depthwise"]["ms_per_step"], j["depthwise"]["launches_per_step"], j["fused"]["ms_per_step"], j["other_ms_per_step"]))
+PY
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --batch 1 --steps 50 --warmup 10 --no-cpu-baseline --no-other-gemm --no-side-configs > /dev/null 2> $O/stats.err
+f=$(find $O/stats -name '*kernel_stats.csv' | head -1); python - <<PY
+import csv
+rows=list(csv.DictReader(open("$f")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:25]:
+    print("%-90s calls %6s avg %8.1f ns  %5.1f%%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), 100*float(r["TotalDurationNs"])/tot))
+PY
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+}
+
+# ---- beamcmp: 
+task_beamcmp() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_t512s1024.so; do
+  export VASR_LIB_PATH=$f; echo "== $(basename $f)"; python tests/devtools/bench_beam.py 2>&1 | grep -v amdgpu
+done
+}
+
+# ---- beamgroup: 
+task_beamgroup() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+MODE=base python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/var_t512s1024.so
+for m in base group group_nomask half; do MODE=$m python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1; done
+MODE=half NCU=32 python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
+MODE=group NCU=128 python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
+}
+
+# ---- beampack: 
+task_beampack() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+for f in dev $R/viet-asr_amd/lib/var_*.so; do
+  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
+  echo "== $(basename $f)"; python tools/probes/beam_pack.py 2>&1 | grep -v amdgpu | tail -5
+done
+}
+
+# ---- beamprof: 
+task_beamprof() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/var_prof.so
+python tools/probes/beam_slots.py 2>&1 | grep -v amdgpu | grep "beam prof" | awk 'NR==61||NR==93||NR==96||NR==77||NR==29'
+}
+
+# ---- beamslots: 
+task_beamslots() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+for s in 512 1024 2048 auto; do
+  [ $s = auto ] && unset VASR_BEAM_SLOTS || export VASR_BEAM_SLOTS=$s
+  python tools/probes/beam_slots.py 2>&1 | grep -v amdgpu | tail -1
+done
+unset VASR_BEAM_SLOTS VASR_LIB_PATH
+timeout 900 python -m pytest tests/test_beam.py -m gpu -q -p no:cacheprovider -x 2>&1 | tail -2
+}
+
+# ---- beamvar: 
+task_beamvar() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+for f in dev $R/viet-asr_amd/lib/var_*.so; do
+  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
+  echo "== $(basename $f)"; python tests/devtools/bench_beam.py 2>&1 | grep -v amdgpu | grep "128"
+  timeout 300 python tests/devtools/fuzz_beam.py 150 0 2>&1 | tail -1
+done
+}
+
+# ---- c5prof: 
+task_c5prof() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-c5prof}; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --config ${2:-5} --steps 3 --warmup 1 --no-cpu-baseline --no-other-gemm > $O/bench.json 2> $O/stats.err
+f=$(find $O/stats -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; python - <<PY
+import csv
+rows=list(csv.DictReader(open("$f")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:28]:
+    print("%-84s calls %5s avg %10.1f us  %5.1f%%" % (r["Name"].replace("vasr::(anonymous namespace)::","").replace("void ","")[:84], r["Calls"], float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot))
+PY
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+}
+
+# ---- dwbig: 
+task_dwbig() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_BENCH_KEEP_AMAX=1 B=512 T=1501
+for f in dev $R/viet-asr_amd/lib/var_*.so; do
+  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
+  for upw in 0 1 2 4; do
+    [ $upw = 0 ] && unset VASR_DW_UPW || export VASR_DW_UPW=$upw
+    echo "== $(basename $f) upw=$upw"; python tools/bench_dw.py 51 75 2>&1 | grep -v amdgpu
+    [ $f != dev ] && break
+  done
+done
+}
+
+# ---- dwcmp: GPU box: depthwise policy comparison (auto = Toeplitz from 51 dense taps, VASR_DW_MFMA=0 packed FMAs only, =1 Toeplitz everywhere) over the bench workloads
+task_dwcmp() {
+# GPU box: depthwise policy comparison (auto = Toeplitz from 51 dense taps, VASR_DW_MFMA=0 packed FMAs only, =1 Toeplitz everywhere) over the bench workloads
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/dwcmp; mkdir -p $O; cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "matrix_pipe or goldens or bounded_memory or real_recordings" > $O/pytest.log 2>&1; tail -2 $O/pytest.log
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm"
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], 'dw', d.get('depthwise',{}).get('ms_per_step'), d.get('depthwise',{}).get('frac'), 'gemm', d['roofline'].get('ms_per_step'))"; }
+for env in "" "VASR_DW_MFMA=0" "VASR_DW_MFMA=1"; do
+  for args in "" "--seconds 10.3" "--ragged" "--config 2" "--config 5 --steps 3 --warmup 1"; do
+    env $env timeout 200 $B $args 2>$O/err.log | show "[$env] [$args]"
+  done
+done
+}
+
+# ---- epi: 
+task_epi() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+python tools/bench_pw.py 512 512 256 256 2>/dev/null | grep -v amdgpu
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm --no-side-configs > gpurun_out/epi_bench.json 2> gpurun_out/epi_bench.err
+python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/epi_bench.json").read().splitlines() if l.startswith("{")][-1])
+print("bench: %.0fx %.3f ms pw %.3f (frac %.3f) dw %.3f fused %.3f" % (j["value"], j["ms_per_step"], j["roofline"]["ms_per_step"], j["roofline"]["frac"], j["depthwise"]["ms_per_step"], j["fused"]["ms_per_step"]))
+PY
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x -k "golden or fused or alternate" 2>&1 | tail -2
+}
+
+# ---- final_r03: Round-3 profile run: kernel stats, PMC traffic, bench lines (default with all configs, 10.3 s), SQ counters of the fused kernel
+task_final_r03() {
+# Round-3 profile run: kernel stats, PMC traffic, bench lines (default with all configs, 10.3 s), SQ counters of the fused kernel
+# and of the 512-channel GEMM inside the bench workload.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+bash tools/profile_round.sh $TAG > $O/profile.log 2>&1
+python bench.py --seconds 10.3 --no-cpu-baseline --no-other-gemm --no-side-configs > $O/bench_10p3s.json 2> /dev/null
+for c in 2 4 5; do timeout 300 python bench.py --config $c --steps $([ $c = 5 ] && echo 5 || echo 20) --warmup 3 --no-other-gemm --no-cpu-baseline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+cd /tmp && export TMPDIR=/tmp
+BQ="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-gemm --no-side-configs"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $O/sq1 -- $BQ > $O/sq1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $BQ > $O/sq2.log 2>&1
+python - <<PY > $O/sq_counters.txt 2>&1
+import csv, glob, collections
+for tag in ("sq1", "sq2"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("$O/%s/*/*counter_collection.csv" % tag):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            for key in ("pw_gemm_split_kernel", "dwpw_fused_kernel", "dw_toeplitz_kernel"):
+                if key in k:
+                    name = key + "<" + k.split(key + "<")[1].split(">")[0] + ">"
+                    agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    agg[name]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for name, c in sorted(agg.items()):
+        ncnt = max(1, len(c) - 1)
+        print(tag, name, "dispatches", len(c["_dur_us"]) // ncnt)
+        for cn, v in sorted(c.items()):
+            print("    %-28s mean %.4g" % (cn, sum(v) / len(v)))
+PY
+find $O -name '*counter_collection.csv' -delete; find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+cd $R; ls $O; head -40 $O/sq_counters.txt
+}
+
+# ---- full: the whole GPU suite + smoke + default bench, as the driver runs them at round end
+task_full() {
+# the whole GPU suite + smoke + default bench, as the driver runs them at round end
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-full}; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+(time timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
+tail -8 $O/pytest.log; tail -2 $O/smoke.log; head -c 600 $O/bench_default.json
+}
+
+# ---- fvar: fused-kernel variants: default library and every viet-asr_amd/lib/var_*.so through bench.py; prints the fused / gemm / dw class times
+task_fvar() {
+# fused-kernel variants: default library and every viet-asr_amd/lib/var_*.so through bench.py; prints the fused / gemm / dw class times
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-fvar}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-gemm"
+for f in default $R/viet-asr_amd/lib/var_*.so; do
+  n=$(basename $f .so); [ $f = default ] && unset VASR_LIB_PATH || export VASR_LIB_PATH=$f
+  $B > $O/bench_$n.json 2> $O/bench_$n.err
+  python - <<PY
+import json
+try:
+    j=json.loads([l for l in open("$O/bench_$n.json").read().splitlines() if l.startswith("{")][-1])
+    print("%-12s %.3f ms/step  gemm-family %.3f  dw %.3f  fused %.3f ms = %.1f us/launch" % ("$n", j["ms_per_step"], j["roofline"]["ms_per_step"], j["depthwise"]["ms_per_step"], j["fused"]["ms_per_step"], 1e3*j["fused"]["ms_per_step"]/max(1,j["fused"]["launches_per_step"])))
+except Exception as e: print("$n bench ERR", e)
+PY
+done
+}
+
+# ---- p4: 
+task_p4() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_BENCH_KEEP_AMAX=1
+for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_*.so; do
+  export VASR_LIB_PATH=$f; echo "== $(basename $f)"; timeout 300 python tools/probes/p4_gemm_probe.py 2>&1 | grep -v amdgpu | tail -2
+done
+}
+
+# ---- phase: phase-shift experiment: 256 x 128 tiles on four wavefronts (two workgroups per CU), second arrival delayed
+task_phase() {
+# phase-shift experiment: 256 x 128 tiles on four wavefronts (two workgroups per CU), second arrival delayed
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+echo "== default tile"; python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu
+for d in ${DELAYS:-0 200 400 600 800}; do
+  echo "== tile 6, delay $d x 10 ns"; VASR_PW3_TILE=6 VASR_PW_PHASE=$d python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu
+done
+}
+
+# ---- phase2: phase shift again, with the activation staging compiled out (what an LDS-DMA of pre-split activations would leave of it)
+task_phase2() {
+# phase shift again, with the activation staging compiled out (what an LDS-DMA of pre-split activations would leave of it)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_*.so; do
+  export VASR_LIB_PATH=$f; echo "== $(basename $f)"
+  echo -n "tile 1: "; VASR_PW3_TILE=1 python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu | cut -c1-60
+  for d in 0 300 500 700; do
+    echo -n "tile 6 delay $d: "; VASR_PW3_TILE=6 VASR_PW_PHASE=$d python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu | cut -c1-60
+  done
+done
+}
+
+# ---- phase3: is the epilogue of the two-workgroups-per-CU tile bandwidth-bound (half the workgroups store in half the time) or not?
+task_phase3() {
+# is the epilogue of the two-workgroups-per-CU tile bandwidth-bound (half the workgroups store in half the time) or not?
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_BENCH_KEEP_AMAX=1
+for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_abl4w4b2.so; do
+  export VASR_LIB_PATH=$f; echo "== $(basename $f)"
+  for t in 1 6; do for e in 0 2 1; do
+    [ $e = 0 ] && unset VASR_DEBUG_NO_EPILOGUE || export VASR_DEBUG_NO_EPILOGUE=$e
+    echo -n "tile $t epilogue-skip $e: "; VASR_PW3_TILE=$t python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu | cut -c1-60
+  done; done
+  unset VASR_DEBUG_NO_EPILOGUE
+  for d in 300 600; do echo -n "tile 6 delay $d: "; VASR_PW3_TILE=6 VASR_PW_PHASE=$d python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu | cut -c1-60; done
+  export VASR_DEBUG_NO_EPILOGUE=1
+  for d in 300 600; do echo -n "tile 6 delay $d no epilogue: "; VASR_PW3_TILE=6 VASR_PW_PHASE=$d python tools/bench_pw.py 512 512 2>/dev/null | grep -v amdgpu | cut -c1-60; done
+  unset VASR_DEBUG_NO_EPILOGUE
+done
+}
+
+# ---- quick: quick GPU check: selected tests + default bench (+ variants given as "ENV=.. ENV=.." strings in $VARIANTS, ';' separated) + kernel stats
+task_quick() {
+# quick GPU check: selected tests + default bench (+ variants given as "ENV=.. ENV=.." strings in $VARIANTS, ';' separated) + kernel stats
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-q}; KEXPR=${2:-"matrix_pipe or goldens"}
+O=$R/gpurun_out/$TAG; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -k "$KEXPR" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm"
+$B > $O/bench_default.json 2> $O/bench_default.err
+i=0
+IFS=';' read -ra VS <<< "${VARIANTS:-}"
+for v in "${VS[@]}"; do i=$((i+1)); env $v $B > $O/bench_v$i.json 2> $O/bench_v$i.err; echo "$v" > $O/bench_v$i.txt; done
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-gemm > $O/bench_under_rocprof.json 2> $O/stats.err
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+cd $R; tail -4 $O/pytest.log
+}
+
+# ---- sq_dw: GPU box: SQ wait / issue counters of the depthwise kernels on an isolated layer (tools/bench_dw.py K), two PMC passes
+task_sq_dw() {
+# GPU box: SQ wait / issue counters of the depthwise kernels on an isolated layer (tools/bench_dw.py K), two PMC passes
+R=${GRAFT_REPO_ROOT:-/root/repo}; K=${1:-75}; O=$R/gpurun_out/sqdw; rm -rf $O; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0 VASR_BENCH_KEEP_AMAX=1
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $O/a -- python $R/tools/bench_dw.py $K > $O/a.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/b -- python $R/tools/bench_dw.py $K > $O/b.log 2>&1
+python - <<PY
+import csv, glob, collections, re
+for tag in ("a", "b"):
+    f = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(f[0])):
+        n = row["Kernel_Name"]
+        if "dw_" not in n: continue
+        acc[re.search(r"dw_\w+(<[^>]*>)?", n).group(0)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, d in acc.items():
+        print(tag, k, {c: "%.3g" % (sum(v) / len(v)) for c, v in d.items()}, "launches", len(next(iter(d.values()))))
+PY
+find $O -name '*.csv' -delete; find $O -name '*.db' -delete
+}
+
+# ---- tzocc: Toeplitz depthwise occupancy variants: isolated layers at 64 x 10 s and 512 x 30 s, then the bench line
+task_tzocc() {
+# Toeplitz depthwise occupancy variants: isolated layers at 64 x 10 s and 512 x 30 s, then the bench line
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export VASR_BENCH_KEEP_AMAX=1
+for f in dev $R/viet-asr_amd/lib/var_*.so; do
+  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
+  echo "== $(basename $f)"
+  B=64 T=501 python tools/bench_dw.py 33 51 63 75 2>&1 | grep -v amdgpu
+  B=512 T=1501 python tools/bench_dw.py 51 75 2>&1 | grep -v amdgpu
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm --no-side-configs 2>/dev/null | python -c "
+import json,sys
+j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('   bench: %.0fx %.3f ms pw %.3f dw %.3f (frac %.3f) fused %.3f' % (j['value'], j['ms_per_step'], j['roofline']['ms_per_step'], j['depthwise']['ms_per_step'], j['depthwise']['frac'], j['fused']['ms_per_step']))"
+done
+}
+
+# ---- var: time the default library and every viet-asr_amd/lib/var_*.so: isolated GEMM layers + the bench line + (optional) goldens
+task_var() {
+# time the default library and every viet-asr_amd/lib/var_*.so: isolated GEMM layers + the bench line + (optional) goldens
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-var}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+export VASR_BENCH_KEEP_AMAX=1
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-gemm"
+for f in default $R/viet-asr_amd/lib/var_*.so; do
+  n=$(basename $f .so); [ $f = default ] && unset VASR_LIB_PATH || export VASR_LIB_PATH=$f
+  echo "== $n"; python tools/bench_pw.py 512 512 256 256 512 1024 2>/dev/null | grep -v amdgpu
+  $B > $O/bench_$n.json 2> $O/bench_$n.err
+  python - <<PY
+import json
+try:
+    j=json.loads([l for l in open("$O/bench_$n.json").read().splitlines() if l.startswith("{")][-1])
+    print("   bench: %.0fx %.3f ms pw %.3f dw %.3f" % (j["value"], j["ms_per_step"], j["roofline"]["ms_per_step"], j["depthwise"]["ms_per_step"]))
+except Exception as e: print("   bench ERR", e)
+PY
+  if [ -n "${KEXPR:-}" ]; then timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "$KEXPR" 2>&1 | tail -1; fi
+done
+}
+
+# ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them
+task_probes() {
+cd $R/tools/probes
+for p in place_probe tr_probe; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $p.hip -o $p && ./$p; done
+}
+
+task=${1:-list}; shift || true
+if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
+if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi
+"task_$task" "$@"

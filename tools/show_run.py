@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a gpurun_out/<tag> directory written by tools/gpu_quick.sh (dev tool)."""
+"""Summarise a gpurun_out/<tag> directory written by tools/gpu.sh quick (dev tool)."""
 import csv, glob, json, os, sys
 d = sys.argv[1]
 for f in sorted(glob.glob(os.path.join(d, "bench_*.json"))):

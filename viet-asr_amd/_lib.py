@@ -75,6 +75,7 @@ SIGNATURES = {
     "vasr_beam_hash_step": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "vasr_last_error": (C.c_char_p, []),
     "vasr_version": (C.c_char_p, []),
+    "vasr_abi_version": (C.c_int, []),
     "vasr_algorithmic_work": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "vasr_profile_begin": (C.c_int, [_P]),
     "vasr_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -101,6 +102,8 @@ DEV_SIGNATURES = {
     "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
+ABI_VERSION = 4          # VASR_ABI_VERSION of the include/vasr.h these signatures were written against
+
 _lib = None
 _dev = None
 
@@ -119,6 +122,9 @@ def _load(path, tables):
                     raise VasrError(f"{path} does not export {name}")
                 continue
             fn.restype, fn.argtypes = res, args
+    have = l.vasr_abi_version() if hasattr(l, "vasr_abi_version") else 0
+    if have != ABI_VERSION:
+        raise VasrError(f"{path} implements ABI {have}, these bindings expect {ABI_VERSION}: rebuild it (make -C viet-asr_amd/csrc)")
     return l
 
 

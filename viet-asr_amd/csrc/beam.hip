@@ -752,7 +752,7 @@ size_t beam_lds_bytes(int slots) {
          (8 + 8 + 4 + 4 + 4) * kMaxBeams + 8 * slots + 2 * (max_fill(slots) + 2) + 16;
 }
 
-// Measured (MI355X, 64 x 501 frames, tools/gpu_beamslots.sh): CTC-like posteriors, beam 20 / 50 / 100 / 128:
+// Measured (MI355X, 64 x 501 frames, tools/gpu.sh beamslots): CTC-like posteriors, beam 20 / 50 / 100 / 128:
 // 2.22 / 2.56 / 3.55 / 4.34 ms at 1024 slots, 2.63 / 2.99 / 3.83 / 4.50 at 2048; peaked ones 2.90 / 3.45 / 5.63 / 7.20 against
 // 3.43 / 3.91 / 5.20 / 6.28.  (512 slots: another 5-7 % at beam <= 20, but 1.5x slower there on flat posteriors.)
 int beam_slots_for(int beam_width) {

@@ -119,6 +119,7 @@ struct vasr_handle {
   bool slice_ready = false;
   bool row_independent = false;   // vasr_set_row_independent
   int busy_cus = 0;               // vasr_set_busy_cus
+  int n_cu = 256;                 // compute units of the device the handle was finalized on (tile-fill decisions)
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
   // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), 1 = 3 x bf16 split operands on v_mfma_f32_32x32x16_bf16 (measured
@@ -611,11 +612,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  VASR_FUSED_MIN_TILES=n forces
       // the fused form from n tiles on, whatever the fill (tests).
       static const int fused_min_tiles = dev_env("VASR_FUSED_MIN_TILES") ? atoi(dev_env("VASR_FUSED_MIN_TILES")) : 0;
-      static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-      }();
+      const int n_cu = h->n_cu;
       // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- take no workgroups: 256 tiles on the
       // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
       const int f_cus = h->busy_cus > 0 && h->busy_cus < n_cu - 32 ? n_cu - h->busy_cus : n_cu;
@@ -744,7 +741,8 @@ int run_decoder(vasr_handle* h, const float* encp, int64_t ld, int64_t T1, int b
 extern "C" {
 
 const char* vasr_last_error(void) { return g_err.c_str(); }
-const char* vasr_version(void) { return "vasr-hip 0.1 (gfx950)"; }
+const char* vasr_version(void) { return "vasr-hip 0.4 (gfx950)"; }
+int vasr_abi_version(void) { return VASR_ABI_VERSION; }
 int64_t vasr_padded_frames(int64_t frames) { return pad_frames(frames); }
 
 int vasr_create(const vasr_model_desc* d, vasr_handle** out) {
@@ -837,6 +835,11 @@ int vasr_finalize(vasr_handle* h) {
   if (h->has_encoder && (rc = build_encoder(h))) return rc;
   if (h->has_decoder && (rc = build_decoder(h))) return rc;
   HIP_TRY(hipDeviceSynchronize());
+  {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      h->n_cu = n;
+  }
   h->weights.clear();
   h->finalized = true;
   return 0;
@@ -1171,7 +1174,7 @@ int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double f
 }
 
 #ifdef VASR_DEVTOOLS
-__global__ void vasr_noop_kernel() {}
+static __global__ void dev_noop_kernel() {}
 
 int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us) {
   if (n < 1 || n > 4096 || !out_us) return fail(VASR_ERR_INVALID, "bad argument");
@@ -1180,7 +1183,7 @@ int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us) {
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int i = 0; i < n; ++i) {   // same shape as ProfScope: record, launch, record -- back to back on one stream
     HIP_TRY(hipEventRecord(ev[2 * i], st));
-    hipLaunchKernelGGL(vasr_noop_kernel, dim3(1), dim3(64), 0, st);
+    hipLaunchKernelGGL(dev_noop_kernel, dim3(1), dim3(64), 0, st);
     HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
   }
   HIP_TRY(hipEventSynchronize(ev.back()));

@@ -55,7 +55,10 @@ class AudioToTextDataLayer(DataLayerNM):
         batches = None
         if self.placement == DeviceType.AllGpu and torch.distributed.is_available() and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-            if shard_by == "duration" and all(it[1] > 0 for it in items):
+            # duration-balanced dealing fixes the batch composition (length buckets), so it is only taken when the caller did
+            # not ask for something it cannot honour: shuffle=True (the reference's DistributedSampler shuffles
+            # utterances, actions.py:669-693) and bucket_by_length=False fall back to equal-count contiguous shards
+            if shard_by == "duration" and all(it[1] > 0 for it in items) and bucket_by_length and not shuffle:
                 # length buckets of batch_size utterances dealt heaviest-first to the least loaded rank: the ranks'
                 # padded work (rows x longest row, summed over batches) ends up within a few percent of each other
                 batches = [sorted(b, key=lambda i: (items[i][1], i)) for b in balanced_shards([it[1] for it in items], world, batch_size)[rank]]
@@ -69,8 +72,8 @@ class AudioToTextDataLayer(DataLayerNM):
             order.sort(key=lambda i: items[i][1])    # similar lengths share a batch: less padding work
         self._items, self._order = items, order
         self._batches = batches if batches is not None else [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
-        if drop_last and self._batches and len(self._batches[-1]) < batch_size:
-            self._batches.pop()
+        if drop_last:     # (the duration-balanced path sorts its batches by length: the short one is not the last)
+            self._batches = [b for b in self._batches if len(b) == batch_size]
 
     def tokens(self, text):
         return [self._lab[c] for c in text if c in self._lab]

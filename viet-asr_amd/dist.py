@@ -79,6 +79,50 @@ def gather_id_sequences(ids, id_len, group=None, extra=None):
     return out + (torch.cat([e[:r] for e, r in zip(all_ex, rows)]),)
 
 
+class AsyncIdGather:
+    """Double-buffered asynchronous gather of one batch's (ids, id_len) per step -- the steady-state form of the result
+    gather for fixed-shape batches (every rank produces the same [B, T'] per step: the weak-scaling bench loop, a
+    server's fixed batch).  One ``all_gather_into_tensor`` per returned tensor, like actions.py:774-807 issues one
+    collective per tensor, but asynchronously on the backend's own stream into one of ``slots`` buffer pairs: the next
+    batch's kernels do not wait for the other ranks, a buffer pair is reused only after its previous gather has been
+    waited for, ``drain()`` waits for everything in flight.  The source tensors of a submitted gather are kept alive
+    until it has been drained.  (Shapes that differ between ranks go through ``gather_id_sequences``.)"""
+
+    def __init__(self, world, device, group=None, slots=2):
+        self.world, self.device, self.group, self.slots = world, device, group, slots
+        self._bufs, self._inflight, self._n = {}, [None] * slots, 0
+
+    def drain(self, slot=None):
+        for k in (range(self.slots) if slot is None else (slot,)):
+            if self._inflight[k] is not None:
+                for w in self._inflight[k][:2]:
+                    w.wait()
+                self._inflight[k] = None
+
+    def submit(self, ids, id_len):
+        """Enqueue the gather of this rank's batch; returns the slot it went into."""
+        shape = tuple(ids.shape)
+        if shape not in self._bufs:
+            # (the rank-major concatenation along dim 0: the output form both RCCL and gloo accept; read as [world, B, ...])
+            self._bufs[shape] = [(torch.empty((self.world * shape[0],) + shape[1:], dtype=ids.dtype, device=self.device).view((self.world,) + shape),
+                                  torch.empty((self.world * shape[0],), dtype=id_len.dtype, device=self.device).view(self.world, shape[0]))
+                                 for _ in range(self.slots)]
+        slot = self._n % self.slots
+        self._n += 1
+        self.drain(slot)
+        g_ids, g_len = self._bufs[shape][slot]
+        self._inflight[slot] = (dist.all_gather_into_tensor(g_ids.view((-1,) + shape[1:]), ids, group=self.group, async_op=True),
+                                dist.all_gather_into_tensor(g_len.view(-1), id_len, group=self.group, async_op=True), ids, id_len, shape)
+        self._last = (shape, slot)
+        return slot
+
+    def last(self):
+        """(ids [world, B, T'], id_len [world, B]) of the most recent submit, waited for."""
+        shape, slot = self._last
+        self.drain(slot)
+        return self._bufs[shape][slot]
+
+
 def transcribe_sharded(engine, signals, group=None, balance=True, batch_size=None):
     """Each rank transcribes its shard of ``signals`` with the fused engine; every rank returns the full list of
     transcripts in the original order.  balance=True (default): duration-balanced shards (``balanced_shards``: length
