@@ -654,16 +654,17 @@ def main():
             lp_ctc = torch.from_numpy(synth.ctc_like_log_probs(batch, lp.shape[1], cfg["labels"], words, seed=seed)).to(dev)
             ms_ctc = timed(lambda: beam_dec.decode_ids(lp_ctc, a.beam_width), max(3, a.steps // 4))
         ms_step = elapsed / a.steps * 1e3
-        extra["beam"] = {"kernel": "beam_search_kernel (one 512-thread workgroup per utterance, merge table in LDS)",
-                         "bound": "LDS latency (dependent round trips per frame)", "beam_width": a.beam_width,
+        wgs = int(_lib.lib().vasr_beam_workgroups(batch))
+        extra["beam"] = {"kernel": "beam_wave_kernel (one wavefront per utterance, four utterances per compute unit, merge table in LDS)",
+                         "bound": "instruction issue + LDS latency of one wavefront (dependent round trips per frame)", "beam_width": a.beam_width,
                          "ms_per_batch_alone": round(ms_beam, 3), "acoustic_ms_per_batch_alone": round(ms_ac, 3),
                          "ms_per_batch_on_ctc_like_posteriors": round(ms_ctc, 3) if ms_ctc else None,
                          "serial_sum_ms": round(ms_beam + ms_ac, 3),
                          # a job's LAST batch has no following acoustic pass to hide its search under: it costs the
                          # serial sum, i.e. this much more than a steady-state step
                          "last_batch_tail_ms": round(max(0.0, ms_beam + ms_ac - ms_step), 3),
-                         "workgroups": batch, "cus": n_cu,
-                         "cus_busy_frac": round(min(1.0, batch / n_cu), 3), "overlapped": not a.no_overlap, "lm": lm_info}
+                         "workgroups": wgs, "cus": n_cu,
+                         "cus_busy_frac": round(min(1.0, wgs / n_cu), 3), "overlapped": not a.no_overlap, "lm": lm_info}
     if rate != 16000 and rank == 0:
         ms_rs = timed(lambda: audio.resample(passes[0][0], passes[0][1], rate, 16000), max(3, a.steps // 4))
         in_b, out_b = passes[0][0].numel() * 4, wav16.numel() * 4

@@ -33,8 +33,9 @@ extern "C" {
 
 /* Binary interface number of this header; vasr_abi_version() returns the one the library was built from.  Bumped whenever
  * a signature or struct layout changes (4: vasr_profile_end reports five kernel classes with flops / bytes per class --
- * a caller built against the four-class form would be written past its arrays). */
-#define VASR_ABI_VERSION 4
+ * a caller built against the four-class form would be written past its arrays; 5: vasr_lm_create takes 16-byte table
+ * entries with power-of-two capacities). */
+#define VASR_ABI_VERSION 5
 
 typedef struct vasr_handle vasr_handle;
 typedef void* vasr_stream; /* hipStream_t */
@@ -227,6 +228,10 @@ VASR_API int vasr_set_busy_cus(vasr_handle* h, int cus);
  * beam_width <= 128, V+1 <= 128.  token_min_logp / beam_prune_logp: pyctcdecode defaults are -5 / -10. */
 typedef struct vasr_lm vasr_lm;
 VASR_API size_t vasr_beam_workspace_bytes(int batch, int64_t frames);
+/* Compute units a search of `batch` utterances occupies while it runs (one wavefront per utterance, four utterances per
+ * workgroup = per compute unit): what a caller that overlaps the search with the next acoustic pass hands to
+ * vasr_set_busy_cus(). */
+VASR_API int vasr_beam_workgroups(int batch);
 VASR_API int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
                          int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_workspace,
@@ -238,12 +243,18 @@ VASR_API int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row
                               int num_classes, int space_id, int beam_width, float token_min_logp,
                               float beam_prune_logp, const vasr_lm* lm, int32_t* d_ids, int32_t* d_id_len,
                               float* d_score, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
-/* Back-off n-gram model as two open-addressing hash tables (keys built with vasr_beam_hash_*; 0 = empty slot,
- * stored keys have bit 0 set): word-hash -> word id, and hash(n, id_1..id_n) -> (log10 p, log10 back-off).
- * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel. */
-VASR_API int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
-                   const float* h_nval, int ncap, int order, int bos_id, int eos_id, int unk_id, float alpha,
-                   float beta, float unk_offset, vasr_lm** out);
+/* Back-off n-gram model as two open-addressing hash tables of 16-BYTE entries (one load returns key and value), both with
+ * power-of-two capacity 2^lg >= 16, linear probing from the home slot ((uint32)(key ^ key >> 32) * 0x9E3779B1) >> (32 - lg),
+ * key 0 = empty slot, stored keys have bit 0 set:
+ *   h_vocab [vcap] {uint64 key, int32 word id, int32 0}: key = the word's label ids folded with vasr_beam_hash_step from
+ *           vasr_beam_hash_init(), first character first;
+ *   h_ngram [ncap] {uint64 key, float log10 p, float log10 back-off}: the key of (w_1 .. w_n) folds the word ids from the
+ *           LAST word backwards, hash_step(... hash_step(hash_step(init, w_n), w_{n-1}) ..., w_1) -- the keys of every suffix
+ *           of a history then come out of one chain, and the kernel requests the whole back-off walk in one trip to memory.
+ * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel.  (ABI 5; ABI 4 took four
+ * parallel arrays with odd capacities and `key % cap`.) */
+VASR_API int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, int order, int bos_id, int eos_id,
+                   int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out);
 VASR_API void vasr_lm_destroy(vasr_lm* lm);
 VASR_API uint64_t vasr_beam_hash_init(void);
 VASR_API uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v);

@@ -177,14 +177,16 @@ def masked_conv1d(x, lens, weight, stride=1, padding=0, dilation=1, groups=1):
     return F.conv1d(x, weight, None, stride, padding, dilation, groups), lens
 
 
-def _t(a):
-    return torch.as_tensor(np.asarray(a))
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    return t if dtype is None else t.to(dtype)
 
 
 def _bn_eval(x, sd, prefix):
     """nn.BatchNorm1d(C, eps=1e-3) in eval mode (parts/jasper.py:392)."""
-    return F.batch_norm(x, _t(sd[prefix + ".running_mean"]), _t(sd[prefix + ".running_var"]),
-                        _t(sd[prefix + ".weight"]), _t(sd[prefix + ".bias"]), False, 0.1, 1e-3)
+    dt = x.dtype
+    return F.batch_norm(x, _t(sd[prefix + ".running_mean"], dt), _t(sd[prefix + ".running_var"], dt),
+                        _t(sd[prefix + ".weight"], dt), _t(sd[prefix + ".bias"], dt), False, 0.1, 1e-3)
 
 
 def _first(v):
@@ -206,13 +208,13 @@ def jasper_block_forward(x, lens, sd, i, lcfg):
     for r in range(rep):
         p = f"encoder.{i}.mconv"
         if sep:
-            w = _t(sd[f"{p}.{j}.conv.weight"])
+            w = _t(sd[f"{p}.{j}.conv.weight"], x.dtype)
             out, lens = masked_conv1d(out, lens, w, stride, pad, dil, groups=w.shape[0])
-            out, lens = masked_conv1d(out, lens, _t(sd[f"{p}.{j + 1}.conv.weight"]))
+            out, lens = masked_conv1d(out, lens, _t(sd[f"{p}.{j + 1}.conv.weight"], x.dtype))
             out = _bn_eval(out, sd, f"{p}.{j + 2}")
             j += 3
         else:
-            out, lens = masked_conv1d(out, lens, _t(sd[f"{p}.{j}.conv.weight"]), stride, pad, dil)
+            out, lens = masked_conv1d(out, lens, _t(sd[f"{p}.{j}.conv.weight"], x.dtype), stride, pad, dil)
             out = _bn_eval(out, sd, f"{p}.{j + 1}")
             j += 2
         if r != rep - 1:
@@ -220,16 +222,19 @@ def jasper_block_forward(x, lens, sd, i, lcfg):
             j += 2
     if lcfg["residual"]:
         p = f"encoder.{i}.res.0"
-        res, _ = masked_conv1d(x_in, lens_orig, _t(sd[f"{p}.0.conv.weight"]))
+        res, _ = masked_conv1d(x_in, lens_orig, _t(sd[f"{p}.0.conv.weight"], x.dtype))
         res = _bn_eval(res, sd, f"{p}.1")
         out = out + res                                                        # :438-439
     return F.relu(out), lens                                                   # :444 mout
 
 
-def encoder_forward(mel, length, sd, jasper_cfg):
+def encoder_forward(mel, length, sd, jasper_cfg, dtype=torch.float32):
     """JasperEncoder.forward (jasper.py:198-204): Sequential of JasperBlocks.
-    Returns (outputs [B,C,T'] f32, encoded_lengths [B] float32 -- quirk Q3)."""
-    x = torch.as_tensor(mel, dtype=torch.float32)
+    Returns (outputs [B,C,T'] f32, encoded_lengths [B] float32 -- quirk Q3).
+    dtype=torch.float64 runs the SAME graph in double precision: not the reference's arithmetic (that is float32, the
+    default) but the reference's function without its rounding -- the tests use it to tell a frame on which two float32
+    computations may legitimately disagree (a top-2 tie inside float32 rounding) from a wrong answer."""
+    x = torch.as_tensor(mel).to(dtype)
     lens = torch.as_tensor(length)
     with torch.no_grad():
         for i, l in enumerate(jasper_cfg):
@@ -239,9 +244,11 @@ def encoder_forward(mel, length, sd, jasper_cfg):
 
 # --------------------------------------------------------------------------- A9-A11
 def decoder_forward(enc, sd):
-    """JasperDecoderForCTC.forward (jasper.py:253-254): 1x1 conv + bias -> transpose -> log_softmax."""
+    """JasperDecoderForCTC.forward (jasper.py:253-254): 1x1 conv + bias -> transpose -> log_softmax.  (Runs in the dtype of
+    `enc`: float32 = the reference's arithmetic; float64 see encoder_forward.)"""
     with torch.no_grad():
-        y = F.conv1d(torch.as_tensor(enc), _t(sd["decoder_layers.0.weight"]), _t(sd["decoder_layers.0.bias"]))
+        enc = torch.as_tensor(enc)
+        y = F.conv1d(enc, _t(sd["decoder_layers.0.weight"], enc.dtype), _t(sd["decoder_layers.0.bias"], enc.dtype))
         return F.log_softmax(y.transpose(1, 2), dim=-1)
 
 

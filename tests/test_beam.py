@@ -81,6 +81,55 @@ def test_lm_changes_the_ranking(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------- device
+def test_lm_tables_spread_their_keys_and_probe_chains_stay_short():
+    """The device n-gram tables (include/vasr.h vasr_lm_create, csrc/beam_common.h lm_home): power-of-two capacity, home slot
+    by Fibonacci hashing of the xor-folded key.  The keys are FNV-style products of SMALL word ids -- their entropy sits in
+    bits 0-24 and 40+ -- so any plain bit field clusters (round 4's first layout used bits 17.. and sent 20 000 unigrams to
+    256 home slots: every lookup walked thousands of entries, the search took seconds).  Pinned here: the builder's home
+    slots spread and no key sits more than a few dozen slots from home, for unigram-, bigram- and trigram-shaped keys."""
+    from viet_asr_amd import beam
+    h0 = np.uint64(1469598103934665603)
+    r = np.random.RandomState(0)
+    for n_words, order, count in ((20000, 1, 20000), (20000, 2, 50000), (20000, 3, 50000), (300, 2, 5000)):
+        ids = np.stack([r.randint(0, n_words, count) for _ in range(order)], 1).astype(np.uint64)
+        ids = np.unique(ids, axis=0)
+        h = np.full(len(ids), h0, dtype=np.uint64)
+        for i in reversed(range(order)):
+            h = beam._hstep_np(h, ids[:, i])
+        keys = h | np.uint64(1)
+        cap = beam._cap(len(keys))
+        assert cap & (cap - 1) == 0 and cap >= 2 * len(keys)
+        home = beam._home(keys, cap)
+        assert home.min() >= 0 and home.max() < cap
+        assert np.bincount(home, minlength=cap).max() <= 8, (n_words, order)
+        slots, where = beam._table(keys, cap)
+        assert (slots[where] == keys).all()
+        assert int(((where - home) % cap).max()) <= 48, (n_words, order)
+        # a lookup as the kernel does it: from home, linearly, until the key or an empty slot
+        for k, w, hm in list(zip(keys, where, home))[:200]:
+            i = int(hm)
+            while slots[i] != k:
+                assert slots[i] != 0
+                i = (i + 1) & (cap - 1)
+            assert i == w
+
+
+def test_reciprocal_forms_of_the_wave_kernels_integer_divisions():
+    """csrc/beam_wave.hip divides by a wave-uniform small integer through the hardware reciprocal (1 ulp): pair index ->
+    (beam, candidate) as (int)((p + 0.5f) * rcp(nc)) and candidates per pass as (int)((kFill + 0.5f) * rcp(nb)).  Replayed
+    in float32 with the reciprocal perturbed by +-2 ulp: the quotient never moves."""
+    kfill = 512 * 7 // 10
+    for d in range(1, 129):
+        inv = np.float32(1.0) / np.float32(d)
+        for ulp in (-2, -1, 0, 1, 2):
+            rcp = np.nextafter(inv, np.float32(np.inf if ulp > 0 else -np.inf)) if abs(ulp) == 1 else inv
+            if abs(ulp) == 2:
+                rcp = np.nextafter(np.nextafter(inv, np.float32(np.inf if ulp > 0 else -np.inf)), np.float32(np.inf if ulp > 0 else -np.inf))
+            p = np.arange(0, 1024, dtype=np.float32)
+            assert (((p + np.float32(0.5)) * rcp).astype(np.int32) == np.arange(1024) // d).all(), d
+            assert int((np.float32(kfill) + np.float32(0.5)) * rcp) == kfill // d, d
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_lm", [False, True])
 @pytest.mark.parametrize("beam_width,V1,seed", [(8, 29, 1), (32, 29, 2), (128, 29, 3), (20, 91, 4)])

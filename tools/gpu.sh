@@ -352,6 +352,48 @@ PY
 done
 }
 
+# ---- r4a: round 4, call A: full GPU suite (new whole-batch flip tests), default bench line, batch-1 serving-shape profile
+task_r4a() {
+set -u
+TAG=${1:-r4a}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python tools/b1_serving.py > $O/b1_vi.json 2> $O/b1_vi.err
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_15x5.json 2>> $O/b1_vi.err
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --batch 8 --no-beam > $O/b8_15x5.json 2>> $O/b1_vi.err
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b1_vi -- python $R/tools/b1_serving.py --calls 30 > /dev/null 2> $O/stats_b1_vi.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b1_15 -- python $R/tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam --calls 30 > /dev/null 2> $O/stats_b1_15.err
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+cd $R; tail -5 $O/pytest.log; cat $O/b1_vi.json $O/b1_15x5.json $O/b8_15x5.json
+}
+
+# ---- beamlat: beam-search latency of the default dev library and every var_*.so (tools/probes/beam_lat.py), table sizes from $SLOTS
+task_beamlat() {
+cd $R
+for f in dev $R/viet-asr_amd/lib/var_*.so; do
+  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
+  case $f in
+    *prof*|*p.so) echo "== $(basename $f) (section cycle counters, one launch per case)"
+        ONCE=1 BATCHES=1 WIDTHS=${PROF_WIDTHS:-50,100} python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu | grep -E "prof|/B1/" ;;
+    *) for s in ${SLOTS:-auto}; do
+         [ $s = auto ] && unset VASR_BEAM_SLOTS || export VASR_BEAM_SLOTS=$s
+         echo "== $(basename $f) slots $s"; python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
+       done; unset VASR_BEAM_SLOTS ;;
+  esac
+done
+unset VASR_LIB_PATH
+if [ -n "${FUZZ:-}" ]; then
+  for f in $R/viet-asr_amd/lib/var_*.so; do
+    case $f in *prof*|*p.so) continue ;; esac
+    echo "== fuzz $(basename $f)"; VASR_LIB_PATH=$f timeout 600 python tests/devtools/fuzz_beam.py $FUZZ 0 2>&1 | tail -1
+  done
+fi
+}
+
 # ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them
 task_probes() {
 cd $R/tools/probes

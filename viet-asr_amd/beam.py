@@ -50,18 +50,26 @@ def _hstep_np(h, v):
         return (h ^ (v.astype(np.uint64) + np.uint64(1))) * np.uint64(_FNV_PRIME)
 
 
+def _home(keys, cap):
+    """Home slot of a key in a table of 2^lg slots: Fibonacci hashing of the xor-folded key.  (The keys are FNV-style
+    products of small word ids; a plain bit field of them clusters badly.)"""
+    lg = int(cap).bit_length() - 1
+    f = (keys ^ (keys >> np.uint64(32))) & np.uint64(0xFFFFFFFF)
+    return (((f * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(32 - lg)).astype(np.int64)
+
+
 def _table(keys, cap):
-    """Open-addressing table the kernel probes linearly from ``key % cap`` (csrc/beam.hip lm_find): returns (slots
-    [cap] u64, position of every key).  Built in vectorised rounds -- a pure-Python insert loop takes minutes on the
+    """Open-addressing table the kernels probe linearly from ``_home(key, cap)`` (csrc/beam_common.h lm_home): returns
+    (slots [cap] u64, position of every key).  Built in vectorised rounds -- a pure-Python insert loop takes minutes on the
     multi-million-entry models the reference ships (.MISSING_LARGE_BLOBS:4-7): in round r every unplaced key looks at
-    slot (home + r) % cap; one key per free slot wins, the others move on.  A key only ever steps over slots that are
-    occupied for good, so every probe chain from a key's home to its slot is gap-free, which is all lookup needs."""
+    slot (home + r) & (cap - 1); one key per free slot wins, the others move on.  A key only ever steps over slots that
+    are occupied for good, so every probe chain from a key's home to its slot is gap-free, which is all lookup needs."""
     keys = np.asarray(keys, dtype=np.uint64) | np.uint64(1)
     if len(np.unique(keys)) != len(keys):
         raise ValueError("64-bit hash collision while building the n-gram tables")
     slots = np.zeros(cap, dtype=np.uint64)
     where = np.full(len(keys), -1, dtype=np.int64)
-    pos = (keys % np.uint64(cap)).astype(np.int64)
+    pos = _home(keys, cap)
     todo = np.arange(len(keys))
     while len(todo):
         p = pos[todo]
@@ -72,15 +80,19 @@ def _table(keys, cap):
         slots[pos[win]] = keys[win]
         where[win] = pos[win]
         todo = todo[where[todo] < 0]
-        pos[todo] = (pos[todo] + 1) % cap
+        pos[todo] = (pos[todo] + 1) & (cap - 1)
     return slots, where
 
 
 def _cap(n):
+    """Power-of-two capacity, load <= 50 %."""
     c = 16
     while c < 2 * n + 1:
         c *= 2
-    return c + 1  # odd capacity: the kernel probes with `hash % cap`
+    return c
+
+
+_ENTRY = np.dtype([("key", "<u8"), ("a", "<u4"), ("b", "<u4")])      # 16-byte table entry (include/vasr.h)
 
 
 class DeviceLM:
@@ -111,9 +123,11 @@ class DeviceLM:
             vvals.append(wid[w])
         vcap = _cap(len(vkeys))
         vslots, vwhere = _table(vkeys, vcap)
-        vid = np.full(vcap, -1, dtype=np.int32)
-        vid[vwhere] = np.asarray(vvals, dtype=np.int32)
-        # n-gram keys: hash(n, id_1 .. id_n), one vectorised pass per order
+        vocab = np.zeros(vcap, dtype=_ENTRY)
+        vocab["key"] = vslots
+        vocab["a"][vwhere] = np.asarray(vvals, dtype=np.int32).view(np.uint32)
+        # n-gram keys: the word ids folded from the LAST word backwards (the keys of every suffix of a history then come
+        # out of one chain on the device), one vectorised pass per order
         by_n = {}
         for ng, pb in ngrams.items():
             by_n.setdefault(len(ng), ([], []))
@@ -122,8 +136,8 @@ class DeviceLM:
         nkeys, nvals = [], []
         for n, (ids, pbs) in sorted(by_n.items()):
             ids = np.asarray(ids, dtype=np.uint64).reshape(len(ids), n)
-            h = _hstep_np(np.full(len(ids), h0, dtype=np.uint64), np.full(len(ids), n, dtype=np.uint64))
-            for i in range(n):
+            h = np.full(len(ids), h0, dtype=np.uint64)
+            for i in reversed(range(n)):
                 h = _hstep_np(h, ids[:, i])
             nkeys.append(h)
             nvals.append(np.asarray(pbs, dtype=np.float32).reshape(len(ids), 2))
@@ -131,14 +145,15 @@ class DeviceLM:
         nvals = np.concatenate(nvals) if nvals else np.zeros((0, 2), dtype=np.float32)
         ncap = _cap(len(nkeys))
         nslots, nwhere = _table(nkeys, ncap)
-        nval = np.zeros((ncap, 2), dtype=np.float32)
-        nval[nwhere] = nvals
+        ngram = np.zeros(ncap, dtype=_ENTRY)
+        ngram["key"] = nslots
+        ngram["a"][nwhere] = nvals[:, 0].view(np.uint32)
+        ngram["b"][nwhere] = nvals[:, 1].view(np.uint32)
         self.order, self.n_words, self.n_ngrams = order, len(words), len(ngrams)
         self.table_load = len(nkeys) / ncap
         self._h = C.c_void_p()
-        _lib.check(L.vasr_lm_create(vslots.ctypes.data, vid.ctypes.data, vcap, nslots.ctypes.data, nval.ctypes.data,
-                                    ncap, order, wid["<s>"], wid["</s>"], wid["<unk>"], float(alpha), float(beta),
-                                    float(unk_offset), C.byref(self._h)))
+        _lib.check(L.vasr_lm_create(vocab.ctypes.data, vcap, ngram.ctypes.data, ncap, order, wid["<s>"], wid["</s>"],
+                                    wid["<unk>"], float(alpha), float(beta), float(unk_offset), C.byref(self._h)))
 
     @property
     def handle(self):

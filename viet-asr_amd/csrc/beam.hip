@@ -29,38 +29,22 @@
 #include <type_traits>
 
 #include "vasr_internal.h"
+#include "beam_common.h"
 
 namespace vasr {
 
 namespace {
+using namespace beam_detail;
 
 #ifndef VASR_BEAM_THREADS
 #define VASR_BEAM_THREADS 512
 #endif
 constexpr int kThreads = VASR_BEAM_THREADS;   // workgroup size: 256, 512 or 1024
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxBeams = 128;
 // Merge-table slots: a template parameter of the kernel (a power of two, a multiple of the workgroup size), chosen per
 // launch from the beam width -- clearing and sweeping the table is a fixed cost per frame, so a narrow beam is faster with a
 // small table and a wide one with few passes (launch_beam_search).  kMaxFill(slots) pairs per pass keep it <= 70 % full.
 constexpr int max_fill(int slots) { return slots * 7 / 10; }   // 1433 at 2048 slots
-constexpr int kMaxClasses = 128;
-constexpr int kMaxCtx = 4;      // LM order <= 5
-constexpr unsigned long long kFnvOffset = 1469598103934665603ull, kFnvPrime = 1099511628211ull;
-constexpr double kFix = 17592186044416.0;  // 2^44
-
-__host__ __device__ inline unsigned long long hmix(unsigned long long h, unsigned long long v) {
-  return (h ^ (v + 1)) * kFnvPrime;
-}
-__device__ inline long long ord64(double d) {  // order-preserving map double -> signed 64
-  long long b = __double_as_longlong(d);
-  return b >= 0 ? b : (long long)(0x8000000000000000ull ^ (unsigned long long)~b) ;
-}
-__device__ inline double unord64(long long o) {
-  long long b = o >= 0 ? o : (long long)~(0x8000000000000000ull ^ (unsigned long long)o);
-  return __longlong_as_double(b);
-}
-
 struct Beam {
   unsigned long long key;    // hash of the prefix characters, committed spaces included
   unsigned long long whash;  // rolling hash of the current partial word (label ids)
@@ -83,158 +67,11 @@ struct Slots {
 };
 constexpr size_t slot_bytes(int slots) { return (size_t)slots * (8 + 8 + 8 + 4); }
 
-struct LmView {
-  const unsigned long long* vkey; const int* vid; int vcap;
-  const unsigned long long* nkey; const float2* nval; int ncap;
-  int order, bos, eos, unk;
-  float alpha, beta, unk_offset;
-};
-
-__device__ int lm_word_id(const LmView& lm, unsigned long long whash) {
-  unsigned long long k = whash | 1ull;
-  for (int i = (int)(k % (unsigned)lm.vcap), n = 0; n < lm.vcap; ++n, i = (i + 1 == lm.vcap ? 0 : i + 1)) {
-    const unsigned long long e = lm.vkey[i];
-    if (e == k) return lm.vid[i];
-    if (e == 0) break;
-  }
-  return -1;  // out of vocabulary
-}
-
-__device__ bool lm_find(const LmView& lm, const int* ids, int n, float2* out) {
-  unsigned long long k = hmix(kFnvOffset, (unsigned long long)n);
-  for (int i = 0; i < n; ++i) k = hmix(k, (unsigned long long)ids[i]);
-  k |= 1ull;
-  for (int i = (int)(k % (unsigned)lm.ncap), c = 0; c < lm.ncap; ++c, i = (i + 1 == lm.ncap ? 0 : i + 1)) {
-    const unsigned long long e = lm.nkey[i];
-    if (e == k) { *out = lm.nval[i]; return true; }
-    if (e == 0) break;
-  }
-  return false;
-}
-
-// KenLM BaseScore on a full history: log10 p(w | ctx) with back-off.
-__device__ float lm_base_score(const LmView& lm, const int* ctx, int w) {
-  int ids[kMaxCtx + 1];
-  int n = 0;
-  for (int i = 0; i < kMaxCtx; ++i)
-    if (ctx[i] >= 0 && kMaxCtx - i <= lm.order - 1) ids[n++] = ctx[i];
-  ids[n] = w;
-  float score = 0.f;
-  int start = 0;
-  while (true) {
-    float2 v;
-    if (lm_find(lm, ids + start, n - start + 1, &v)) { score += v.x; break; }
-    if (start == n) {  // unigram missing: fall back to <unk>
-      int u = lm.unk;
-      if (lm_find(lm, &u, 1, &v)) score += v.x; else score += -100.f;
-      break;
-    }
-    if (lm_find(lm, ids + start, n - start, &v)) score += v.y;  // back-off weight of the context
-    ++start;
-  }
-  return score;
-}
-
-// pyctcdecode LanguageModel.score (alpha * log10 * ln10 + beta, OOV offset, optional </s>)
-__device__ float lm_word_score(const LmView& lm, const int* ctx, unsigned long long whash, bool eos, int* wid_out) {
-  int wid = lm_word_id(lm, whash);
-  const bool oov = wid < 0;
-  if (oov) wid = lm.unk;
-  float s = lm_base_score(lm, ctx, wid);
-  if (oov) s += lm.unk_offset;
-  if (eos) {
-    int c2[kMaxCtx];
-    for (int i = 0; i < kMaxCtx - 1; ++i) c2[i] = ctx[i + 1];
-    c2[kMaxCtx - 1] = wid;
-    s += lm_base_score(lm, c2, lm.eos);
-  }
-  *wid_out = wid;
-  return lm.alpha * s * 2.302585092994046f + lm.beta;
-}
-
-__device__ inline float partial_penalty(float unk_offset, int wlen) {
-  if (wlen <= 0) return 0.f;
-  float u = unk_offset;                    // no character trie: every partial word is OOV (is_oov = 1.0)
-  if (wlen > 6) u = u * (float)wlen / 6.0f;
-  return u;
-}
-
-// log(r) for r in [1, 2^20): exponent split + atanh series (10 odd terms at |s| <= 0.1716: < 1e-16 relative).
-// The library log costs ~2400 cycles per wavefront here, every merged prefix needs one per frame.
-__device__ inline double log_ge1(double r) {
-  long long bits = __double_as_longlong(r);
-  int e = (int)((bits >> 52) & 0x7ff) - 1023;
-  double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);   // [1, 2)
-  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }                                         // [0.7071, 1.4142]
-  // 1/(m+1): hardware estimate + two Newton steps (full IEEE division is ~25 fp64 instructions, 8 cycles each)
-  const double d = m + 1.0;
-  double r1 = __builtin_amdgcn_rcp(d);
-  r1 = fma(fma(-d, r1, 1.0), r1, r1);
-  r1 = fma(fma(-d, r1, 1.0), r1, r1);
-  const double s = (m - 1.0) * r1, z = s * s;
-  double p = 1.0 / 21.0;
-  p = fma(p, z, 1.0 / 19.0); p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0); p = fma(p, z, 1.0);
-  return fma((double)e, 0.6931471805599453, 2.0 * s * p);
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it
 // waits for the back-pointer stores of the previous frame to be acknowledged and for the prefetched log-prob row
 // to arrive -- a full HBM round trip per frame that nothing in the workgroup depends on.
 __device__ inline void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Wavefront-wide inclusive scan / max on the DPP data path (row shifts + row broadcasts, ~20 VALU instructions).
-// The __shfl_up / __shfl_xor forms go through ds_bpermute: six dependent LDS round trips, ~700 cycles per scan, and
-// the frame loop runs five or more of them.
-template <int CTRL>
-__device__ inline int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-
-__device__ inline int wave_scan_incl(int v) {
-  const int lane = threadIdx.x & 63, rl = lane & 15;
-  int x = v, t;
-  t = dpp_mov<0x111>(x); if (rl >= 1) x += t;              // row_shr:1
-  t = dpp_mov<0x112>(x); if (rl >= 2) x += t;              // row_shr:2
-  t = dpp_mov<0x114>(x); if (rl >= 4) x += t;              // row_shr:4
-  t = dpp_mov<0x118>(x); if (rl >= 8) x += t;              // row_shr:8
-  t = dpp_mov<0x142>(x); if ((lane & 31) >= 16) x += t;    // row_bcast:15
-  t = dpp_mov<0x143>(x); if (lane >= 32) x += t;           // row_bcast:31
-  return x;
-}
-
-__device__ inline unsigned wave_max_u32(unsigned v) {
-  const int lane = threadIdx.x & 63, rl = lane & 15;
-  unsigned x = v, t;
-  t = (unsigned)dpp_mov<0x111>((int)x); if (rl >= 1) x = max(x, t);
-  t = (unsigned)dpp_mov<0x112>((int)x); if (rl >= 2) x = max(x, t);
-  t = (unsigned)dpp_mov<0x114>((int)x); if (rl >= 4) x = max(x, t);
-  t = (unsigned)dpp_mov<0x118>((int)x); if (rl >= 8) x = max(x, t);
-  t = (unsigned)dpp_mov<0x142>((int)x); if ((lane & 31) >= 16) x = max(x, t);
-  t = (unsigned)dpp_mov<0x143>((int)x); if (lane >= 32) x = max(x, t);
-  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
-
-__device__ inline unsigned wave_or_u32(unsigned v) {
-  const int lane = threadIdx.x & 63, rl = lane & 15;
-  unsigned x = v, t;
-  t = (unsigned)dpp_mov<0x111>((int)x); if (rl >= 1) x |= t;
-  t = (unsigned)dpp_mov<0x112>((int)x); if (rl >= 2) x |= t;
-  t = (unsigned)dpp_mov<0x114>((int)x); if (rl >= 4) x |= t;
-  t = (unsigned)dpp_mov<0x118>((int)x); if (rl >= 8) x |= t;
-  t = (unsigned)dpp_mov<0x142>((int)x); if ((lane & 31) >= 16) x |= t;
-  t = (unsigned)dpp_mov<0x143>((int)x); if (lane >= 32) x |= t;
-  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
-
-// max of a signed 64-bit value over the wavefront: high words first, then the low words of the lanes that tie
-__device__ inline long long wave_max_i64(long long v) {
-  const unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ull;
-  const unsigned hi = (unsigned)(u >> 32), lo = (unsigned)u;
-  const unsigned hmax = wave_max_u32(hi);
-  const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
-  return (long long)((((unsigned long long)hmax << 32) | lmax) ^ 0x8000000000000000ull);
 }
 
 // Exclusive scan over the workgroup with ONE barrier: the per-wavefront totals go to one of two scratch rows that
@@ -757,7 +594,7 @@ size_t beam_lds_bytes(int slots) {
 // 3.43 / 3.91 / 5.20 / 6.28.  (512 slots: another 5-7 % at beam <= 20, but 1.5x slower there on flat posteriors.)
 int beam_slots_for(int beam_width) {
   static const int forced = dev_env("VASR_BEAM_SLOTS") ? atoi(dev_env("VASR_BEAM_SLOTS")) : 0;
-  if (forced == 1024 || forced == 2048) return forced;
+  if (forced == 512 || forced == 1024 || forced == 2048) return forced;
   return beam_width > 64 ? 2048 : 1024;
 }
 
@@ -770,8 +607,9 @@ int launch_beam_search(const float* logp, int batch, int frames, int V1, int spa
   int use_lm = 0;
   if (lm) {
     use_lm = 1;
-    v.vkey = lm->vkey; v.vid = lm->vid; v.vcap = lm->vcap; v.nkey = lm->nkey;
-    v.nval = reinterpret_cast<const float2*>(lm->nval); v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
+    v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
+    v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
+    v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
     v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
   }
   auto go = [&](auto slots_tag) -> int {
@@ -784,7 +622,11 @@ int launch_beam_search(const float* logp, int batch, int frames, int V1, int spa
                        token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len, out_score);
     return 0;
   };
-  if (beam_slots_for(beam_width) == 1024) return go(std::integral_constant<int, 1024>{});
+  const int slots = beam_slots_for(beam_width);
+#ifdef VASR_DEVTOOLS
+  if (slots == 512 && kThreads <= 512) return go(std::integral_constant<int, 512>{});
+#endif
+  if (slots == 1024) return go(std::integral_constant<int, 1024>{});
   return go(std::integral_constant<int, 2048>{});
 }
 

@@ -1,0 +1,750 @@
+// CTC prefix beam search with optional back-off n-gram LM: ONE WAVEFRONT PER UTTERANCE (gfx950).
+//
+// Replaces BeamSearchDecoderWithLM.forward (reference nemo/collections/asr/beam_search_decoder.py:95-102), which hands
+// exp(log_probs[0]) to pyctcdecode on the host, one utterance at a time -- batch 1, beam width 50 (app.py:27) or 100
+// (infer.py:191) is the shape the reference SERVES.  pyctcdecode / kenlm are third-party and absent (parity unpinned);
+// the algorithm restated here is oracle/beam_oracle.py (file header there).
+//
+// Rounds 1-3 ran one 512-thread workgroup per utterance (beam.hip, kept in the devtools build): every frame crossed
+// ~20 workgroup barriers and every one of its eight wavefronts executed the whole ~5 000-instruction frame program --
+// 13 us per general frame although a frame of a pruned search has 30-150 (beam, character) pairs, less than one per
+// thread: the time was instruction issue and barrier latency, replicated eight times, not work.  This kernel gives an
+// utterance to ONE wavefront: no s_barrier anywhere (LDS operations of one wavefront execute in order), scans,
+// reductions and ranks are ballots / DPP, every per-frame cost is proportional to the pairs and merged prefixes the
+// frame really has (claimed table slots go on a list: nothing sweeps or clears the whole table), the log-probs of the
+// next frames are prefetched four deep, the LM score of a pending word is computed once per (text, word) lineage and
+// inherited, and the final trace-back walks the back-pointer rows through LDS in batches instead of one dependent HBM
+// round trip per frame.  An utterance needs 34 KB of LDS and 1 of the 16 wavefront slots a compute unit has, so four
+// utterances share a CU (one workgroup of `upw` independent wavefronts): a batch of 64 occupies 16 compute units instead
+// of 64 while the acoustic pass of the next batch runs on the rest.
+//
+// Per frame:
+//   1. candidate characters {c : logp >= token_min_logp} U {argmax}: ballots (lane = class, two classes per lane);
+//      a frame whose only candidate is blank, met by beams that all end in blank, shifts every score by the same
+//      amount and changes nothing else: add, write an identity back-pointer row, next frame;
+//   2. every (beam, character) pair is hashed -- key = hash(prefix string incl. committed spaces, last character) --
+//      into an LDS open-addressing table where identical prefixes MERGE by log-sum-exp (fp64 max via ordered-int
+//      atomicMax, then a 2^-44 fixed-point atomicAdd of exp(score - max): associative, hence deterministic).  A frame
+//      with more pairs than the table takes (flat posteriors) runs its candidates in several PASSES -- pairs of
+//      different candidates never merge (the key carries the candidate), the survivors of the earlier passes are
+//      carried in registers into the next pass's selection (top-k of a union = top-k of the partial top-ks);
+//   3. every merged prefix gets its combined score: a word committed by ' ' is scored with the n-gram LM (hashed
+//      tables in HBM, back-off walk), partial words get pyctcdecode's OOV penalty; prefixes below max-10 are dropped;
+//      the top `beam_width` are kept by a radix select on the ordered bits of the combined score (8-bit digits; skipped
+//      when everything that survived the prune fits, which is the usual case);
+//   4. survivors become the new beams (parent fields gathered from LDS), one back-pointer row per frame.
+#include <cstdlib>
+
+#include "beam_common.h"
+
+namespace vasr {
+
+namespace {
+using namespace beam_detail;
+
+constexpr int kTab = 512;                 // merge-table slots per utterance
+constexpr int kFill = kTab * 7 / 10;      // pairs per pass (<= 70 % load)
+constexpr int kTbRows = 12;               // back-pointer rows per trace-back batch (6 KB, two batches in LDS)
+constexpr int kLpFrames = 8;              // frames of log-probs per staging batch
+constexpr int kLpRegs = kLpFrames * kMaxClasses / 64;   // floats a lane holds of the batch in flight
+constexpr int kChars = 3072;              // characters of a transcript assembled in LDS (longer ones go through HBM)
+
+// One utterance's working set in LDS.
+struct WaveLds {
+  // beams, two buffers that swap roles every frame (structure of arrays: lanes read consecutive words)
+  unsigned long long key[2][kMaxBeams];    // hash of the prefix characters, committed spaces included
+  unsigned long long whash[2][kMaxBeams];  // rolling hash of the pending word (label ids)
+  double logit[2][kMaxBeams];
+  float lm_text[2][kMaxBeams];             // LM score of the committed words
+  // (last + 1) [7:0] (0 = none, blank = V + 1) | wlen [23:8] | cached [24] | commit_valid [25]
+  unsigned int meta[2][kMaxBeams];
+  int ctx[2][kMaxBeams][kMaxCtx];          // LM history, most recent last, -1 = empty
+  float commit_lmd[2][kMaxBeams];          // LM score the pending word gets when ' ' commits it (valid: meta bit 25)
+  int commit_wid[2][kMaxBeams];            // its word id
+  // merge table:  tkey 0 = empty;  tmx ordered bits of the max score, later of the combined score;
+  //               tsum fixed-point sum of exp(score - max), later the bits of the merged logit;  tsrc (beam << 8) | class
+  unsigned long long tkey[kTab];
+  long long tmx[kTab];
+  unsigned long long tsum[kTab];
+  int tsrc[kTab];
+  unsigned short list[kFill + 2];          // claimed slots, in claim order
+  unsigned short pair_slot[kFill + 2];     // slot of pair p
+  // survivors of a pass, by rank
+  long long sel_lgt[kMaxBeams], sel_tot[kMaxBeams];
+  int sel_src[kMaxBeams];
+  double lp[kMaxClasses];
+  unsigned long long cmix[kMaxClasses];    // per-class constant folded into a pair's key (the "last character" part)
+  float lpq[kLpFrames * kMaxClasses];      // log-probs of the current batch of frames, [frame][class] as in memory
+  unsigned char cand[kMaxClasses];
+  int hist[256];
+};
+static_assert(sizeof(WaveLds) * 4 <= 160 * 1024, "four utterances per compute unit");
+static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
+static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
+
+constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25;
+__device__ inline int meta_last(unsigned m) { return (int)(m & 0xffu) - 1; }
+__device__ inline int meta_wlen(unsigned m) { return (int)((m >> 8) & 0xffffu); }
+__device__ inline unsigned make_meta(int last, int wlen, unsigned flags) {
+  return (unsigned)(last + 1) | ((unsigned)min(wlen, 0xffff) << 8) | flags;
+}
+
+// Orders the LDS traffic of the wavefront's phases for the COMPILER (the hardware executes one wavefront's LDS
+// operations in order): lanes read what other lanes of the same wavefront wrote, which per-thread alias analysis
+// cannot see.
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ inline int rank_in(unsigned long long mask) {   // set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ inline int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
+
+// grid (ceil(B / upw)), block 64 * upw: wavefront w of workgroup g searches utterance g * upw + w, alone
+__global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict__ logp, int batch, int frames_ld,
+                                                        const int32_t* __restrict__ row_frames, int V1, int space_id,
+                                                        int beam_width, float token_min_logp, float beam_prune_logp,
+                                                        LmView lm, int use_lm, unsigned int* __restrict__ bp_all,
+                                                        unsigned long long* __restrict__ eoslog_all,
+                                                        int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
+                                                        float* __restrict__ out_score) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+  const int b = (int)blockIdx.x * (int)(blockDim.x >> 6) + wv;
+  if (b >= batch) return;                                   // (no barrier anywhere below: a wavefront may leave)
+  WaveLds& S = *reinterpret_cast<WaveLds*>(smem + (size_t)wv * sizeof(WaveLds));
+  const int V = V1 - 1;
+  const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
+  const float* lrow = logp + (int64_t)b * frames_ld * V1;
+  unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
+  // pyctcdecode's LM score cache, as its key set (see step 2b): hash of "text + pending word" of every beam that met a
+  // frame with ' ' among the candidates, once per lineage
+  unsigned long long* eoslog = eoslog_all + (int64_t)b * frames_ld * kMaxBeams;
+
+
+  // ---- empty table, one beam: the empty prefix ----
+  for (int i = lane; i < kTab; i += 64) { S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0; }
+  for (int c = lane; c < kMaxClasses; c += 64) S.cmix[c] = hmix(hmix(kFnvOffset, (unsigned long long)(c + 7)), 0x9e3779b9ull);
+  if (lane == 0) {
+    S.key[0][0] = kFnvOffset; S.whash[0][0] = kFnvOffset; S.logit[0][0] = 0.0; S.lm_text[0][0] = 0.f;
+    S.meta[0][0] = make_meta(-1, 0, 0);
+    for (int i = 0; i < kMaxCtx; ++i) S.ctx[0][0][i] = -1;
+    if (use_lm) S.ctx[0][0][kMaxCtx - 1] = lm.bos;
+    S.commit_lmd[0][0] = 0.f; S.commit_wid[0][0] = 0;
+  }
+  wave_sync();
+  int cur = 0, nb = 1, n_log = 0;
+  bool all_blank = false;      // every live beam ends in blank (uniform)
+#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals and work counters of utterance 0 (tools/probes/beam_lat.py, ONCE=1)
+  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = (long long)__builtin_readcyclecounter();
+  long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // general frames, pairs, merged entries, passes, radix digit passes, LM scorings, select frames
+#define WTICK(k) { const long long now_ = (long long)__builtin_readcyclecounter(); prof[k] += now_ - pt; pt = now_; }
+#define WCOUNT(k, v) cnt[k] += (v);
+#else
+#define WTICK(k)
+#define WCOUNT(k, v)
+#endif
+
+  // Log-probs reach the frames through LDS, kLpFrames frames per batch (a contiguous run of kLpFrames * V1 floats), and
+  // the batch after the current one is already on its way in registers: a per-frame prefetch does not work here --
+  // s_waitcnt vmcnt counts in order, so waiting for the frame requested four frames ago also waits for the request just
+  // issued (and for the back-pointer stores): one full HBM round trip per frame (1 700 of 14 600 cycles, measured).
+  float q[kLpRegs];
+  const int lp_batch = kLpFrames * V1;                        // floats per batch
+  auto lp_request = [&](int t0) {
+    const int64_t base = (int64_t)t0 * V1;
+    const int n = max(0, min(lp_batch, (frames - t0) * V1));
+#pragma unroll
+    for (int k = 0; k < kLpRegs; ++k) { const int f = 64 * k + lane; q[k] = f < n ? lrow[base + f] : 0.f; }
+  };
+  lp_request(0);
+
+  for (int t = 0; t < frames; ++t) {
+    // ---- 1. log-probs (pyctcdecode: log(clip(p, 1e-15, 1)) = clip(x, log 1e-15, 0)) and candidate characters ----
+    const int c0 = lane, c1 = lane + 64;
+    if ((t & (kLpFrames - 1)) == 0) {                        // batch boundary: land the batch in LDS, request the next one
+#pragma unroll
+      for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) S.lpq[64 * k + lane] = q[k];
+      lp_request(t + kLpFrames);
+      wave_sync();
+    }
+    const float* lq = S.lpq + (t & (kLpFrames - 1)) * V1;
+    const float x0 = c0 < V1 ? lq[c0] : 0.f, x1 = c1 < V1 ? lq[c1] : 0.f;
+    const double d0 = fmin(fmax((double)x0, -34.538776394910684), 0.0);
+    const double d1 = fmin(fmax((double)x1, -34.538776394910684), 0.0);
+    if (c0 < V1) S.lp[c0] = d0;
+    if (c1 < V1) S.lp[c1] = d1;
+    const float v0 = c0 < V1 ? (float)d0 : 0.f, v1 = c1 < V1 ? (float)d1 : 0.f;
+    auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
+    const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+    const unsigned kmax = wave_max_u32(max(key0, key1));
+    const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+    const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
+    const bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
+    const bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    if (k0) S.cand[rank_in(m0)] = (unsigned char)c0;
+    if (k1) S.cand[__popcll(m0) + rank_in(m1)] = (unsigned char)c1;
+    const int nc_all = __popcll(m0) + __popcll(m1);
+    const bool has_space = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
+    const bool only_blank = nc_all == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
+    wave_sync();
+    WTICK(0)
+
+    // A frame whose only candidate is blank, met by beams that all end in blank already, changes nothing but the
+    // scores, and those by the same amount: prefixes and last characters stay distinct (no merge), the LM parts and
+    // every score difference stay what the previous frame's prune and selection saw.  A trained CTC model emits long
+    // runs of such frames; the first of a run goes the general way (beams that differ only in their last character
+    // merge there).  logit + lp is the sum the general path would have stored.
+    if (only_blank && all_blank) {
+      const double add = S.lp[V];
+      for (int i = lane; i < nb; i += 64) {
+        S.logit[cur][i] += add;
+        bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
+      }
+      wave_sync();
+      WTICK(1)
+      continue;
+    }
+    WCOUNT(0, 1)
+
+    // ---- 2b. this frame puts "text + pending word" of every live beam into pyctcdecode's LM score cache ----
+    if (use_lm && has_space) {
+      for (int i0 = 0; i0 < nb; i0 += 64) {
+        const int i = i0 + lane;
+        bool put = false;
+        unsigned long long h = 0;
+        if (i < nb) {
+          const unsigned m = S.meta[cur][i];
+          put = meta_wlen(m) > 0 && !(m & kMetaCached);
+          h = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+        }
+        const unsigned long long pm = __ballot(put);
+        if (put) eoslog[n_log + rank_in(pm)] = h;
+        n_log += __popcll(pm);
+      }
+    }
+
+    // candidates per pass: nb * cap pairs fit the merge table.  kFill / nb through the hardware reciprocal: the quotient's
+    // fraction is >= 0.5 / 128 away from an integer boundary, the reciprocal is good to 1e-7 (tests replay both forms)
+    const int cap = max(1, (int)(((float)kFill + 0.5f) * __builtin_amdgcn_rcpf((float)nb)));
+    // survivors carried from the earlier passes of this frame: ranks lane and lane + 64
+    long long c_tot[2] = {ord64(-1e300), ord64(-1e300)}, c_lgt[2] = {0, 0};
+    int c_src[2] = {0, 0};
+    int n_sel = 0;
+#pragma unroll 1
+    for (int c_lo = 0; c_lo < nc_all; c_lo += cap) {
+      const int nc = min(cap, nc_all - c_lo);
+      const int npairs = nb * nc;
+      const float inv_nc = __builtin_amdgcn_rcpf((float)nc);
+      WCOUNT(1, npairs) WCOUNT(3, 1)
+      WTICK(2)
+      // ---- 2. expand: every (beam, character) pair claims / finds its slot and raises the slot's max ... ----
+      int n_list = 0;
+#pragma unroll 1
+      for (int p0 = 0; p0 < npairs; p0 += 64) {
+        const int p = p0 + lane;
+        bool claimed = false;
+        int slot = 0;
+        if (p < npairs) {
+          const int bi = (int)(((float)p + 0.5f) * inv_nc);          // p / nc (exact: tests/test_beam.py replays it)
+          const int c = S.cand[c_lo + p - bi * nc];
+          const unsigned m = S.meta[cur][bi];
+          const int last = meta_last(m);
+          unsigned long long key = S.key[cur][bi];
+          // the prefix grows unless the character is blank, a repeat, or a space with no word pending -- one multiply,
+          // no branches; the "last character" part of the key is a per-class constant (S.cmix)
+          const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
+          const unsigned long long kx = hmix(key, (unsigned long long)c);
+          key = grows ? kx : key;
+          const unsigned long long k = (key ^ S.cmix[c]) | 1ull;                        // (prefix, last char)
+          // home slot and probe stride from the upper bits (bit 0 of k is forced to 1); an odd stride visits every slot
+          // of the power-of-two table: double hashing, no primary clustering
+          int i = (int)((k >> 17) & (kTab - 1));
+          const int stride = (int)((k >> 40) & (kTab - 1)) | 1;
+          while (true) {
+            const unsigned long long e = S.tkey[i];
+            if (e == k) break;
+            if (e == 0) {
+              const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
+              if (old == 0ull) { S.tsrc[i] = (bi << 8) | c; claimed = true; break; }
+              if (old == k) break;
+            }
+            i = (i + stride) & (kTab - 1);
+          }
+          atomicMax(&S.tmx[i], ord64(S.logit[cur][bi] + S.lp[c]));
+          S.pair_slot[p] = (unsigned short)i;
+          slot = i;
+        }
+        const unsigned long long cm = __ballot(claimed);
+        if (claimed) S.list[n_list + rank_in(cm)] = (unsigned short)slot;
+        n_list += __popcll(cm);
+      }
+      wave_sync();
+      WTICK(3)
+      WCOUNT(2, n_list)
+      // ---- ... then adds exp(score - max): hardware 2^x on a float (1 ulp); exp2(0) is exactly 1, so a slot with a
+      //      single contributor holds exactly 2^44 ----
+#pragma unroll 1
+      for (int p = lane; p < npairs; p += 64) {
+        const int bi = (int)(((float)p + 0.5f) * inv_nc);
+        const int c = S.cand[c_lo + p - bi * nc];
+        const int i = S.pair_slot[p];
+        const double score = S.logit[cur][bi] + S.lp[c];
+        const float e = __builtin_amdgcn_exp2f((float)((score - unord64(S.tmx[i])) * 1.4426950408889634));
+        atomicAdd(&S.tsum[i], (unsigned long long)((double)e * kFix));
+      }
+      wave_sync();
+      WTICK(4)
+      // ---- 3. merged prefixes: LM score of a committed word, combined score, running maximum ----
+      long long my_best = max(c_tot[0], c_tot[1]);
+#pragma unroll 1
+      for (int e0 = 0; e0 < n_list; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < n_list) {
+          const int i = S.list[e];
+          const int src = S.tsrc[i], bi = src >> 8, c = src & 255;
+          float lmt = 0.f;
+          if (use_lm) {
+            unsigned m = S.meta[cur][bi];
+            const int last = meta_last(m), wlen = meta_wlen(m);
+            const bool stay = (c == V || c == last);
+            const bool commit = !stay && c == space_id && wlen > 0;
+            const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
+            lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new);
+            if (commit) {
+              // computed once per (text, word): children that keep both inherit it (build step); (bi, ' ') is one
+              // table entry, so this lane is the only writer of beam bi's cache
+              if (!(m & kMetaCommit)) {
+                int ctx[kMaxCtx];
+#pragma unroll
+                for (int q = 0; q < kMaxCtx; ++q) ctx[q] = S.ctx[cur][bi][q];
+                int w;
+                const float s = lm_word_score(lm, ctx, S.whash[cur][bi], false, &w);
+                S.commit_lmd[cur][bi] = s; S.commit_wid[cur][bi] = w;
+                S.meta[cur][bi] = m | kMetaCommit;
+                lmt += s;
+              } else {
+                lmt += S.commit_lmd[cur][bi];
+              }
+            }
+          }
+          const unsigned long long s8 = S.tsum[i];
+          // a slot with a single contributor holds exactly exp(0) * 2^44: no logarithm needed
+          const double logit = unord64(S.tmx[i]) + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
+          const long long tot = ord64(logit + (double)lmt);
+          S.tmx[i] = tot;
+          S.tsum[i] = (unsigned long long)__double_as_longlong(logit);
+          my_best = max(my_best, tot);
+        }
+      }
+      const long long best = wave_max_i64(my_best);
+      wave_sync();
+      WTICK(5)
+      // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
+      const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
+      const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
+      int tot_live = 0;
+      unsigned long long diff = 0;      // OR of (key ^ best key) over the live keys: where they first differ
+#pragma unroll 1
+      for (int e0 = 0; e0 < n_list; e0 += 64) {
+        const int e = e0 + lane;
+        const long long tt = e < n_list ? S.tmx[S.list[e]] : ord64(-1e300);
+        const bool live = e < n_list && tt >= thr_prune;
+        if (live) diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest;
+        tot_live += __popcll(__ballot(live));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool live = lane + 64 * j < n_sel && c_tot[j] >= thr_prune;
+        if (live) diff |= ((unsigned long long)c_tot[j] ^ 0x8000000000000000ull) ^ ubest;
+        tot_live += __popcll(__ballot(live));
+      }
+      unsigned long long prefix = 0, mask = 0;
+      int want = beam_width;
+      if (tot_live > beam_width) {
+        WCOUNT(6, 1)
+        diff = ((unsigned long long)wave_or_u32((unsigned)(diff >> 32)) << 32) | wave_or_u32((unsigned)diff);
+        // scores of live beams lie within beam_prune_logp of the best: their keys share the sign, the exponent and
+        // usually the top mantissa bits -- the leading digits all keys have in common cost no pass
+        const int same = diff ? __clzll((long long)diff) / 8 : 8;
+        if (same > 0) { mask = same == 8 ? ~0ull : (~0ull << (64 - 8 * same)); prefix = ubest & mask; }
+#pragma unroll 1
+        for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
+          WCOUNT(4, 1)
+          for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
+          wave_sync();
+#pragma unroll 1
+          for (int e = lane; e < n_list; e += 64) {
+            const long long tt = S.tmx[S.list[e]];
+            const unsigned long long u = (unsigned long long)tt ^ 0x8000000000000000ull;
+            if (tt >= thr_prune && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned long long u = (unsigned long long)c_tot[j] ^ 0x8000000000000000ull;
+            if (lane + 64 * j < n_sel && c_tot[j] >= thr_prune && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
+          }
+          wave_sync();
+          // the bucket holding the want-th largest key, searched from the top: lane l owns bins 255 - 4l ... 252 - 4l
+          int cnt[4], mine = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
+          int above = wave_scan_incl(mine) - mine;
+          int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+            above += cnt[j];
+          }
+          const unsigned long long fm = __ballot(f_bucket >= 0);
+          const int fl = __ffsll((long long)fm) - 1;           // exactly one lane finds it (tot_live > want >= 1)
+          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+          want = __builtin_amdgcn_readlane(f_want, fl);
+          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
+          prefix |= (unsigned long long)bucket << shift;
+          mask |= 0xFFull << shift;
+          if (whole) break;       // the whole bucket is taken: no need to refine further
+        }
+      }
+      // selected: live and key > threshold prefix, plus the first `want` (entries in list order, then the carried
+      // survivors by rank) equal to it
+      WTICK(6)
+      const bool more = c_lo + cap < nc_all;
+      int n_out = 0, eq_seen = 0;
+      // the records go to the sel_* rows; the carried survivors sit in registers, so nothing that is still needed is
+      // overwritten
+#pragma unroll 1
+      for (int e0 = 0; e0 < n_list; e0 += 64) {
+        const int e = e0 + lane;
+        bool gt = false, eq = false;
+        int i = 0;
+        long long tt = 0;
+        if (e < n_list) {
+          i = S.list[e];
+          tt = S.tmx[i];
+          if (tt >= thr_prune) {
+            const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
+            if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
+          }
+        }
+        const unsigned long long em = __ballot(eq);
+        const bool take = gt || (eq && eq_seen + rank_in(em) < want);
+        eq_seen += __popcll(em);
+        const unsigned long long tm = __ballot(take);
+        const int dst = n_out + rank_in(tm);
+        if (take && dst < kMaxBeams) {
+          S.sel_src[dst] = S.tsrc[i]; S.sel_lgt[dst] = (long long)S.tsum[i]; S.sel_tot[dst] = tt;
+        }
+        n_out += __popcll(tm);
+        // the table goes back to empty: only the claimed slots are touched
+        if (e < n_list) { S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0; }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bool gt = false, eq = false;
+        if (lane + 64 * j < n_sel && c_tot[j] >= thr_prune) {
+          const unsigned long long u = ((unsigned long long)c_tot[j] ^ 0x8000000000000000ull) & mask;
+          if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
+        }
+        const unsigned long long em = __ballot(eq);
+        const bool take = gt || (eq && eq_seen + rank_in(em) < want);
+        eq_seen += __popcll(em);
+        const unsigned long long tm = __ballot(take);
+        const int dst = n_out + rank_in(tm);
+        if (take && dst < kMaxBeams) { S.sel_src[dst] = c_src[j]; S.sel_lgt[dst] = c_lgt[j]; S.sel_tot[dst] = c_tot[j]; }
+        n_out += __popcll(tm);
+      }
+      n_sel = min(n_out, kMaxBeams);
+      wave_sync();
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = lane + 64 * j;
+          if (r < n_sel) { c_tot[j] = S.sel_tot[r]; c_lgt[j] = S.sel_lgt[r]; c_src[j] = S.sel_src[r]; }
+          else { c_tot[j] = ord64(-1e300); c_lgt[j] = 0; c_src[j] = 0; }
+        }
+        wave_sync();
+      }
+      WTICK(7)
+    }   // passes
+
+    // ---- 5. the new beams, one per rank: parent fields gathered from the current buffer ----
+    const int nxt = cur ^ 1;
+    bool any_char = false;
+#pragma unroll 1
+    for (int r = lane; r < n_sel; r += 64) {
+      const int src = S.sel_src[r], bi = src >> 8, c = src & 255;
+      const unsigned m = S.meta[cur][bi];
+      const int last = meta_last(m), wlen = meta_wlen(m);
+      const bool stay = (c == V || c == last);
+      unsigned long long key = S.key[cur][bi], whash = S.whash[cur][bi];
+      float lm_text = S.lm_text[cur][bi];
+      int ctx[kMaxCtx];
+#pragma unroll
+      for (int q = 0; q < kMaxCtx; ++q) ctx[q] = S.ctx[cur][bi][q];
+      int wlen_new = wlen;
+      unsigned int appended = 0;
+      unsigned flags = 0;
+      if (stay) {
+        // same text and pending word as the parent: in the LM cache if the parent was, or if this frame put it there;
+        // the commit score of the pending word is inherited with them
+        if ((m & kMetaCached) || (has_space && wlen > 0)) flags |= kMetaCached;
+        flags |= m & kMetaCommit;
+      } else if (c == space_id) {
+        if (wlen > 0) {
+          key = hmix(key, (unsigned long long)c);
+          appended = c + 1;
+          if (use_lm) {
+            lm_text += S.commit_lmd[cur][bi];
+#pragma unroll
+            for (int q = 0; q < kMaxCtx - 1; ++q) ctx[q] = ctx[q + 1];
+            ctx[kMaxCtx - 1] = S.commit_wid[cur][bi];
+          }
+          wlen_new = 0; whash = kFnvOffset;
+        }
+      } else {
+        key = hmix(key, (unsigned long long)c);
+        whash = hmix(whash, (unsigned long long)c);
+        wlen_new = wlen + 1;
+        appended = c + 1;
+      }
+      if (c != V) any_char = true;
+      S.key[nxt][r] = key; S.whash[nxt][r] = whash;
+      S.logit[nxt][r] = __longlong_as_double(S.sel_lgt[r]);
+      S.lm_text[nxt][r] = lm_text;
+      S.meta[nxt][r] = make_meta(c, wlen_new, flags);
+#pragma unroll
+      for (int q = 0; q < kMaxCtx; ++q) S.ctx[nxt][r][q] = ctx[q];
+      S.commit_lmd[nxt][r] = S.commit_lmd[cur][bi];
+      S.commit_wid[nxt][r] = S.commit_wid[cur][bi];
+      bp[(int64_t)t * kMaxBeams + r] = ((unsigned)bi << 8) | appended;
+    }
+    all_blank = __ballot(any_char) == 0ull;
+    nb = n_sel;
+    cur = nxt;
+    wave_sync();
+    WTICK(8)
+  }
+#ifdef VASR_BEAM_PROF
+  if (lane == 0 && b == 0 && frames > 0)
+    printf("wave prof (cycles/frame over %d frames): candidates %lld blank-exit %lld eoslog+setup %lld expand1 %lld expand2 %lld score %lld "
+           "select %lld publish+clear %lld build %lld | general frames %lld pairs/gf %lld entries/gf %lld passes %lld radix digit "
+           "passes %lld select frames %lld live beams %d\n", frames, prof[0] / frames, prof[1] / frames, prof[2] / frames,
+           prof[3] / frames, prof[4] / frames, prof[5] / frames, prof[6] / frames, prof[7] / frames, prof[8] / frames, cnt[0],
+           cnt[1] / max(cnt[0], 1ll), cnt[2] / max(cnt[0], 1ll), cnt[3], cnt[4], cnt[6], nb);
+  long long pt_tail = (long long)__builtin_readcyclecounter();
+#endif
+
+  // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best ----
+  // Is "text + pending word" in pyctcdecode's LM cache (then its cached score, WITHOUT </s>, is what the final pass
+  // uses)?  Known for beams whose own lineage put it there (`cached`); the others look their hash up in eoslog: their
+  // hashes go into the (idle, empty) merge table, the wavefront walks the log and marks the hashes it meets.
+  int in_cache[2] = {0, 0};
+  if (use_lm) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the log's stores have reached L2 (read back past the L1 below)
+    int myslot[2] = {-1, -1};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nb) {
+        const unsigned m = S.meta[cur][i];
+        if (meta_wlen(m) > 0) {
+          in_cache[j] = (m & kMetaCached) ? 1 : 0;
+          if (!in_cache[j] && n_log > 0) {
+            const unsigned long long k = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+            int q = (int)((k >> 17) & (kTab - 1));
+            while (true) {
+              const unsigned long long old = atomicCAS(&S.tkey[q], 0ull, k);
+              if (old == 0ull || old == k) break;
+              q = (q + 1) & (kTab - 1);
+            }
+            myslot[j] = q;
+          }
+        }
+      }
+    }
+    for (int i = lane; i < kTab; i += 64) S.tsrc[i] = 0;
+    wave_sync();
+    for (int q = lane; q < n_log; q += 64) {
+      const unsigned long long k = __hip_atomic_load(&eoslog[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = (int)((k >> 17) & (kTab - 1));; i = (i + 1) & (kTab - 1)) {
+        const unsigned long long e = S.tkey[i];
+        if (e == k) { S.tsrc[i] = 1; break; }
+        if (e == 0) break;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) if (myslot[j] >= 0) in_cache[j] = S.tsrc[myslot[j]];
+    wave_sync();
+  }
+  // per beam: combined final score, final text key, last-frame combined score (pyctcdecode keeps its beams sorted by it)
+  double* fin = S.lp;                                                      // [kMaxBeams]
+  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(S.sel_lgt);   // [kMaxBeams]
+  double* frank = reinterpret_cast<double*>(S.sel_tot);                    // [kMaxBeams]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nb) {
+      const unsigned m = S.meta[cur][i];
+      const int wlen = meta_wlen(m);
+      double total = S.logit[cur][i];
+      if (use_lm) {
+        float lmv = S.lm_text[cur][i];
+        if (wlen > 0) {
+          int ctx[kMaxCtx], wid;
+#pragma unroll
+          for (int q = 0; q < kMaxCtx; ++q) ctx[q] = S.ctx[cur][i][q];
+          lmv += lm_word_score(lm, ctx, S.whash[cur][i], !in_cache[j], &wid);
+        }
+        total += (double)lmv;
+      }
+      fin[i] = total;
+      fkey[i] = wlen > 0 ? hmix(S.key[cur][i], (unsigned long long)space_id) : S.key[cur][i];
+      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen)) : 0.0);
+    }
+  }
+  wave_sync();
+  // Merge by text: log-sum-exp of the LOGIT scores, as pyctcdecode does.  "abc" with the word still pending and "abc "
+  // with it committed are the same final text but not the same LM part (only the pending word is scored with </s>):
+  // pyctcdecode's _merge_beams overwrites the group's entry with every further member it meets while walking its
+  // score-sorted beam list, so the member with the LOWEST last-frame score provides the LM part.  Every lane takes the
+  // groups whose first member it owns; the best group is the first maximum in beam order.
+  double my_score = -1e300;
+  int my_first = 0x7fffffff;
+#pragma unroll 1
+  for (int i = lane; i < nb; i += 64) {
+    const unsigned long long k = fkey[i];
+    bool first = true;
+    for (int j = 0; j < i; ++j) if (fkey[j] == k) { first = false; break; }
+    if (!first) continue;
+    double m = S.logit[cur][i];
+    int rep = i;
+    for (int j = i + 1; j < nb; ++j)
+      if (fkey[j] == k) { m = fmax(m, S.logit[cur][j]); if (frank[j] < frank[rep]) rep = j; }
+    double ssum = 0;
+    for (int j = i; j < nb; ++j) if (fkey[j] == k) ssum += exp(S.logit[cur][j] - m);
+    const double merged = (fin[rep] - S.logit[cur][rep]) + m + log(ssum);
+    if (merged > my_score) { my_score = merged; my_first = i; }
+  }
+  const long long sbest = wave_max_i64(ord64(my_score));
+  const unsigned long long wm = __ballot(ord64(my_score) == sbest);
+  // lowest beam index among the lanes that hold the maximum (a lane's own groups are already in beam order)
+  int bi_best = 0x7fffffff;
+  for (unsigned long long q = wm; q; q &= q - 1) bi_best = min(bi_best, __builtin_amdgcn_readlane(my_first, __ffsll((long long)q) - 1));
+  const double bs = unord64(sbest);
+
+  // ---- trace back: the back-pointer rows come through LDS kTbRows at a time (one batch = one contiguous 6 KB read), the
+  //      batch after the current one already requested while the current one is walked; the characters are collected in
+  //      LDS and leave as one coalesced write (the workgroup kernel walked 501 dependent HBM round trips and reversed the
+  //      text in HBM with one thread: 0.2 ms of a 3 ms search) ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's own back-pointer stores have reached L2
+  unsigned int* rows = reinterpret_cast<unsigned int*>(S.tkey);            // [2][kTbRows][kMaxBeams], aliases tkey + tmx + tsum
+  unsigned short* chars = reinterpret_cast<unsigned short*>(&S.key[0][0]);  // [kChars], aliases the beam keys / hashes / logits
+  int32_t* out = out_ids + (int64_t)b * frames_ld;
+  const bool in_lds = frames <= kChars;
+  int n = 0, cur_b = bi_best;
+  bool lead = true;                                          // still inside the trailing whitespace of the text
+  constexpr int kRowRegs = kTbRows * kMaxBeams / 4 / 64;     // uint4 per lane and batch
+  uint4 rr[kRowRegs];
+  const int nbatch = (frames + kTbRows - 1) / kTbRows;       // batch j: frames (frames - (j + 1) kTbRows, frames - j kTbRows]
+  auto tb_request = [&](int j) {
+    const int t_hi = frames - 1 - j * kTbRows, t_lo = max(0, t_hi - kTbRows + 1), nq = (t_hi - t_lo + 1) * (kMaxBeams / 4);
+    const uint4* g = reinterpret_cast<const uint4*>(bp + (int64_t)t_lo * kMaxBeams);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) rr[k] = 64 * k + lane < nq ? g[64 * k + lane] : make_uint4(0, 0, 0, 0);
+  };
+  auto tb_land = [&](int j) {
+    uint4* dst = reinterpret_cast<uint4*>(rows + (j & 1) * kTbRows * kMaxBeams);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) dst[64 * k + lane] = rr[k];
+  };
+  if (nbatch > 0) { tb_request(0); tb_land(0); }
+  for (int j = 0; j < nbatch; ++j) {
+    if (j + 1 < nbatch) tb_request(j + 1);
+    wave_sync();
+    const int t_hi = frames - 1 - j * kTbRows, t_lo = max(0, t_hi - kTbRows + 1);
+    const unsigned int* rb = rows + (j & 1) * kTbRows * kMaxBeams;
+    for (int tt = t_hi - t_lo; tt >= 0; --tt) {
+      const unsigned int e = rb[tt * kMaxBeams + cur_b];
+      const unsigned int ch = e & 255;
+      if (ch) {
+        const int id = (int)ch - 1;
+        if (!(lead && id == space_id)) {                      // normalise trailing whitespace
+          lead = false;
+          if (in_lds) chars[n] = (unsigned short)id;
+          else if (lane == 0) out[frames_ld - 1 - n] = id;    // long transcripts: filled from the back, moved below
+          ++n;
+        }
+      }
+      cur_b = (int)(e >> 8);
+    }
+    if (j + 1 < nbatch) tb_land(j + 1);
+    wave_sync();
+  }
+  if (in_lds) {
+    for (int j = lane; j < n; j += 64) out[j] = (int)chars[n - 1 - j];
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // out[j] = out[frames_ld - n + j]: destination indices lie below the source indices and a chunk's loads complete
+    // before its stores, so overlapping ranges are safe
+    const int off = frames_ld - n;
+    if (off > 0) {
+      for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        int v = 0;
+        if (j < n) v = __hip_atomic_load(&out[off + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (j < n) out[j] = v;
+      }
+    }
+  }
+  if (lane == 0) {
+    out_len[b] = n;
+    out_score[b] = (float)bs;
+  }
+#ifdef VASR_BEAM_PROF
+  if (lane == 0 && b == 0) printf("wave prof tail (final pass + trace-back): %lld cycles total\n", (long long)__builtin_readcyclecounter() - pt_tail);
+#endif
+}
+
+}  // namespace
+
+size_t beam_wave_lds_bytes() { return sizeof(WaveLds); }
+
+// utterances per workgroup (= per compute unit): a lone utterance gets a workgroup of its own; a batch is packed four to a
+// compute unit so that the search of batch k leaves the rest of the chip to the acoustic pass of batch k + 1
+int beam_wave_utts_per_workgroup(int batch) { return batch >= 4 ? 4 : (batch >= 2 ? 2 : 1); }
+
+int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+                            float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
+                            int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
+                            const int32_t* row_frames) {
+  unsigned long long* eoslog = reinterpret_cast<unsigned long long*>(bp + (size_t)batch * frames * kMaxBeams);
+  LmView v{};
+  int use_lm = 0;
+  if (lm) {
+    use_lm = 1;
+    v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
+    v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
+    v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
+    v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
+  }
+  const int upw = beam_wave_utts_per_workgroup(batch);
+  const size_t lds = sizeof(WaveLds) * (size_t)upw;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_wave_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(WaveLds) * 4));
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL(beam_wave_kernel, dim3((batch + upw - 1) / upw), dim3(64 * upw), lds, st, logp, batch, frames,
+                     row_frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids,
+                     out_len, out_score);
+  return 0;
+}
+
+}  // namespace vasr

@@ -1084,6 +1084,14 @@ size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
   return batch > 0 && frames > 0 ? (size_t)batch * frames * kBeamMax * (sizeof(unsigned int) + sizeof(uint64_t)) : 0;
 }
 
+int vasr_beam_workgroups(int batch) {
+  if (batch <= 0) return 0;
+  static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
+  if (wg_kernel) return batch;
+  const int upw = beam_wave_utts_per_workgroup(batch);
+  return (batch + upw - 1) / upw;
+}
+
 int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,
                          int32_t* d_ids, int32_t* d_id_len, float* d_score, void* d_ws, size_t ws_bytes,
@@ -1103,36 +1111,35 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (space_id < -1 || space_id >= num_classes - 1) return fail(VASR_ERR_INVALID, "space_id out of range");
   const size_t need_bytes = vasr_beam_workspace_bytes(batch, frames);
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
-  const int e = launch_beam_search(d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width,
-                                   token_min_logp, beam_prune_logp, lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws),
-                                   d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream), d_row_frames);
+  // one wavefront per utterance (beam_wave.hip); VASR_BEAM_WG=1 (devtools build) keeps the workgroup-per-utterance kernel of
+  // rounds 1-3 for A/B runs
+  static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
+  const int e = (wg_kernel ? launch_beam_search : launch_beam_search_wave)(
+      d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width, token_min_logp, beam_prune_logp,
+      lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws), d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream),
+      d_row_frames);
   if (e) return fail(VASR_ERR_HIP, "beam search: %s", hipGetErrorString((hipError_t)e));
   return check_launch("beam_search");
 }
 
-int vasr_lm_create(const uint64_t* h_vkey, const int32_t* h_vid, int vcap, const uint64_t* h_nkey,
-                   const float* h_nval, int ncap, int order, int bos_id, int eos_id, int unk_id, float alpha,
-                   float beta, float unk_offset, vasr_lm** out) {
-  if (!h_vkey || !h_vid || !h_nkey || !h_nval || !out || vcap <= 0 || ncap <= 0) return fail(VASR_ERR_INVALID, "bad argument");
+int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, int order, int bos_id, int eos_id,
+                   int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out) {
+  if (!h_vocab || !h_ngram || !out || vcap <= 0 || ncap <= 0) return fail(VASR_ERR_INVALID, "bad argument");
+  if ((vcap & (vcap - 1)) || (ncap & (ncap - 1)) || vcap < 16 || ncap < 16)
+    return fail(VASR_ERR_INVALID, "table capacities must be powers of two >= 16");
   if (order < 1 || order > 5) return fail(VASR_ERR_UNSUPPORTED, "n-gram order %d (supported: 1..5)", order);
   auto* lm = new vasr_lm();
-  void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-  hipError_t e = hipMalloc(&p0, (size_t)vcap * 8);
-  if (e == hipSuccess) e = hipMalloc(&p1, (size_t)vcap * 4);
-  if (e == hipSuccess) e = hipMalloc(&p2, (size_t)ncap * 8);
-  if (e == hipSuccess) e = hipMalloc(&p3, (size_t)ncap * 8);
-  if (e == hipSuccess) e = hipMemcpy(p0, h_vkey, (size_t)vcap * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p1, h_vid, (size_t)vcap * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p2, h_nkey, (size_t)ncap * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p3, h_nval, (size_t)ncap * 8, hipMemcpyHostToDevice);
-  lm->allocs = {p0, p1, p2, p3};
+  void *p0 = nullptr, *p1 = nullptr;
+  hipError_t e = hipMalloc(&p0, (size_t)vcap * 16);
+  if (e == hipSuccess) e = hipMalloc(&p1, (size_t)ncap * 16);
+  if (e == hipSuccess) e = hipMemcpy(p0, h_vocab, (size_t)vcap * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p1, h_ngram, (size_t)ncap * 16, hipMemcpyHostToDevice);
+  lm->allocs = {p0, p1};
   if (e != hipSuccess) {
     vasr_lm_destroy(lm);
     return fail(VASR_ERR_HIP, "uploading the n-gram tables: %s", hipGetErrorString(e));
   }
-  lm->view = BeamLm{static_cast<unsigned long long*>(p0), static_cast<int32_t*>(p1), vcap,
-                    static_cast<unsigned long long*>(p2), static_cast<float*>(p3), ncap, order, bos_id, eos_id,
-                    unk_id, alpha, beta, unk_offset};
+  lm->view = BeamLm{p0, vcap, p1, ncap, order, bos_id, eos_id, unk_id, alpha, beta, unk_offset};
   *out = lm;
   return 0;
 }

@@ -230,8 +230,8 @@ void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int b
 
 // ---- beam search (beam.hip) ----
 struct BeamLm {  // device-resident hashed back-off n-gram model
-  const unsigned long long* vkey; const int32_t* vid; int vcap;   // word hash -> word id
-  const unsigned long long* nkey; const float* nval; int ncap;    // n-gram hash -> (log10 p, log10 backoff)
+  const void* vocab; int vcap;    // [vcap] 16-byte entries {u64 word hash | 1, i32 word id, i32 0}, vcap a power of two
+  const void* ngram; int ncap;    // [ncap] 16-byte entries {u64 n-gram key | 1, f32 log10 p, f32 log10 back-off}
   int order, bos, eos, unk;
   float alpha, beta, unk_offset;
 };
@@ -241,6 +241,13 @@ int launch_beam_search(const float* logp,   // 0 or a hipError_t
                         float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
                         int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                         const int32_t* row_frames = nullptr);   // [batch] frames searched per row, nullptr = all
+// beam_wave.hip: one wavefront per utterance, `beam_wave_utts_per_workgroup` utterances per workgroup (= compute unit)
+int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+                            float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
+                            int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
+                            const int32_t* row_frames = nullptr);
+int beam_wave_utts_per_workgroup(int batch);
+size_t beam_wave_lds_bytes();
 unsigned long long beam_hash_step(unsigned long long h, unsigned long long v);
 unsigned long long beam_hash_init();
 

@@ -146,12 +146,12 @@ class QuartzNetCTC:
     def forward_beam(self, wav, length, beam_decoder, beam_width, frames=None, overlap=True):
         """Acoustic pass + beam search (+ LM) of one device-resident batch: the batched form of infer.py:146-160.
 
-        overlap=True runs the search on a side stream: it occupies one workgroup per utterance (64 of the 256 CUs at
-        B = 64) for about as long as the acoustic pass of the NEXT batch takes on the whole chip, so queued behind the
-        log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
+        overlap=True runs the search on a side stream: it occupies one wavefront per utterance, four utterances per compute
+        unit (16 of the 256 CUs at B = 64) for about as long as the acoustic pass of the NEXT batch takes on the rest of the
+        chip, so queued behind the log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
         score, done): ``done`` is an event on the side stream (None when overlap is off); wait for it -- or
         synchronise the device -- before reading the results from another stream."""
-        # a search of the previous batch that is still queued or running holds one compute unit per utterance while this
+        # a search of the previous batch that is still queued or running holds a compute unit per four utterances while this
         # acoustic pass runs: the GEMM tile choice should fill whole rounds of what is left (vasr_set_busy_cus)
         busy = self._beam_inflight[1] if overlap and self._beam_inflight and not self._beam_inflight[0].query() else 0
         self.handle.set_busy_cus(busy)
@@ -172,7 +172,7 @@ class QuartzNetCTC:
             ids, n, score = beam_decoder.decode_ids(r["logp"], beam_width, frames)
             done = torch.cuda.Event()
             done.record(self._beam_stream)
-        self._beam_inflight = (done, int(r["logp"].shape[0]))
+        self._beam_inflight = (done, int(_lib.lib().vasr_beam_workgroups(int(r["logp"].shape[0]))))
         r["logp"].record_stream(self._beam_stream)     # allocated on the main stream, last read on the side stream
         return dict(ids=ids, id_len=n, score=score, done=done, enc_len=r["enc_len"])
 
