@@ -321,3 +321,53 @@ def test_beam_module_through_the_executor_with_a_batch(gpu):
     dl.set_signal(sig[1, : lens[1]])
     single = nf.infer(tensors=[hyp], verbose=False)[0][0]
     assert isinstance(single, str)                                   # what infer.py consumes: evaluated_tensors[0][0]
+
+
+_AB_SNIPPET = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch
+import viet_asr_amd
+from viet_asr_amd.beam import BeamSearchDecoder
+import test_beam as T
+path, _ = T.toy_lm({tmp!r})
+out = []
+for V1, labels in ((29, T.LABELS),):
+    lp = np.stack([T.ctc_like_posteriors(160, V1, 900 + b, p_blank=0.55) for b in range(6)] +
+                  [T.random_posteriors(160, V1, 950 + b, peaky=k) for b, k in enumerate((0.5, 2.0, 4.0))])
+    x = torch.from_numpy(lp).cuda()
+    for lm in (None, path):
+        dec = BeamSearchDecoder(labels, lm_path=lm, alpha=0.7, beta=1.1)
+        for w in (8, 50, 100, 128):
+            ids, n, score = dec.decode_ids(x, w)
+            out.append((ids.cpu().numpy(), n.cpu().numpy(), score.cpu().numpy()))
+np.save({dst!r}, np.array([(a.tobytes(), b.tobytes(), c.tobytes()) for a, b, c in out], dtype=object), allow_pickle=True)
+"""
+
+
+@pytest.mark.gpu
+def test_wave_kernel_and_workgroup_kernel_agree(gpu, tmp_path):
+    """beam_wave.hip (one wavefront per utterance, the product kernel) against beam.hip (one 512-thread workgroup per
+    utterance, rounds 1-3, devtools build, VASR_BEAM_WG=1): the same merge arithmetic (ordered-int max, fixed-point sums)
+    in a different schedule -- hypotheses, lengths and scores identical bit for bit on CTC-like, flat and peaked posteriors,
+    widths 8 ... 128, with and without the LM.  Each kernel runs in its own process (the switch is read once)."""
+    import subprocess, sys
+    from conftest import ROOT
+    dev = os.path.join(ROOT, "viet-asr_amd", "lib", "libvasr_hip_dev.so")
+    res = []
+    for tag, extra in (("wave", {}), ("wg", {"VASR_BEAM_WG": "1"})):
+        dst = str(tmp_path / f"{tag}.npy")
+        env = dict(os.environ, VASR_LIB_PATH=dev, **extra)
+        r = subprocess.run([sys.executable, "-c", _AB_SNIPPET.format(root=ROOT, tmp=str(tmp_path), dst=dst)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(dst, allow_pickle=True))
+    assert len(res[0]) == len(res[1]) == 8
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        n_a, n_b = np.frombuffer(a[1], np.int32), np.frombuffer(b[1], np.int32)
+        assert (n_a == n_b).all(), k
+        ids_a = np.frombuffer(a[0], np.int32).reshape(len(n_a), -1)
+        ids_b = np.frombuffer(b[0], np.int32).reshape(len(n_b), -1)
+        for r_ in range(len(n_a)):
+            assert (ids_a[r_, : n_a[r_]] == ids_b[r_, : n_b[r_]]).all(), (k, r_)
+        assert a[2] == b[2], k            # scores, bit for bit

@@ -630,7 +630,5 @@ int launch_beam_search(const float* logp, int batch, int frames, int V1, int spa
   return go(std::integral_constant<int, 2048>{});
 }
 
-unsigned long long beam_hash_step(unsigned long long h, unsigned long long v) { return hmix(h, v); }
-unsigned long long beam_hash_init() { return kFnvOffset; }
 
 }  // namespace vasr

@@ -49,7 +49,7 @@ __host__ __device__ inline int lm_home(unsigned long long k, int lg) {
   return (int)((((unsigned)k ^ (unsigned)(k >> 32)) * 0x9E3779B1u) >> (32 - lg));
 }
 
-__device__ inline int lm_word_id(const LmView& lm, unsigned long long whash) {
+__device__ __forceinline__ int lm_word_id(const LmView& lm, unsigned long long whash) {
   const unsigned long long k = whash | 1ull;
   for (int i = lm_home(k, lm.vlg), n = 0; n < lm.vcap; ++n, i = (i + 1) & (lm.vcap - 1)) {
     const uint4 e = lm.vocab[i];
@@ -61,7 +61,7 @@ __device__ inline int lm_word_id(const LmView& lm, unsigned long long whash) {
 }
 
 // the rest of a probe chain whose first entry `e` was neither the key nor empty (rare at <= 50 % load)
-__device__ inline bool lm_probe_on(const LmView& lm, unsigned long long k, uint4 e, float2* out) {
+__device__ __forceinline__ bool lm_probe_on(const LmView& lm, unsigned long long k, uint4 e, float2* out) {
   int i = lm_home(k, lm.nlg);
   for (int c = 0; c < lm.ncap; ++c) {
     const unsigned long long ek = entry_key(e);
@@ -78,7 +78,7 @@ __device__ inline bool lm_probe_on(const LmView& lm, unsigned long long k, uint4
 // keys come from two incremental chains and ALL first probes are requested before any is looked at -- one trip to
 // L2 / HBM for the whole walk instead of one per step (ten dependent trips for a trigram model whose words are unseen
 // together; the LM was 3 100 of the 14 600 cycles of an average frame).
-__device__ float lm_base_score(const LmView& lm, const int* ctx, int w) {
+__device__ __forceinline__ float lm_base_score(const LmView& lm, const int* ctx, int w) {
   int ids[kMaxCtx];               // usable history, most recent LAST
   int n = 0;
   for (int i = 0; i < kMaxCtx; ++i)
@@ -122,7 +122,7 @@ __device__ float lm_base_score(const LmView& lm, const int* ctx, int w) {
 }
 
 // pyctcdecode LanguageModel.score (alpha * log10 * ln10 + beta, OOV offset, optional </s>)
-__device__ float lm_word_score(const LmView& lm, const int* ctx, unsigned long long whash, bool eos, int* wid_out) {
+__device__ __forceinline__ float lm_word_score(const LmView& lm, const int* ctx, unsigned long long whash, bool eos, int* wid_out) {
   int wid = lm_word_id(lm, whash);
   const bool oov = wid < 0;
   if (oov) wid = lm.unk;

@@ -34,6 +34,7 @@
 //      when everything that survived the prune fits, which is the usual case);
 //   4. survivors become the new beams (parent fields gathered from LDS), one back-pointer row per frame.
 #include <cstdlib>
+#include <type_traits>
 
 #include "beam_common.h"
 
@@ -67,12 +68,11 @@ struct WaveLds {
   long long tmx[kTab];
   unsigned long long tsum[kTab];
   int tsrc[kTab];
-  unsigned short list[kFill + 2];          // claimed slots, in claim order
-  unsigned short pair_slot[kFill + 2];     // slot of pair p
-  // survivors of a pass, by rank
+  // survivors of a pass that is not a frame's last, by rank (they come back as carried survivors); after the last frame:
+  // the final text keys / last-frame scores of the beams
   long long sel_lgt[kMaxBeams], sel_tot[kMaxBeams];
   int sel_src[kMaxBeams];
-  double lp[kMaxClasses];
+  double fin[kMaxBeams];                   // combined final score per beam (final pass)
   unsigned long long cmix[kMaxClasses];    // per-class constant folded into a pair's key (the "last character" part)
   float lpq[kLpFrames * kMaxClasses];      // log-probs of the current batch of frames, [frame][class] as in memory
   unsigned char cand[kMaxClasses];
@@ -140,32 +140,89 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   int cur = 0, nb = 1, n_log = 0;
   bool all_blank = false;      // every live beam ends in blank (uniform)
 #ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals and work counters of utterance 0 (tools/probes/beam_lat.py, ONCE=1)
-  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = (long long)__builtin_readcyclecounter();
-  long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // general frames, pairs, merged entries, passes, radix digit passes, LM scorings, select frames
-#define WTICK(k) { const long long now_ = (long long)__builtin_readcyclecounter(); prof[k] += now_ - pt; pt = now_; }
-#define WCOUNT(k, v) cnt[k] += (v);
+  // One VGPR holds everything -- lane k accumulates section k, lane 32 + k counter k: sixteen 64-bit totals in scalar
+  // registers made the compiler spill half the kernel's uniform state around every tick (the first profile of this kernel
+  // showed 1 000 cycles of "loop top" that were nothing but that spill code).
+  unsigned pacc = 0, pt = (unsigned)__builtin_readcyclecounter();
+#define WTICK(k) { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); pacc += lane == (k) ? now_ - pt : 0u; pt = now_; }
+#define WCOUNT(k, v) pacc += lane == 32 + (k) ? (unsigned)(v) : 0u;
 #else
 #define WTICK(k)
 #define WCOUNT(k, v)
 #endif
 
   // Log-probs reach the frames through LDS, kLpFrames frames per batch (a contiguous run of kLpFrames * V1 floats), and
-  // the batch after the current one is already on its way in registers: a per-frame prefetch does not work here --
-  // s_waitcnt vmcnt counts in order, so waiting for the frame requested four frames ago also waits for the request just
-  // issued (and for the back-pointer stores): one full HBM round trip per frame (1 700 of 14 600 cycles, measured).
+  // the batch after the current one is already on its way in registers.  Two things measured on the way: (1) a per-frame
+  // register prefetch does not work -- s_waitcnt vmcnt counts in order, so waiting for the frame requested four frames
+  // ago also waits for the request just issued and for the back-pointer stores: one HBM round trip per frame; (2) LLVM
+  // SINKS plain loads to their first use, i.e. to the next batch boundary, and with a predicate per load they came out as
+  // sixteen dependent round trips there (8 900 cycles per batch; volatile loads are worse: the back end drains the counter
+  // after each).  Hence: unconditional loads of a clamped index, all in flight together.
   float q[kLpRegs];
   const int lp_batch = kLpFrames * V1;                        // floats per batch
-  auto lp_request = [&](int t0) {
-    const int64_t base = (int64_t)t0 * V1;
-    const int n = max(0, min(lp_batch, (frames - t0) * V1));
+  auto lp_request = [&](int t0) __attribute__((always_inline)) {
+    const int n = min(lp_batch, (frames - t0) * V1);
+    if (n <= 0) return;
+    const float* src = lrow + (int64_t)t0 * V1;
 #pragma unroll
-    for (int k = 0; k < kLpRegs; ++k) { const int f = 64 * k + lane; q[k] = f < n ? lrow[base + f] : 0.f; }
+    for (int k = 0; k < kLpRegs; ++k) q[k] = src[min(64 * k + lane, n - 1)];
   };
   lp_request(0);
 
+  // One new beam at rank r from pair (parent bi, character c) with merged logit bits lgt: the parent's fields are gathered
+  // from the current buffer, the child goes to the other one, one back-pointer word per rank and frame.
+  auto build_child = [&](int t, int r, int src, long long lgt, bool has_space, bool& any_char) __attribute__((always_inline)) {
+    const int nxt = cur ^ 1;
+    const int bi = src >> 8, c = src & 255;
+    const unsigned m = S.meta[cur][bi];
+    const int last = meta_last(m), wlen = meta_wlen(m);
+    const bool stay = (c == V || c == last);
+    unsigned long long key = S.key[cur][bi], whash = S.whash[cur][bi];
+    float lm_text = S.lm_text[cur][bi];
+    const int4 ctx_p = *reinterpret_cast<const int4*>(&S.ctx[cur][bi][0]);
+    int4 ctx_n = ctx_p;
+    const float p_lmd = S.commit_lmd[cur][bi];
+    const int p_wid = S.commit_wid[cur][bi];
+    int wlen_new = wlen;
+    unsigned int appended = 0;
+    unsigned flags = 0;
+    if (stay) {
+      // same text and pending word as the parent: in the LM cache if the parent was, or if this frame put it there; the
+      // commit score of the pending word is inherited with them
+      if ((m & kMetaCached) || (has_space && wlen > 0)) flags |= kMetaCached;
+      flags |= m & kMetaCommit;
+    } else if (c == space_id) {
+      if (wlen > 0) {
+        key = hmix(key, (unsigned long long)c);
+        appended = c + 1;
+        if (use_lm) {
+          lm_text += p_lmd;
+          ctx_n = make_int4(ctx_p.y, ctx_p.z, ctx_p.w, p_wid);
+        }
+        wlen_new = 0; whash = kFnvOffset;
+      }
+    } else {
+      key = hmix(key, (unsigned long long)c);
+      whash = hmix(whash, (unsigned long long)c);
+      wlen_new = wlen + 1;
+      appended = c + 1;
+    }
+    if (c != V) any_char = true;
+    S.key[nxt][r] = key; S.whash[nxt][r] = whash;
+    S.logit[nxt][r] = __longlong_as_double(lgt);
+    S.lm_text[nxt][r] = lm_text;
+    S.meta[nxt][r] = make_meta(c, wlen_new, flags);
+    *reinterpret_cast<int4*>(&S.ctx[nxt][r][0]) = ctx_n;
+    S.commit_lmd[nxt][r] = p_lmd;
+    S.commit_wid[nxt][r] = p_wid;
+    bp[(int64_t)t * kMaxBeams + r] = ((unsigned)bi << 8) | appended;
+  };
+
   for (int t = 0; t < frames; ++t) {
-    // ---- 1. log-probs (pyctcdecode: log(clip(p, 1e-15, 1)) = clip(x, log 1e-15, 0)) and candidate characters ----
+    // ---- 1. candidate characters.  pyctcdecode works on log(clip(p, 1e-15, 1)) = clip(x, log 1e-15, 0); for every class
+    //         that can be a candidate (x >= token_min_logp, or the arg-max) that is min(x, 0), a float: no fp64 here ----
     const int c0 = lane, c1 = lane + 64;
+    WTICK(9)
     if ((t & (kLpFrames - 1)) == 0) {                        // batch boundary: land the batch in LDS, request the next one
 #pragma unroll
       for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) S.lpq[64 * k + lane] = q[k];
@@ -173,12 +230,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       wave_sync();
     }
     const float* lq = S.lpq + (t & (kLpFrames - 1)) * V1;
-    const float x0 = c0 < V1 ? lq[c0] : 0.f, x1 = c1 < V1 ? lq[c1] : 0.f;
-    const double d0 = fmin(fmax((double)x0, -34.538776394910684), 0.0);
-    const double d1 = fmin(fmax((double)x1, -34.538776394910684), 0.0);
-    if (c0 < V1) S.lp[c0] = d0;
-    if (c1 < V1) S.lp[c1] = d1;
-    const float v0 = c0 < V1 ? (float)d0 : 0.f, v1 = c1 < V1 ? (float)d1 : 0.f;
+    const float v0 = c0 < V1 ? fminf(fmaxf(lq[c0], -34.538776f), 0.f) : 0.f, v1 = c1 < V1 ? fminf(fmaxf(lq[c1], -34.538776f), 0.f) : 0.f;
     auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
     const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
     const unsigned kmax = wave_max_u32(max(key0, key1));
@@ -201,7 +253,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     // runs of such frames; the first of a run goes the general way (beams that differ only in their last character
     // merge there).  logit + lp is the sum the general path would have stored.
     if (only_blank && all_blank) {
-      const double add = S.lp[V];
+      const double add = (double)fminf(lq[V], 0.f);
       for (int i = lane; i < nb; i += 64) {
         S.logit[cur][i] += add;
         bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
@@ -212,21 +264,42 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     }
     WCOUNT(0, 1)
 
-    // ---- 2b. this frame puts "text + pending word" of every live beam into pyctcdecode's LM score cache ----
+    // ---- 2. ' ' is a candidate: "text + pending word" of every live beam enters pyctcdecode's LM score cache (eoslog), and
+    //         every pending word gets the LM score a commit would add -- once per (text, word): children that keep both
+    //         inherit it.  Lane = beam: all the n-gram walks of the frame are in flight together ----
     if (use_lm && has_space) {
       for (int i0 = 0; i0 < nb; i0 += 64) {
         const int i = i0 + lane;
         bool put = false;
+#ifdef VASR_BEAM_PROF
+        bool did_lm = false;
+#endif
         unsigned long long h = 0;
         if (i < nb) {
           const unsigned m = S.meta[cur][i];
-          put = meta_wlen(m) > 0 && !(m & kMetaCached);
-          h = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+          if (meta_wlen(m) > 0) {
+            put = !(m & kMetaCached);
+            h = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+            if (!(m & kMetaCommit)) {
+              int ctx[kMaxCtx];
+#pragma unroll
+              for (int qq = 0; qq < kMaxCtx; ++qq) ctx[qq] = S.ctx[cur][i][qq];
+              int w;
+              S.commit_lmd[cur][i] = lm_word_score(lm, ctx, S.whash[cur][i], false, &w);
+              S.commit_wid[cur][i] = w;
+              S.meta[cur][i] = m | kMetaCommit;
+#ifdef VASR_BEAM_PROF
+              did_lm = true;
+#endif
+            }
+          }
         }
         const unsigned long long pm = __ballot(put);
         if (put) eoslog[n_log + rank_in(pm)] = h;
         n_log += __popcll(pm);
+        WCOUNT(5, __popcll(__ballot(did_lm)))
       }
+      wave_sync();
     }
 
     // candidates per pass: nb * cap pairs fit the merge table.  kFill / nb through the hardware reciprocal: the quotient's
@@ -236,26 +309,35 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     long long c_tot[2] = {ord64(-1e300), ord64(-1e300)}, c_lgt[2] = {0, 0};
     int c_src[2] = {0, 0};
     int n_sel = 0;
-#pragma unroll 1
-    for (int c_lo = 0; c_lo < nc_all; c_lo += cap) {
-      const int nc = min(cap, nc_all - c_lo);
+    bool any_char = false;
+    WTICK(2)
+
+    // One pass = nc candidates x nb beams, PPL pairs per lane (pair p = 64 j + lane), everything between the table and the
+    // new beams in REGISTERS: a pair's slot and score, a merged prefix's combined score and logit in the lane that claimed
+    // its slot.  The claimed-slot list, the pair -> slot map and the survivor records of the first version of this kernel
+    // (all of them LDS round trips between dependent phases) exist no more; PPL is picked per pass from the pair count.
+    auto pass = [&](auto ppl_tag, int c_lo, int nc, bool last_pass) __attribute__((always_inline)) {
+      constexpr int PPL = decltype(ppl_tag)::value;
       const int npairs = nb * nc;
       const float inv_nc = __builtin_amdgcn_rcpf((float)nc);
       WCOUNT(1, npairs) WCOUNT(3, 1)
-      WTICK(2)
-      // ---- 2. expand: every (beam, character) pair claims / finds its slot and raises the slot's max ... ----
-      int n_list = 0;
-#pragma unroll 1
-      for (int p0 = 0; p0 < npairs; p0 += 64) {
-        const int p = p0 + lane;
-        bool claimed = false;
-        int slot = 0;
+      int slot[PPL], src[PPL];
+      double score[PPL];
+      unsigned claimed = 0, act = 0;
+      // ---- expand: every (beam, character) pair claims / finds its slot and raises the slot's max ... ----
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int p = 64 * j + lane;
+        slot[j] = 0; src[j] = 0; score[j] = 0.0;
         if (p < npairs) {
+          act |= 1u << j;
           const int bi = (int)(((float)p + 0.5f) * inv_nc);          // p / nc (exact: tests/test_beam.py replays it)
           const int c = S.cand[c_lo + p - bi * nc];
           const unsigned m = S.meta[cur][bi];
           const int last = meta_last(m);
           unsigned long long key = S.key[cur][bi];
+          score[j] = S.logit[cur][bi] + (double)fminf(lq[c], 0.f);
+          src[j] = (bi << 8) | c;
           // the prefix grows unless the character is blank, a repeat, or a space with no word pending -- one multiply,
           // no branches; the "last character" part of the key is a per-class constant (S.cmix)
           const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
@@ -271,98 +353,77 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
             if (e == k) break;
             if (e == 0) {
               const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
-              if (old == 0ull) { S.tsrc[i] = (bi << 8) | c; claimed = true; break; }
+              if (old == 0ull) { claimed |= 1u << j; break; }
               if (old == k) break;
             }
             i = (i + stride) & (kTab - 1);
           }
-          atomicMax(&S.tmx[i], ord64(S.logit[cur][bi] + S.lp[c]));
-          S.pair_slot[p] = (unsigned short)i;
-          slot = i;
+          atomicMax(&S.tmx[i], ord64(score[j]));
+          slot[j] = i;
         }
-        const unsigned long long cm = __ballot(claimed);
-        if (claimed) S.list[n_list + rank_in(cm)] = (unsigned short)slot;
-        n_list += __popcll(cm);
       }
       wave_sync();
       WTICK(3)
-      WCOUNT(2, n_list)
       // ---- ... then adds exp(score - max): hardware 2^x on a float (1 ulp); exp2(0) is exactly 1, so a slot with a
       //      single contributor holds exactly 2^44 ----
-#pragma unroll 1
-      for (int p = lane; p < npairs; p += 64) {
-        const int bi = (int)(((float)p + 0.5f) * inv_nc);
-        const int c = S.cand[c_lo + p - bi * nc];
-        const int i = S.pair_slot[p];
-        const double score = S.logit[cur][bi] + S.lp[c];
-        const float e = __builtin_amdgcn_exp2f((float)((score - unord64(S.tmx[i])) * 1.4426950408889634));
-        atomicAdd(&S.tsum[i], (unsigned long long)((double)e * kFix));
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        if (act >> j & 1) {
+          const float e = __builtin_amdgcn_exp2f((float)((score[j] - unord64(S.tmx[slot[j]])) * 1.4426950408889634));
+          atomicAdd(&S.tsum[slot[j]], (unsigned long long)((double)e * kFix));
+        }
       }
       wave_sync();
       WTICK(4)
-      // ---- 3. merged prefixes: LM score of a committed word, combined score, running maximum ----
+      // ---- 3. merged prefixes, each in the lane that claimed its slot: combined score; the slot goes back to empty ----
+      long long tot[PPL], lgt[PPL];
       long long my_best = max(c_tot[0], c_tot[1]);
-#pragma unroll 1
-      for (int e0 = 0; e0 < n_list; e0 += 64) {
-        const int e = e0 + lane;
-        if (e < n_list) {
-          const int i = S.list[e];
-          const int src = S.tsrc[i], bi = src >> 8, c = src & 255;
+#ifdef VASR_BEAM_PROF
+      int n_claimed = 0;
+#endif
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        tot[j] = ord64(-1e300); lgt[j] = 0;
+        if (claimed >> j & 1) {
+          const int i = slot[j], bi = src[j] >> 8, c = src[j] & 255;
+          const unsigned long long s8 = S.tsum[i];
+          const long long mxo = S.tmx[i];
           float lmt = 0.f;
           if (use_lm) {
-            unsigned m = S.meta[cur][bi];
+            const unsigned m = S.meta[cur][bi];
             const int last = meta_last(m), wlen = meta_wlen(m);
             const bool stay = (c == V || c == last);
-            const bool commit = !stay && c == space_id && wlen > 0;
             const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
             lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new);
-            if (commit) {
-              // computed once per (text, word): children that keep both inherit it (build step); (bi, ' ') is one
-              // table entry, so this lane is the only writer of beam bi's cache
-              if (!(m & kMetaCommit)) {
-                int ctx[kMaxCtx];
-#pragma unroll
-                for (int q = 0; q < kMaxCtx; ++q) ctx[q] = S.ctx[cur][bi][q];
-                int w;
-                const float s = lm_word_score(lm, ctx, S.whash[cur][bi], false, &w);
-                S.commit_lmd[cur][bi] = s; S.commit_wid[cur][bi] = w;
-                S.meta[cur][bi] = m | kMetaCommit;
-                lmt += s;
-              } else {
-                lmt += S.commit_lmd[cur][bi];
-              }
-            }
+            if (!stay && c == space_id && wlen > 0) lmt += S.commit_lmd[cur][bi];       // filled by step 2
           }
-          const unsigned long long s8 = S.tsum[i];
+          S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0;
           // a slot with a single contributor holds exactly exp(0) * 2^44: no logarithm needed
-          const double logit = unord64(S.tmx[i]) + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
-          const long long tot = ord64(logit + (double)lmt);
-          S.tmx[i] = tot;
-          S.tsum[i] = (unsigned long long)__double_as_longlong(logit);
-          my_best = max(my_best, tot);
+          const double logit = unord64(mxo) + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
+          tot[j] = ord64(logit + (double)lmt);
+          lgt[j] = __double_as_longlong(logit);
+          my_best = max(my_best, tot[j]);
         }
+#ifdef VASR_BEAM_PROF
+        n_claimed += __popcll(__ballot(claimed >> j & 1));
+#endif
       }
+      WCOUNT(2, n_claimed)
       const long long best = wave_max_i64(my_best);
       wave_sync();
       WTICK(5)
       // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
       const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
       const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
+      unsigned live = 0;                // bit j: entry j survives the prune; bits PPL, PPL + 1: the carried survivors
       int tot_live = 0;
       unsigned long long diff = 0;      // OR of (key ^ best key) over the live keys: where they first differ
-#pragma unroll 1
-      for (int e0 = 0; e0 < n_list; e0 += 64) {
-        const int e = e0 + lane;
-        const long long tt = e < n_list ? S.tmx[S.list[e]] : ord64(-1e300);
-        const bool live = e < n_list && tt >= thr_prune;
-        if (live) diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest;
-        tot_live += __popcll(__ballot(live));
-      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bool live = lane + 64 * j < n_sel && c_tot[j] >= thr_prune;
-        if (live) diff |= ((unsigned long long)c_tot[j] ^ 0x8000000000000000ull) ^ ubest;
-        tot_live += __popcll(__ballot(live));
+      for (int j = 0; j < PPL + 2; ++j) {
+        const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
+        const bool lv = j < PPL ? ((claimed >> j & 1) && tt >= thr_prune) : (lane + 64 * (j - PPL) < n_sel && tt >= thr_prune);
+        if (lv) { live |= 1u << j; diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest; }
+        tot_live += __popcll(__ballot(lv));
       }
       unsigned long long prefix = 0, mask = 0;
       int want = beam_width;
@@ -378,16 +439,10 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
           WCOUNT(4, 1)
           for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
           wave_sync();
-#pragma unroll 1
-          for (int e = lane; e < n_list; e += 64) {
-            const long long tt = S.tmx[S.list[e]];
-            const unsigned long long u = (unsigned long long)tt ^ 0x8000000000000000ull;
-            if (tt >= thr_prune && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
-          }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const unsigned long long u = (unsigned long long)c_tot[j] ^ 0x8000000000000000ull;
-            if (lane + 64 * j < n_sel && c_tot[j] >= thr_prune && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
+          for (int j = 0; j < PPL + 2; ++j) {
+            const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+            if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
           }
           wave_sync();
           // the bucket holding the want-th largest key, searched from the top: lane l owns bins 255 - 4l ... 252 - 4l
@@ -411,44 +466,17 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
           if (whole) break;       // the whole bucket is taken: no need to refine further
         }
       }
-      // selected: live and key > threshold prefix, plus the first `want` (entries in list order, then the carried
-      // survivors by rank) equal to it
       WTICK(6)
-      const bool more = c_lo + cap < nc_all;
+      // selected: live and key > threshold prefix, plus the first `want` (pairs in order, then the carried survivors by
+      // rank) equal to it.  A selected entry's record (pair, merged logit) goes to the sel_* rows at its rank: after the
+      // last pass the new beams are built from them, otherwise they come back as carried survivors (rank = lane, lane + 64).
       int n_out = 0, eq_seen = 0;
-      // the records go to the sel_* rows; the carried survivors sit in registers, so nothing that is still needed is
-      // overwritten
-#pragma unroll 1
-      for (int e0 = 0; e0 < n_list; e0 += 64) {
-        const int e = e0 + lane;
-        bool gt = false, eq = false;
-        int i = 0;
-        long long tt = 0;
-        if (e < n_list) {
-          i = S.list[e];
-          tt = S.tmx[i];
-          if (tt >= thr_prune) {
-            const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
-            if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
-          }
-        }
-        const unsigned long long em = __ballot(eq);
-        const bool take = gt || (eq && eq_seen + rank_in(em) < want);
-        eq_seen += __popcll(em);
-        const unsigned long long tm = __ballot(take);
-        const int dst = n_out + rank_in(tm);
-        if (take && dst < kMaxBeams) {
-          S.sel_src[dst] = S.tsrc[i]; S.sel_lgt[dst] = (long long)S.tsum[i]; S.sel_tot[dst] = tt;
-        }
-        n_out += __popcll(tm);
-        // the table goes back to empty: only the claimed slots are touched
-        if (e < n_list) { S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0; }
-      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < PPL + 2; ++j) {
+        const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
         bool gt = false, eq = false;
-        if (lane + 64 * j < n_sel && c_tot[j] >= thr_prune) {
-          const unsigned long long u = ((unsigned long long)c_tot[j] ^ 0x8000000000000000ull) & mask;
+        if (live >> j & 1) {
+          const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
           if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
         }
         const unsigned long long em = __ballot(eq);
@@ -456,12 +484,17 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         eq_seen += __popcll(em);
         const unsigned long long tm = __ballot(take);
         const int dst = n_out + rank_in(tm);
-        if (take && dst < kMaxBeams) { S.sel_src[dst] = c_src[j]; S.sel_lgt[dst] = c_lgt[j]; S.sel_tot[dst] = c_tot[j]; }
+        if (take && dst < kMaxBeams) {
+          const int sr = j < PPL ? src[j] : c_src[j - PPL];
+          const long long lg = j < PPL ? lgt[j] : c_lgt[j - PPL];
+          S.sel_src[dst] = sr; S.sel_lgt[dst] = lg;
+          if (!last_pass) S.sel_tot[dst] = tt;
+        }
         n_out += __popcll(tm);
       }
       n_sel = min(n_out, kMaxBeams);
       wave_sync();
-      if (more) {
+      if (!last_pass) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int r = lane + 64 * j;
@@ -471,73 +504,54 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         wave_sync();
       }
       WTICK(7)
-    }   // passes
+    };
 
-    // ---- 5. the new beams, one per rank: parent fields gathered from the current buffer ----
-    const int nxt = cur ^ 1;
-    bool any_char = false;
 #pragma unroll 1
-    for (int r = lane; r < n_sel; r += 64) {
-      const int src = S.sel_src[r], bi = src >> 8, c = src & 255;
-      const unsigned m = S.meta[cur][bi];
-      const int last = meta_last(m), wlen = meta_wlen(m);
-      const bool stay = (c == V || c == last);
-      unsigned long long key = S.key[cur][bi], whash = S.whash[cur][bi];
-      float lm_text = S.lm_text[cur][bi];
-      int ctx[kMaxCtx];
-#pragma unroll
-      for (int q = 0; q < kMaxCtx; ++q) ctx[q] = S.ctx[cur][bi][q];
-      int wlen_new = wlen;
-      unsigned int appended = 0;
-      unsigned flags = 0;
-      if (stay) {
-        // same text and pending word as the parent: in the LM cache if the parent was, or if this frame put it there;
-        // the commit score of the pending word is inherited with them
-        if ((m & kMetaCached) || (has_space && wlen > 0)) flags |= kMetaCached;
-        flags |= m & kMetaCommit;
-      } else if (c == space_id) {
-        if (wlen > 0) {
-          key = hmix(key, (unsigned long long)c);
-          appended = c + 1;
-          if (use_lm) {
-            lm_text += S.commit_lmd[cur][bi];
-#pragma unroll
-            for (int q = 0; q < kMaxCtx - 1; ++q) ctx[q] = ctx[q + 1];
-            ctx[kMaxCtx - 1] = S.commit_wid[cur][bi];
-          }
-          wlen_new = 0; whash = kFnvOffset;
-        }
-      } else {
-        key = hmix(key, (unsigned long long)c);
-        whash = hmix(whash, (unsigned long long)c);
-        wlen_new = wlen + 1;
-        appended = c + 1;
-      }
-      if (c != V) any_char = true;
-      S.key[nxt][r] = key; S.whash[nxt][r] = whash;
-      S.logit[nxt][r] = __longlong_as_double(S.sel_lgt[r]);
-      S.lm_text[nxt][r] = lm_text;
-      S.meta[nxt][r] = make_meta(c, wlen_new, flags);
-#pragma unroll
-      for (int q = 0; q < kMaxCtx; ++q) S.ctx[nxt][r][q] = ctx[q];
-      S.commit_lmd[nxt][r] = S.commit_lmd[cur][bi];
-      S.commit_wid[nxt][r] = S.commit_wid[cur][bi];
-      bp[(int64_t)t * kMaxBeams + r] = ((unsigned)bi << 8) | appended;
+    for (int c_lo = 0; c_lo < nc_all; c_lo += cap) {
+      const int nc = min(cap, nc_all - c_lo);
+      const bool last_pass = c_lo + cap >= nc_all;
+      const int npairs = nb * nc;
+#ifndef VASR_BEAM_PPLSET
+#define VASR_BEAM_PPLSET 0
+#endif
+#if VASR_BEAM_PPLSET == 0
+      if (npairs <= 64) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
+      else if (npairs <= 128) pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
+      else if (npairs <= 256) pass(std::integral_constant<int, 4>{}, c_lo, nc, last_pass);
+      else pass(std::integral_constant<int, 6>{}, c_lo, nc, last_pass);
+#elif VASR_BEAM_PPLSET == 1
+      if (npairs <= 128) pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
+      else pass(std::integral_constant<int, 6>{}, c_lo, nc, last_pass);
+#elif VASR_BEAM_PPLSET == 2
+      pass(std::integral_constant<int, 6>{}, c_lo, nc, last_pass);
+#else
+      if (npairs <= 64) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
+      else if (npairs <= 192) pass(std::integral_constant<int, 3>{}, c_lo, nc, last_pass);
+      else pass(std::integral_constant<int, 6>{}, c_lo, nc, last_pass);
+#endif
     }
+    // ---- 5. the new beams, one per rank ----
+#pragma unroll 1
+    for (int r = lane; r < n_sel; r += 64) build_child(t, r, S.sel_src[r], S.sel_lgt[r], has_space, any_char);
     all_blank = __ballot(any_char) == 0ull;
     nb = n_sel;
-    cur = nxt;
+    cur ^= 1;
     wave_sync();
     WTICK(8)
   }
 #ifdef VASR_BEAM_PROF
-  if (lane == 0 && b == 0 && frames > 0)
-    printf("wave prof (cycles/frame over %d frames): candidates %lld blank-exit %lld eoslog+setup %lld expand1 %lld expand2 %lld score %lld "
-           "select %lld publish+clear %lld build %lld | general frames %lld pairs/gf %lld entries/gf %lld passes %lld radix digit "
-           "passes %lld select frames %lld live beams %d\n", frames, prof[0] / frames, prof[1] / frames, prof[2] / frames,
-           prof[3] / frames, prof[4] / frames, prof[5] / frames, prof[6] / frames, prof[7] / frames, prof[8] / frames, cnt[0],
-           cnt[1] / max(cnt[0], 1ll), cnt[2] / max(cnt[0], 1ll), cnt[3], cnt[4], cnt[6], nb);
-  long long pt_tail = (long long)__builtin_readcyclecounter();
+  S.hist[lane] = (int)pacc;
+  wave_sync();
+  if (lane == 0 && b == 0 && frames > 0) {
+    const int* P = S.hist;
+    const int gf = max(P[32], 1);
+    printf("wave prof (cycles/frame over %d frames): top %d candidates %d blank-exit %d LM+eoslog %d expand1 %d expand2 %d score %d "
+           "select %d publish %d build %d | general frames %d pairs/gf %d entries/gf %d passes %d radix digit passes %d LM scorings %d "
+           "select frames %d live beams %d\n", frames, P[9] / frames, P[0] / frames, P[1] / frames, P[2] / frames, P[3] / frames,
+           P[4] / frames, P[5] / frames, P[6] / frames, P[7] / frames, P[8] / frames, P[32], P[33] / gf, P[34] / gf, P[35], P[36],
+           P[37], P[38], nb);
+  }
+  const unsigned pt_tail = (unsigned)__builtin_readcyclecounter();
 #endif
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best ----
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     wave_sync();
   }
   // per beam: combined final score, final text key, last-frame combined score (pyctcdecode keeps its beams sorted by it)
-  double* fin = S.lp;                                                      // [kMaxBeams]
+  double* fin = S.fin;                                                     // [kMaxBeams]
   unsigned long long* fkey = reinterpret_cast<unsigned long long*>(S.sel_lgt);   // [kMaxBeams]
   double* frank = reinterpret_cast<double*>(S.sel_tot);                    // [kMaxBeams]
 #pragma unroll
@@ -653,13 +667,13 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   constexpr int kRowRegs = kTbRows * kMaxBeams / 4 / 64;     // uint4 per lane and batch
   uint4 rr[kRowRegs];
   const int nbatch = (frames + kTbRows - 1) / kTbRows;       // batch j: frames (frames - (j + 1) kTbRows, frames - j kTbRows]
-  auto tb_request = [&](int j) {
+  auto tb_request = [&](int j) __attribute__((always_inline)) {
     const int t_hi = frames - 1 - j * kTbRows, t_lo = max(0, t_hi - kTbRows + 1), nq = (t_hi - t_lo + 1) * (kMaxBeams / 4);
     const uint4* g = reinterpret_cast<const uint4*>(bp + (int64_t)t_lo * kMaxBeams);
 #pragma unroll
     for (int k = 0; k < kRowRegs; ++k) rr[k] = 64 * k + lane < nq ? g[64 * k + lane] : make_uint4(0, 0, 0, 0);
   };
-  auto tb_land = [&](int j) {
+  auto tb_land = [&](int j) __attribute__((always_inline)) {
     uint4* dst = reinterpret_cast<uint4*>(rows + (j & 1) * kTbRows * kMaxBeams);
 #pragma unroll
     for (int k = 0; k < kRowRegs; ++k) dst[64 * k + lane] = rr[k];
@@ -710,7 +724,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     out_score[b] = (float)bs;
   }
 #ifdef VASR_BEAM_PROF
-  if (lane == 0 && b == 0) printf("wave prof tail (final pass + trace-back): %lld cycles total\n", (long long)__builtin_readcyclecounter() - pt_tail);
+  if (lane == 0 && b == 0) printf("wave prof tail (final pass + trace-back): %u cycles total\n", (unsigned)__builtin_readcyclecounter() - pt_tail);
 #endif
 }
 
@@ -746,5 +760,8 @@ int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, in
                      out_len, out_score);
   return 0;
 }
+
+unsigned long long beam_hash_step(unsigned long long h, unsigned long long v) { return beam_detail::hmix(h, v); }
+unsigned long long beam_hash_init() { return beam_detail::kFnvOffset; }
 
 }  // namespace vasr

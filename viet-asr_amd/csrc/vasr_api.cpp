@@ -1086,8 +1086,10 @@ size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
 
 int vasr_beam_workgroups(int batch) {
   if (batch <= 0) return 0;
+#ifdef VASR_DEVTOOLS
   static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
   if (wg_kernel) return batch;
+#endif
   const int upw = beam_wave_utts_per_workgroup(batch);
   return (batch + upw - 1) / upw;
 }
@@ -1113,8 +1115,13 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
   // one wavefront per utterance (beam_wave.hip); VASR_BEAM_WG=1 (devtools build) keeps the workgroup-per-utterance kernel of
   // rounds 1-3 for A/B runs
+#ifdef VASR_DEVTOOLS
   static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
-  const int e = (wg_kernel ? launch_beam_search : launch_beam_search_wave)(
+  const auto launch = wg_kernel ? launch_beam_search : launch_beam_search_wave;
+#else
+  const auto launch = launch_beam_search_wave;
+#endif
+  const int e = launch(
       d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width, token_min_logp, beam_prune_logp,
       lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws), d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream),
       d_row_frames);
