@@ -394,6 +394,25 @@ if [ -n "${FUZZ:-}" ]; then
 fi
 }
 
+# ---- r4b: round 4, call B: full GPU suite, default bench, serving-shape latencies, depthwise walk variants at configs[1]
+task_r4b() {
+set -u
+TAG=${1:-r4b2}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python tools/b1_serving.py > $O/b1_vi.json 2> $O/b1_vi.err
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_15x5.json 2>> $O/b1_vi.err
+for u in 0 1 2 4 8; do
+  echo "== VASR_DW_UPW=$u"; VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so VASR_DW_UPW=$u python bench.py --config 2 --steps 30 --warmup 5 --no-cpu-baseline --no-other-gemm 2>/dev/null | python -c "
+import sys,json
+j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(j['ms_per_step'], 'dw', j['depthwise']['ms_per_step'], j['depthwise']['frac'], 'gemm', j['roofline']['ms_per_step'])"
+done > $O/dw_upw.txt 2>&1
+tail -5 $O/pytest.log; cat $O/b1_vi.json $O/b1_15x5.json $O/dw_upw.txt
+}
+
 # ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them
 task_probes() {
 cd $R/tools/probes

@@ -324,56 +324,97 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       int slot[PPL], src[PPL];
       double score[PPL];
       unsigned claimed = 0, act = 0;
-      // ---- expand: every (beam, character) pair claims / finds its slot and raises the slot's max ... ----
+      // ---- expand: every (beam, character) pair claims / finds its slot and raises the slot's max ...  In stages over the
+      //      lane's PPL pairs, so that their LDS round trips overlap: keys and home slots, then ALL first probes, then ALL
+      //      claims (compare-and-swap on the slots that looked empty), and only a pair that met a foreign key walks on alone
+      //      (<= 70 % load, double hashing: few do).  One pair after the other -- each with its own dependent read, swap and
+      //      maximum -- took 1 500-2 500 cycles per 64 pairs, and a frame of 400 pairs ran six of those in a row ----
+      unsigned long long kk[PPL];
+      int stride[PPL];
+      // (branch-free: a lane whose pair index is past the end recomputes the last pair and merely takes no part in the
+      // claims -- with a predicate around each pair's reads the PPL chains ran one after the other instead of together)
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int p = 64 * j + lane;
-        slot[j] = 0; src[j] = 0; score[j] = 0.0;
-        if (p < npairs) {
-          act |= 1u << j;
-          const int bi = (int)(((float)p + 0.5f) * inv_nc);          // p / nc (exact: tests/test_beam.py replays it)
-          const int c = S.cand[c_lo + p - bi * nc];
-          const unsigned m = S.meta[cur][bi];
-          const int last = meta_last(m);
-          unsigned long long key = S.key[cur][bi];
-          score[j] = S.logit[cur][bi] + (double)fminf(lq[c], 0.f);
-          src[j] = (bi << 8) | c;
-          // the prefix grows unless the character is blank, a repeat, or a space with no word pending -- one multiply,
-          // no branches; the "last character" part of the key is a per-class constant (S.cmix)
-          const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
-          const unsigned long long kx = hmix(key, (unsigned long long)c);
-          key = grows ? kx : key;
-          const unsigned long long k = (key ^ S.cmix[c]) | 1ull;                        // (prefix, last char)
-          // home slot and probe stride from the upper bits (bit 0 of k is forced to 1); an odd stride visits every slot
-          // of the power-of-two table: double hashing, no primary clustering
-          int i = (int)((k >> 17) & (kTab - 1));
-          const int stride = (int)((k >> 40) & (kTab - 1)) | 1;
-          while (true) {
-            const unsigned long long e = S.tkey[i];
-            if (e == k) break;
-            if (e == 0) {
-              const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
-              if (old == 0ull) { claimed |= 1u << j; break; }
-              if (old == k) break;
-            }
-            i = (i + stride) & (kTab - 1);
-          }
-          atomicMax(&S.tmx[i], ord64(score[j]));
-          slot[j] = i;
-        }
+        if (p < npairs) act |= 1u << j;
+        const int pp = min(p, npairs - 1);
+        const int bi = (int)(((float)pp + 0.5f) * inv_nc);           // pp / nc (exact: tests/test_beam.py replays it)
+        const int c = S.cand[c_lo + pp - bi * nc];
+        const unsigned m = S.meta[cur][bi];
+        const int last = meta_last(m);
+        unsigned long long key = S.key[cur][bi];
+        score[j] = S.logit[cur][bi] + (double)fminf(lq[c], 0.f);
+        src[j] = (bi << 8) | c;
+        // the prefix grows unless the character is blank, a repeat, or a space with no word pending -- one multiply,
+        // no branches; the "last character" part of the key is a per-class constant (S.cmix)
+        const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
+        const unsigned long long kx = hmix(key, (unsigned long long)c);
+        key = grows ? kx : key;
+        const unsigned long long k = (key ^ S.cmix[c]) | 1ull;                          // (prefix, last char)
+        // home slot and probe stride from the upper bits (bit 0 of k is forced to 1); an odd stride visits every slot
+        // of the power-of-two table: double hashing, no primary clustering
+        kk[j] = k;
+        slot[j] = (int)((k >> 17) & (kTab - 1));
+        stride[j] = (int)((k >> 40) & (kTab - 1)) | 1;
       }
-      wave_sync();
-      WTICK(3)
-      // ---- ... then adds exp(score - max): hardware 2^x on a float (1 ulp); exp2(0) is exactly 1, so a slot with a
-      //      single contributor holds exactly 2^44 ----
+      unsigned long long seen[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) seen[j] = S.tkey[slot[j]];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)        // a slot that looked empty: try to take it (the answer says who holds it now)
+        if ((act >> j & 1) && seen[j] == 0ull) {
+          seen[j] = atomicCAS(&S.tkey[slot[j]], 0ull, kk[j]);
+          if (seen[j] == 0ull) { claimed |= 1u << j; seen[j] = kk[j]; }
+        }
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         if (act >> j & 1) {
-          const float e = __builtin_amdgcn_exp2f((float)((score[j] - unord64(S.tmx[slot[j]])) * 1.4426950408889634));
-          atomicAdd(&S.tsum[slot[j]], (unsigned long long)((double)e * kFix));
+          int i = slot[j];
+          const unsigned long long k = kk[j];
+          if (seen[j] != k) {              // a foreign key sits there: walk on
+            while (true) {
+              i = (i + stride[j]) & (kTab - 1);
+              const unsigned long long e = S.tkey[i];
+              if (e == k) break;
+              if (e == 0) {
+                const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
+                if (old == 0ull) { claimed |= 1u << j; break; }
+                if (old == k) break;
+              }
+            }
+          }
+          // The pair that CLAIMED a slot keeps its score in a register; only a pair that found its key already there -- a
+          // merge: one or two per frame, against hundreds of pairs -- goes through the slot's max / sum words.  (Raising the
+          // max and adding exp(score - max) for EVERY pair were two of the three LDS atomics a pair cost, and the 64-bit LDS
+          // atomics are what a frame with hundreds of pairs is bound by, here as in the workgroup kernel.)
+          if (!(claimed >> j & 1)) atomicMax(&S.tmx[i], ord64(score[j]));
+          slot[j] = i;
         }
       }
+      const bool any_merge = __ballot((act & ~claimed) != 0u) != 0ull;      // uniform
       wave_sync();
+      WTICK(3)
+      // ---- ... a merged slot's max becomes max(claimer, contributors), the contributors add exp(score - max): hardware 2^x
+      //      on a float (1 ulp), as a 2^-44 fixed-point integer -- associative, hence deterministic ----
+      unsigned merged = 0;             // bit j: the slot this lane claimed for pair j has further contributors
+      if (any_merge) {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          if (claimed >> j & 1) {
+            const long long mo = S.tmx[slot[j]];
+            if (mo != ord64(-1e300)) { merged |= 1u << j; S.tmx[slot[j]] = max(mo, ord64(score[j])); }
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          if ((act & ~claimed) >> j & 1) {
+            const float e = __builtin_amdgcn_exp2f((float)((score[j] - unord64(S.tmx[slot[j]])) * 1.4426950408889634));
+            atomicAdd(&S.tsum[slot[j]], (unsigned long long)((double)e * kFix));
+          }
+        }
+        wave_sync();
+      }
       WTICK(4)
       // ---- 3. merged prefixes, each in the lane that claimed its slot: combined score; the slot goes back to empty ----
       long long tot[PPL], lgt[PPL];
@@ -383,29 +424,34 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
 #endif
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
-        tot[j] = ord64(-1e300); lgt[j] = 0;
-        if (claimed >> j & 1) {
-          const int i = slot[j], bi = src[j] >> 8, c = src[j] & 255;
-          const unsigned long long s8 = S.tsum[i];
-          const long long mxo = S.tmx[i];
-          float lmt = 0.f;
-          if (use_lm) {
-            const unsigned m = S.meta[cur][bi];
-            const int last = meta_last(m), wlen = meta_wlen(m);
-            const bool stay = (c == V || c == last);
-            const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
-            lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new);
-            if (!stay && c == space_id && wlen > 0) lmt += S.commit_lmd[cur][bi];       // filled by step 2
-          }
-          S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0;
-          // a slot with a single contributor holds exactly exp(0) * 2^44: no logarithm needed
-          const double logit = unord64(mxo) + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
-          tot[j] = ord64(logit + (double)lmt);
-          lgt[j] = __double_as_longlong(logit);
-          my_best = max(my_best, tot[j]);
+        // (reads unconditional -- every lane has a valid slot and parent for every j -- so that the PPL chains overlap;
+        // only the writes are predicated)
+        const bool mine = claimed >> j & 1;
+        const int i = slot[j], bi = src[j] >> 8, c = src[j] & 255;
+        float lmt = 0.f;
+        if (use_lm) {
+          const unsigned m = S.meta[cur][bi];
+          const int last = meta_last(m), wlen = meta_wlen(m);
+          const bool stay = (c == V || c == last);
+          const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
+          const float commit = S.commit_lmd[cur][bi];                                   // filled by step 2 when it is needed
+          lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new) + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
         }
+        if (mine) S.tkey[i] = 0;
+        // a prefix with a single contributor keeps that pair's score, exactly (exp(0) = 1: no logarithm)
+        double logit = score[j];
+        if (merged >> j & 1) {
+          const double m = unord64(S.tmx[i]);
+          const float e = __builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634));
+          const unsigned long long s8 = S.tsum[i] + (unsigned long long)((double)e * kFix);
+          S.tmx[i] = ord64(-1e300); S.tsum[i] = 0;
+          logit = m + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
+        }
+        tot[j] = mine ? ord64(logit + (double)lmt) : ord64(-1e300);
+        lgt[j] = __double_as_longlong(logit);
+        my_best = max(my_best, tot[j]);
 #ifdef VASR_BEAM_PROF
-        n_claimed += __popcll(__ballot(claimed >> j & 1));
+        n_claimed += __popcll(__ballot(mine));
 #endif
       }
       WCOUNT(2, n_claimed)

@@ -15,7 +15,11 @@ namespace vasr {
 namespace {
 
 
-// grid (ceil(T/64), B), block 64
+// grid (ceil(T/64), B), block 64.  VMAX = classes rounded up to 32: every logit of the lane's frame is requested ONCE, all
+// requests in flight together, and max / sum-exp / log-probs / arg-max run out of registers.  (Rounds 1-3 walked the classes
+// three times with dependent loads: 14 us per batch-1 call at 29 classes, 41 us at the Vietnamese head's 91 -- a tenth of the
+// whole batch-1 pass of QuartzNet12x1.)
+template <int VMAX>
 __global__ __launch_bounds__(64) void logsoftmax_argmax_kernel(const float* __restrict__ logits, int64_t row_ld,
                                                                int64_t batch_stride, int frames, int V,
                                                                float* __restrict__ logp,
@@ -23,20 +27,28 @@ __global__ __launch_bounds__(64) void logsoftmax_argmax_kernel(const float* __re
   extern __shared__ float tile[];  // [64][V + 1]
   const int lane = threadIdx.x, b = blockIdx.y;
   const int t0 = blockIdx.x * 64, t = t0 + lane;
-  const float* x = logits + (int64_t)b * batch_stride + t;
+  const float* x = logits + (int64_t)b * batch_stride + min(t, frames - 1);
   const int n_t = min(64, frames - t0);
+  float xv[VMAX];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) xv[v] = x[(int64_t)min(v, V - 1) * row_ld];
   if (t < frames) {
     float mx = -INFINITY;
-    for (int v = 0; v < V; ++v) mx = fmaxf(mx, x[(int64_t)v * row_ld]);
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) if (v < V) mx = fmaxf(mx, xv[v]);
     float s = 0.f;
-    for (int v = 0; v < V; ++v) s += expf(x[(int64_t)v * row_ld] - mx);
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) if (v < V) s += expf(xv[v] - mx);
     const float ls = logf(s);
     float best = -INFINITY;
     int arg = 0;
-    for (int v = 0; v < V; ++v) {
-      const float lp = (x[(int64_t)v * row_ld] - mx) - ls;
-      if (lp > best) { best = lp; arg = v; }  // strict >: first maximum wins (quirk Q6)
-      if (logp) tile[lane * (V + 1) + v] = lp;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      if (v < V) {
+        const float lp = (xv[v] - mx) - ls;
+        if (lp > best) { best = lp; arg = v; }  // strict >: first maximum wins (quirk Q6)
+        if (logp) tile[lane * (V + 1) + v] = lp;
+      }
     }
     if (pred) pred[(int64_t)b * frames + t] = arg;
   }
@@ -106,8 +118,13 @@ void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch
                               int num_classes, float* logp, int64_t* pred, hipStream_t st) {
   dim3 grid((frames + 63) / 64, batch);
   const size_t lds = logp ? (size_t)64 * (num_classes + 1) * sizeof(float) : 0;
-  hipLaunchKernelGGL(logsoftmax_argmax_kernel, grid, dim3(64), lds, st, logits, row_ld, batch_stride, frames,
-                     num_classes, logp, pred);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, logits, row_ld, batch_stride, frames, num_classes, logp, pred);
+  };
+  if (num_classes <= 32) go(logsoftmax_argmax_kernel<32>);
+  else if (num_classes <= 64) go(logsoftmax_argmax_kernel<64>);
+  else if (num_classes <= 96) go(logsoftmax_argmax_kernel<96>);
+  else go(logsoftmax_argmax_kernel<128>);
 }
 
 void launch_argmax(const float* logp, int batch, int64_t frames, int num_classes, int64_t* pred, hipStream_t st) {

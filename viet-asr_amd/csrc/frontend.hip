@@ -10,6 +10,7 @@
 // even/odd split.  The 64 mel filters map one-per-lane; the [64 mel][32 frame] tile goes
 // back to HBM as 128-byte row segments.
 #include "vasr_internal.h"
+#include "len_chain.h"
 
 namespace vasr {
 
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
 __global__ void seq_len_kernel(const int64_t* __restrict__ len, int batch, int hop, int64_t* __restrict__ seq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   // features.py:238-239  ceil(len.float() / hop).long()
-  if (b < batch) seq[b] = (int64_t)ceilf((float)len[b] / (float)hop);
+  if (b < batch) seq[b] = (int64_t)ceilf((float)len[b] / (float)hop);   // (seq_of below)
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -181,36 +182,68 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// normalize_batch("per_feature") + length mask (features.py:17-30, 287-291).  One wavefront per
-// (utterance, mel bin) row; statistics in double like ATen's CPU Welford accumulator.
-__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ mel, int64_t ld,
-                                                        const int64_t* __restrict__ seq, int rows, int n_mels,
-                                                        int frames, int normalize) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int b = row / n_mels;
-  float* x = mel + (int64_t)row * ld;
-  int64_t n64 = seq[b];
-  const int n = (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64));
+// normalize_batch("per_feature") + length mask (features.py:17-30, 287-291).  One 256-thread workgroup per (utterance,
+// mel bin) row; statistics in double like ATen's CPU Welford accumulator, the four wavefronts' partial sums combined in a
+// fixed order.  (Rounds 1-3 gave a row to ONE wavefront: 16 serial trips over a 10 s row, twice -- 8-11 us at batch 1.)
+// seq: frames per utterance, or nullptr: computed here from the sample counts `len` (features.py:238-239).
+// Workgroups >= rows (normalize_chain_kernel launches ceil(batch / 256) of them) run the encoder's length chain instead
+// (len_chain.h) and publish seq: the chain has no business on the critical path of a batch-1 call, where it was a launch
+// of its own (5-10 us of dependent scalar arithmetic) in front of the encoder.
+__device__ __forceinline__ int64_t seq_of(int64_t len, int hop) { return (int64_t)ceilf((float)len / (float)hop); }
+
+__device__ __forceinline__ void normalize_row(float* __restrict__ x, int n, int frames, int normalize, double* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float mean = 0.f, stdv = 1.f;
   if (normalize) {
     double s = 0.0;
-    for (int t = lane; t < n; t += 64) s += (double)x[t];
+    for (int t = tid; t < n; t += 256) s += (double)x[t];
     s = wave_sum(s);
-    const double mu = s / (double)n;  // n == 0 -> NaN, like torch .mean() of an empty slice
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const double mu = (((red[0] + red[1]) + red[2]) + red[3]) / (double)n;  // n == 0 -> NaN, like torch .mean() of an empty slice
     double q = 0.0;
-    for (int t = lane; t < n; t += 64) { const double d = (double)x[t] - mu; q += d * d; }
+    for (int t = tid; t < n; t += 256) { const double d = (double)x[t] - mu; q += d * d; }
     q = wave_sum(q);
+    if (lane == 0) red[4 + wv] = q;
+    __syncthreads();
     mean = (float)mu;
-    stdv = (float)sqrt(q / (double)(n - 1));  // unbiased; n == 1 -> NaN like torch .std()
+    stdv = (float)sqrt((((red[4] + red[5]) + red[6]) + red[7]) / (double)(n - 1));  // unbiased; n == 1 -> NaN like torch .std()
     stdv = stdv + 1e-5f;                        // features.py:24-25 CONSTANT
   }
-  for (int t = lane; t < frames; t += 64) {
+  for (int t = tid; t < frames; t += 256) {
     float v = 0.f;  // pad_value
     if (t < n) v = normalize ? (x[t] - mean) / stdv : x[t];
     x[t] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ mel, int64_t ld,
+                                                        const int64_t* __restrict__ seq, int rows, int n_mels,
+                                                        int frames, int normalize) {
+  __shared__ double red[8];
+  const int row = blockIdx.x;
+  const int64_t n64 = seq[row / n_mels];
+  normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red);
+}
+
+__global__ __launch_bounds__(256) void normalize_chain_kernel(float* __restrict__ mel, int64_t ld,
+                                                              const int64_t* __restrict__ len, int hop, int batch, int n_mels,
+                                                              int frames, int normalize, int64_t* __restrict__ seq,
+                                                              const LenStep* __restrict__ steps, int n_steps,
+                                                              int32_t* __restrict__ lens_tab, float* __restrict__ enc_len,
+                                                              const int64_t* __restrict__ wav_len, int frames_cap) {
+  __shared__ double red[8];
+  const int rows = batch * n_mels;
+  if ((int)blockIdx.x < rows) {
+    const int row = blockIdx.x;
+    const int64_t n64 = seq_of(len[row / n_mels], hop);
+    normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red);
+    return;
+  }
+  const int b = ((int)blockIdx.x - rows) * 256 + (int)threadIdx.x;
+  const int64_t l0 = b < batch ? seq_of(len[b], hop) : 0;
+  if (b < batch) seq[b] = l0;
+  len_chain_body(b, l0, batch, steps, n_steps, lens_tab, enc_len, wav_len, hop, frames_cap);
 }
 
 }  // namespace
@@ -233,8 +266,15 @@ void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStr
 void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,
                       int normalize, hipStream_t st) {
   const int rows = batch * n_mels;
-  hipLaunchKernelGGL(normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, mel, mel_ld, seq, rows, n_mels,
-                     frames, normalize);
+  hipLaunchKernelGGL(normalize_kernel, dim3(rows), dim3(256), 0, st, mel, mel_ld, seq, rows, n_mels, frames, normalize);
+}
+
+void launch_normalize_chain(float* mel, int64_t mel_ld, const int64_t* len, int hop, int batch, int n_mels, int frames,
+                            int normalize, int64_t* seq, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
+                            float* enc_len, const int64_t* wav_len, int frames_cap, hipStream_t st) {
+  const int rows = batch * n_mels;
+  hipLaunchKernelGGL(normalize_chain_kernel, dim3(rows + (batch + 255) / 256), dim3(256), 0, st, mel, mel_ld, len, hop, batch,
+                     n_mels, frames, normalize, seq, d_steps, n_steps, lens_tab, enc_len, wav_len, frames_cap);
 }
 
 }  // namespace vasr

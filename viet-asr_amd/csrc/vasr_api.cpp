@@ -543,15 +543,18 @@ static int run_pointwise(vasr_handle* h, PwArgs& a, const ConvLayer& W, hipStrea
 // output pitch), for the CTC head of the fused path; the table lives in the workspace until the next encoder pass.
 int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const int64_t* seq, int batch,
                 float* out, int64_t out_ld, float* enc_len, char* ws, const WsPlan& p, hipStream_t st,
-                AmaxTab* enc_amax = nullptr, const int64_t* wav_len = nullptr, const int32_t** own_frames = nullptr) {
+                AmaxTab* enc_amax = nullptr, const int64_t* wav_len = nullptr, const int32_t** own_frames = nullptr,
+                bool chain_done = false) {
   int32_t* lens_tab = reinterpret_cast<int32_t*>(ws + p.lens_tab);
   auto lens = [&](int step) { return lens_tab + (size_t)step * batch; };
   // row-independent mode (fused path): everything the CTC head sees of a row must depend on that row alone, also the
   // fp16 scale of its input -- the encoder output's maxima are then taken over the frames an unbatched call on the row
   // would produce, and the head zeroes the columns behind them (they are not decoded in this mode)
   const bool own = h->row_independent && wav_len != nullptr;
-  launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st, own ? wav_len : nullptr,
-                   h->fe.hop_length, (int)p.T1);
+  // (the fused path has run the chain as extra workgroups of its normalisation launch: launch_normalize_chain)
+  if (!chain_done)
+    launch_len_chain(seq, batch, h->d_steps, (int)h->steps.size(), lens_tab, enc_len, st, own ? wav_len : nullptr,
+                     h->fe.hop_length, (int)p.T1);
   const int32_t* own_tab = own ? lens((int)h->steps.size() + 1) : nullptr;
   if (own_frames) *own_frames = own_tab;
   float* bufs[4] = {reinterpret_cast<float*>(ws + p.bufP), reinterpret_cast<float*>(ws + p.bufQ),
@@ -940,15 +943,19 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
   float* logits = reinterpret_cast<float*>(ws + p.logits);
   int64_t* pred = d_pred ? d_pred : reinterpret_cast<int64_t*>(ws + p.pred);
   {
+    // two launches: the STFT / log-mel tiles, then the per-feature normalisation whose launch also carries (as extra
+    // workgroups) seq = ceil(len / hop) and the encoder's length chain -- three launches fewer on the critical path of a
+    // batch-1 call than seq_len + stft + normalize + len_chain
     ProfScope ps(h, kProfFrontend, st);
-    launch_seq_len(d_len, batch, h->fe.hop_length, seq, st);
     launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
                        h->fe.preemph, h->fe.log_guard, melp, p.Tp0, (int)T, st);
-    launch_normalize(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, h->fe.normalize, st);
+    launch_normalize_chain(melp, p.Tp0, d_len, h->fe.hop_length, batch, h->fe.n_mels, (int)T, h->fe.normalize, seq,
+                           h->d_steps, (int)h->steps.size(), reinterpret_cast<int32_t*>(ws + p.lens_tab), d_enc_len,
+                           h->row_independent ? d_len : nullptr, (int)p.T1, st);
   }
   AmaxTab enc_amax{};
   const int32_t* own_frames = nullptr;
-  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st, &enc_amax, d_len, &own_frames);
+  int rc = run_encoder(h, melp, p.Tp0, T, seq, batch, encp, p.Tp1, d_enc_len, ws, p, st, &enc_amax, d_len, &own_frames, true);
   if (rc) return rc;
   if ((rc = run_decoder(h, encp, p.Tp1, p.T1, batch, logits, d_logp, pred, st, enc_amax, own_frames))) return rc;
   if (d_ids && d_id_len) {

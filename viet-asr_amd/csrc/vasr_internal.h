@@ -96,6 +96,11 @@ struct LenStep { int32_t kernel, stride, dilation, pad; };
 // lens_tab[s][b] = mask length seen by the s-th MaskedConv1d of the main chain; row n_steps = after
 // the last one; enc_len[b] = the reference's float length (quirk Q3).  wav_len (optional): row n_steps + 1 = the
 // output frames an unbatched call on the row would produce, capped at frames_cap (row-independent mode).
+// fused path: per-feature normalisation of the log-mel rows + (as extra workgroups of the same launch) seq = ceil(len / hop)
+// and the length chain
+void launch_normalize_chain(float* mel, int64_t mel_ld, const int64_t* len, int hop, int batch, int n_mels, int frames,
+                            int normalize, int64_t* seq, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
+                            float* enc_len, const int64_t* wav_len, int frames_cap, hipStream_t st);
 void launch_len_chain(const int64_t* seq, int batch, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
                       float* enc_len, hipStream_t st, const int64_t* wav_len = nullptr, int hop = 1, int frames_cap = 0);
 
