@@ -413,6 +413,27 @@ done > $O/dw_upw.txt 2>&1
 tail -5 $O/pytest.log; cat $O/b1_vi.json $O/b1_15x5.json $O/dw_upw.txt
 }
 
+# ---- final_r04: round-4 record: full GPU suite, kernel stats + PMC traffic of the bench, bench lines (default with every config,
+#      10.3 s, configs 2 / 4 / 5 on their own), kernel stats of the reference's serving shape (batch 1, 12x1_vi, greedy + beam)
+task_final_r04() {
+set -u
+TAG=${1:-r04}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+cp $R/gpurun_out/parity_errors.jsonl $O/parity_errors.jsonl 2>/dev/null
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+bash tools/profile_round.sh $TAG > $O/profile.log 2>&1
+python bench.py --seconds 10.3 --no-cpu-baseline --no-other-gemm --no-side-configs > $O/bench_10p3s.json 2> /dev/null
+for c in 2 4 5; do timeout 300 python bench.py --config $c --steps $([ $c = 5 ] && echo 5 || echo 20) --warmup 3 --no-other-gemm --no-cpu-baseline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+python tools/b1_serving.py > $O/b1_vi12x1.json 2> /dev/null
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_15x5.json 2> /dev/null
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b1 -- python $R/tools/b1_serving.py --calls 30 > /dev/null 2> $O/stats_b1.err
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*.db' -delete
+cd $R; tail -3 $O/pytest.log; cat $O/smoke.log | tail -2; ls $O
+}
+
 # ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them
 task_probes() {
 cd $R/tools/probes
