@@ -125,7 +125,7 @@ def usable_cores():
     return n, src
 
 
-def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0):
+def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0, batch=64, clip_seconds=10.0):
     """Time the CPU oracle (port of the reference path on the same ATen CPU ops) on a bounded sample of the workload:
     best of up to 5 runs after one warm-up, inside ~25 s, on as many intra-op threads as the process can really use
     (usable_cores), which is what `cores` reports."""
@@ -142,7 +142,10 @@ def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0):
         b, seconds = 1, 2.0       # the restated pyctcdecode loop is pure Python: one 2 s utterance is ~10 s of CPU
         lm = BO.LanguageModel(BO.NgramLM.from_arpa(lm_path), alpha=0.5, beta=1.5) if lm_path else None
     else:
-        b, seconds = 4, 10.0
+        # the workload's own batch when that is <= 640 audio-seconds (the headline: 64 x 10 s, ~2.3 s per run on 16 cores),
+        # else as many of its clips as fit that bound
+        seconds = clip_seconds
+        b = max(1, min(batch, int(640.0 / seconds)))
     sig, lens = synth.audio_batch(b, int(seconds * 16000), seed, ragged=False)
 
     def once():
@@ -802,7 +805,7 @@ def main():
             launches_b1 = sum(p1[k]["launches"] for k in ("depthwise", "pointwise", "fused")) + 3 + 3 + 1
             out["sol"] = sol_block(cfg, work, batch, samples, elapsed / a.steps * 1e3, launches_b1)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, seed, decoder, lm_path)
+            out["cpu_baseline"] = cpu_baseline(model, seed, decoder, lm_path, batch=batch, clip_seconds=seconds)
         if dist is not None:
             import ctypes
             ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in C stdio's buffer: keep the JSON line last
