@@ -142,10 +142,10 @@ def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0, batch=64, clip_se
         b, seconds = 1, 2.0       # the restated pyctcdecode loop is pure Python: one 2 s utterance is ~10 s of CPU
         lm = BO.LanguageModel(BO.NgramLM.from_arpa(lm_path), alpha=0.5, beta=1.5) if lm_path else None
     else:
-        # the workload's own batch when that is <= 640 audio-seconds (the headline: 64 x 10 s, ~2.3 s per run on 16 cores),
-        # else as many of its clips as fit that bound
-        seconds = clip_seconds
-        b = max(1, min(batch, int(640.0 / seconds)))
+        # 4 clips: the batch at which the CPU path is FASTEST per audio-second (measured on the GPU box's 16 cores: 292x real
+        # time at 4 x 10 s, 77x at the workload's own 64 x 10 s, whose 67 MB activations per layer fall out of the caches) --
+        # the baseline gets its best configuration, the whole-batch figure is reported beside it (`full_batch`)
+        b, seconds = 4, 10.0
     sig, lens = synth.audio_batch(b, int(seconds * 16000), seed, ragged=False)
 
     def once():
@@ -165,9 +165,17 @@ def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0, batch=64, clip_se
             t0 = time.perf_counter()
             once()
             times.append(time.perf_counter() - t0)
+    full = None
+    if decoder != "beam" and batch * clip_seconds <= 640.0 and batch > b:
+        fs, fl = synth.audio_batch(batch, int(clip_seconds * 16000), seed, ragged=False)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.ctc_decode_strings(O.forward_all(fs, fl, enc_sd, dec_sd, jas)["pred"], cfg["labels"])
+            dt = time.perf_counter() - t0
+        full = {"value": round(batch * clip_seconds / dt, 2), "sample": f"the workload's own batch, {batch} x {clip_seconds:g} s, one run"}
     torch.set_num_threads(prev_threads)
     best = min(times)
-    return {"value": round(b * seconds / best, 2), "unit": "audio-sec/wall-sec", "cores": cores, "cores_how": how,
+    return {"value": round(b * seconds / best, 2), "full_batch": full, "unit": "audio-sec/wall-sec", "cores": cores, "cores_how": how,
             "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{model} {decoder}{' beam 128 + 3-gram LM' if decoder == 'beam' else ''}, batch {b} x {seconds:g} s, "
                       f"best of {len(times)} after 1 warm-up, {cores} intra-op threads"
