@@ -681,7 +681,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[8] = {0, 512, 256, 128, 64, 256, 256, 32};
+  const int rows[9] = {0, 512, 256, 128, 64, 256, 256, 32, 512};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
@@ -705,7 +705,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     const int64_t n1 = blocks(512, 128), rounds = (n1 + cus - 1) / cus;
     if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
-  if (force >= 1 && force <= 7 && a.M % rows[force] == 0) tile = force;
+  if (force >= 1 && force <= 8 && a.M % rows[force] == 0) tile = force;
   static const int phase_delay = dev_env("VASR_PW_PHASE") ? atoi(dev_env("VASR_PW_PHASE")) : 0;   // 10 ns ticks (dev)
   a.phase_delay = phase_delay;
   switch (tile) {
@@ -716,6 +716,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     // (256 x 128 on FOUR wavefronts, two workgroups per CU -- possible with the 64 KB of the two-plane arithmetics -- measured
     // slower than one 512 x 128 workgroup: 57.5 vs 54.6 us on a 512-channel layer; one wavefront per SIMD and workgroup does
     // not cover its own waits, and every workgroup converts the whole activation tile again)
+    case 8: return launch_t<8, 2, 2>(a, arith, st, amax_n);   // 512 x 64 (dev: half-filled chips, configs[1])
     case 7: return launch_t<1, 1, 1>(a, arith, st, amax_n);   // 32 x 32 on one wavefront (dev: batch-1 experiment)
     case 3: return launch_t<4, 1, 2>(a, arith, st, amax_n);
     default: return launch_t<2, 1, 1>(a, arith, st, amax_n);
