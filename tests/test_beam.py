@@ -372,3 +372,23 @@ def test_wave_kernel_and_workgroup_kernel_agree(gpu, tmp_path):
         for r_ in range(len(n_a)):
             assert (ids_a[r_, : n_a[r_]] == ids_b[r_, : n_b[r_]]).all(), (k, r_)
         assert a[2] == b[2], k            # scores, bit for bit
+
+
+@pytest.mark.gpu
+def test_beam_search_on_a_long_recording_takes_the_long_transcript_path(gpu):
+    """beam_wave.hip assembles a transcript in LDS when the utterance has <= 3 072 frames and goes through HBM (characters
+    written from the back of the id row, then moved to its front) beyond that: 3 500 frames (70 s of audio) against the
+    oracle, next to the same posteriors cut to 3 000 frames (the LDS path), narrow beam so that the Python oracle finishes."""
+    from viet_asr_amd.beam import BeamSearchDecoder
+    lp = ctc_like_posteriors(3500, 29, 4242, p_blank=0.7)
+    dec = BeamSearchDecoder(LABELS, lm_path=None)
+    for T in (3500, 3000):
+        x = torch.from_numpy(lp[None, :T].copy()).to(gpu)
+        ids, n, score = dec.decode_ids(x, 8)
+        text = "".join(LABELS[c] for c in ids[0, : int(n[0])].tolist())
+        ref = BO.decode_beams(np.exp(lp[:T].astype(np.float64)), LABELS, 8)
+        close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
+        assert text == ref[0][0] or (close and text == ref[1][0]), (T, text[:60], ref[0][0][:60])
+        assert len(text) > 200                      # a transcript long enough to matter
+        if text == ref[0][0]:
+            assert abs(float(score[0]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50)
