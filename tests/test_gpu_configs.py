@@ -1,10 +1,11 @@
 """-m gpu: the HIP path at BASELINE.json's OWN sizes -- configs[2] (15x5 greedy, 64 x 10 s), configs[3] (15x5 log-probs ->
 beam 128 + n-gram LM, 64 x 501 frames) and one GPU's shard of configs[4] (512 x 30 s at 8 kHz -> 16 kHz -> 15x5 greedy).
 
-The oracle cannot run whole batches of that size in seconds, so each test checks (a) sampled rows against the oracle --
-legitimate because full-length rows of a padded batch do not depend on the other rows (quirk Q5 only touches rows
-shorter than the batch maximum), which the batch-invariance test pins bit-for-bit -- and (b) size-independent properties
-on every row.  Reference wiring: /root/reference/infer.py:132-160 (DAG), :194-206 (CLI loop)."""
+Each test here checks (a) sampled rows against the oracle -- legitimate because full-length rows of a padded batch do not
+depend on the other rows (quirk Q5 only touches rows shorter than the batch maximum), which the batch-invariance test pins
+bit-for-bit -- and (b) size-independent properties on every row.  The WHOLE batches, every row and every frame against the
+oracle with a recorded flip count, are in tests/test_gpu_flips.py (round 4: the oracle runs 64 x 10 s in 2-3 s on the GPU
+box's host cores).  Reference wiring: /root/reference/infer.py:132-160 (DAG), :194-206 (CLI loop)."""
 import os
 import subprocess
 import sys
