@@ -94,7 +94,12 @@ def test_config2_quartznet12x1_vi_b32_10s_full_size(gpu):
     sig, lens = synth.audio_batch(32, 160000, 2)
     wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
     r = eng.forward(wav, ln, want_logp=True)
+    eng.handle.profile_begin()
     r2 = eng.forward(wav, ln, want_logp=True)
+    torch.cuda.synchronize()
+    # round 4: the six 256-channel sub-blocks (each with its folded residual) are ONE kernel each here as well -- 32 x 4 tiles
+    # of 128 frames would fill half the chip, the kernel's 64-frame form fills it
+    assert eng.handle.profile_end()["fused"]["launches"] == 6
     assert torch.equal(r["logp"], r2["logp"]) and torch.equal(r["pred"], r2["pred"])
     assert r["logp"].shape == (32, 501, 91) and bool(torch.isfinite(r["logp"]).all())
     assert float(torch.logsumexp(r["logp"].double(), -1).abs().max()) < 1e-3

@@ -320,6 +320,7 @@ print("ALT_PATH_OK" if not bad else "ALT_PATH_BAD %r" % bad)
                                  {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "2"}, {"VASR_GEMM": "f16x2", "VASR_PW3_TILE": "3"},
                                  {"VASR_GEMM": "bf16x3", "VASR_PW3_TILE": "4"}, {"VASR_DW_MFMA": "0"}, {"VASR_DW_UPW": "3"},
                                  {"VASR_FUSED_MIN_TILES": "1"}, {"VASR_FUSED": "0"},
+                                 {"VASR_FUSED_MIN_TILES": "1", "VASR_FUSED_TILE": "64"},
                                  {"VASR_FUSED_MIN_TILES": "1", "VASR_NO_FUSED_RESIDUAL": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_paths_match_goldens(gpu, env):

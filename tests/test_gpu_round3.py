@@ -227,8 +227,10 @@ print("FUSED_FUZZ_OK" if not bad else "FUSED_FUZZ_BAD %r" % bad)
 """
 
 
-def test_fused_depthwise_pointwise_kernel_on_random_shapes(gpu):
-    """The fused sub-block kernel forced onto small random workloads (devtools build, VASR_FUSED_MIN_TILES=1): random stacks
+@pytest.mark.parametrize("tile", ["128", "64"])
+def test_fused_depthwise_pointwise_kernel_on_random_shapes(gpu, tile):
+    """The fused sub-block kernel -- its 128-frame and (round 4) its 64-frame tile -- forced onto small random workloads
+    (devtools build, VASR_FUSED_MIN_TILES=1, VASR_FUSED_TILE): random stacks
     of 256-channel blocks (K = 33 / 39, repeats 1-5, residual or not), ragged batches with rows that leave whole tiles
     empty, utterances at very different levels -- against the oracle with the goldens' tolerance; every case must really
     have gone through the fused kernel (profile class count)."""
@@ -238,7 +240,7 @@ def test_fused_depthwise_pointwise_kernel_on_random_shapes(gpu):
     here = os.path.dirname(os.path.abspath(__file__))
     dev = os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so")
     code = _FUSED_FUZZ.format(tests=here, root=os.path.dirname(here), n=10)
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VASR_LIB_PATH": dev, "VASR_FUSED_MIN_TILES": "1"},
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VASR_LIB_PATH": dev, "VASR_FUSED_MIN_TILES": "1", "VASR_FUSED_TILE": tile},
                          capture_output=True, text=True, timeout=900)
     assert "FUSED_FUZZ_OK" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
 

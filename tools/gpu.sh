@@ -413,6 +413,30 @@ done > $O/dw_upw.txt 2>&1
 tail -5 $O/pytest.log; cat $O/b1_vi.json $O/b1_15x5.json $O/dw_upw.txt
 }
 
+# ---- fused64: the fused depthwise + pointwise kernel on 64-frame tiles (round 4): parity (fuzz on both tiles, goldens forced through
+#      the 64-frame form), then ms per step of 12x1_vi / 15x5 at batches between the fill rules, per kernel choice
+task_fused64() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/fused64; mkdir -p $O
+if [ "${1:-all}" != time ]; then
+timeout 600 python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -x \
+  -k "fused_depthwise_pointwise_kernel or (alternate_kernel_paths and FUSED)" 2>&1 | tail -15
+fi
+[ "${1:-all}" = test ] && return
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+line() { python -c "
+import sys,json
+j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('%.4f ms  fused %.4f (%s)  dw %.4f  gemm %.4f' % (j['ms_per_step'], j['fused']['ms_per_step'], j['fused'].get('launches_per_step'), j['depthwise']['ms_per_step'], j['roofline']['ms_per_step']))"; }
+for cfg in ${FUSED64_CASES:-2:24 2:32 2:48 3:24 3:32 3:40}; do
+  c=${cfg%%:*}; b=${cfg##*:}
+  for v in off t128 t64 rule; do
+    case "${FUSED64_V:-off t128 t64 rule}" in *$v*) ;; *) continue ;; esac
+    case $v in off) e="VASR_FUSED=0" ;; t128) e="VASR_FUSED_MIN_TILES=1 VASR_FUSED_TILE=128" ;; t64) e="VASR_FUSED_MIN_TILES=1 VASR_FUSED_TILE=64" ;; rule) e="VASR_NONE=1" ;; esac
+    echo -n "config $c batch $b  $v: "
+    env $e python bench.py --config $c --batch $b --steps 40 --warmup 5 --no-cpu-baseline --no-other-gemm --no-side-configs 2>/dev/null | line
+  done
+done | tee $O/matrix.txt
+}
+
 # ---- final_r04: round-4 record: full GPU suite, kernel stats + PMC traffic of the bench, bench lines (default with every config,
 #      10.3 s, configs 2 / 4 / 5 on their own), kernel stats of the reference's serving shape (batch 1, 12x1_vi, greedy + beam)
 task_final_r04() {

@@ -7,7 +7,10 @@
 // C = 256 blocks of QuartzNet (K = 33 / 39; 30 of the 75 separable sub-blocks of 15x5).  The depthwise output never goes
 // to HBM: 33.5 MB written + 33.5 MB read again per sub-block at 64 x 10 s, one launch and its dispatch gap.
 //
-// Structure: a workgroup owns ALL 256 input and output channels of a 128-frame time tile and is split by ROLE
+// Structure (numbers for the 128-frame tile; the 64-frame form of round 4 -- template parameter BN, FTile -- halves the
+// columns of every role: 8 frames per producer lane, 2 x 2 MFMA tiles per consumer, 110 KB of LDS; it is the form for
+// batches whose 128-frame tiles would leave the chip half empty, vasr_api.cpp run_encoder):
+// a workgroup owns ALL 256 input and output channels of a 128-frame time tile and is split by ROLE
 // (wave specialisation -- one kernel, two instruction streams, no compiler-interleaved software pipeline):
 //
 //   wavefronts 4..7  PRODUCERS, vector ALU.  Per 64-channel chunk each takes 16 channels = 8 channel pairs.  The masked
@@ -48,13 +51,23 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int FC = 256;     // channels in = out
-constexpr int FBN = 128;    // tile columns
 constexpr int FCH = 64;     // channels per chunk (4 k-steps of 16)
 constexpr int FNT = 512;    // threads: 4 consumer + 4 producer wavefronts
-constexpr int kBimgBytes = 2 * 2 * 4 * 2 * FBN * 16;   // [buf][plane][k-step][k-half][column] x 16 B = 65536
-constexpr int kWPitch = 1664;                          // bytes per channel pair of a producer window (= 128 mod 256)
-constexpr int kWWave = 8 * kWPitch;                    // 13312
-constexpr int kWinBytes = 4 * kWWave;                  // 53248
+
+// Tile width BN (columns = frames per workgroup): 128 where such tiles fill the chip, 64 for the batches in between (24-47
+// utterances of 10 s: 192-376 tiles of 64 frames against 96-188 of 128).  Everything below that depends on it:
+template <int BN>
+struct FTile {
+  static_assert(BN == 128 || BN == 64, "tile width");
+  static constexpr int FPS = BN / 8;                       // frames per producer lane (8 segments per channel pair): 16 / 8
+  static constexpr int NT = BN / 32;                       // 32-column MFMA tiles of a consumer wavefront: 4 / 2
+  static constexpr int KHS = BN == 128 ? 3 : 2;            // bit of the k-half in the B image's column swizzle
+  static constexpr int kBimgBytes = 2 * 2 * 4 * 2 * BN * 16;   // [buf][plane][k-step][k-half][column] x 16 B = 65536 / 32768
+  static constexpr int kWPitch = BN == 128 ? 1664 : 1152;  // bytes per channel pair of a producer window (= 128 mod 256)
+  static constexpr int kWWave = 8 * kWPitch;               // 13312 / 9216
+  static constexpr int kWinBytes = 4 * kWWave;             // 53248 / 36864
+  static constexpr int kSegBytes = FPS * 8 + 16;           // a lane's segment of its pair's window row incl. its pad: 144 / 80
+};
 
 #ifndef VASR_FUSED_PLAINFMA
 #define VASR_FUSED_PLAINFMA 0   // 1: v_fma_f32 pairs instead of v_pk_fma_f32 (compile with -fno-slp-vectorize)
@@ -74,28 +87,31 @@ constexpr int kWinBytes = 4 * kWWave;                  // 53248
                               // 128 no window staging (LDS writes + reads)
 #endif
 
-template <int K>
+template <int K, int BN>
 struct FGeom {
+  using TL = FTile<BN>;
+  static constexpr int FPS = TL::FPS;
   static constexpr int PAD = K / 2;                              // get_same_padding, stride 1, dilation 1 (jasper.py:60-65)
   static constexpr int PADL = (PAD + 3) & ~3;                    // window origin t0 - PADL: 16-byte aligned in x
   static constexpr int OFF = PADL - PAD;
-  static constexpr int W = (PADL + FBN + (K - 1 - PAD) + 3) & ~3;   // window frames: 160 (K = 33), 168 (K = 39)
+  static constexpr int W = (PADL + BN + (K - 1 - PAD) + 3) & ~3;    // window frames: 160 (K = 33), 168 (K = 39); 96 / 104 at BN = 64
   static constexpr int W4 = W / 4;
-  static constexpr int NLD = (8 * W4 + 63) / 64;                 // (pair, float4-column) items per lane: 5 / 6
-  static constexpr int NF = OFF + 15 + K;                        // frames a lane reads from its region's start
+  static constexpr int NLD = (8 * W4 + 63) / 64;                 // (pair, float4-column) items per lane: 5 / 6 (3 / 4)
+  static constexpr int NF = OFF + FPS - 1 + K;                   // frames a lane reads from its region's start
   static constexpr int NR = (NF + 1) / 2;                        // ds_read_b128 per lane (two interleaved frames each)
   static constexpr int KP = (K + 2) & ~1;                        // taps per pair in the LDS table (zero padded, even)
   static constexpr int TB = 8;                                   // taps per block of the sliding window
   static constexpr int NB = (K + TB - 1) / TB;
   static constexpr int kTapBytes = (FC / 2) * KP * 8;
-  static constexpr size_t LDS = (size_t)kBimgBytes + kWinBytes + kTapBytes;
-  static_assert(W * 8 + ((W + 15) / 16) * 16 <= kWPitch, "window row does not fit its pitch");
-  static_assert(16 * 7 + 2 * NR <= W, "a lane's reads leave the window");
+  static constexpr size_t LDS = (size_t)TL::kBimgBytes + TL::kWinBytes + kTapBytes;
+  static_assert(W * 8 + ((W + FPS - 1) / FPS) * 16 <= TL::kWPitch, "window row does not fit its pitch");
+  static_assert(FPS * 7 + 2 * NR <= W, "a lane's reads leave the window");
+  static_assert(NLD >= FPS / 4, "the residual rows of a lane use the staging registers of the window items");
   static_assert(LDS <= 163840, "LDS budget");
-  // last b128 unit (exclusive) a tap block needs: frames < OFF + min(K, TB (blk + 1)) + 15
+  // last b128 unit (exclusive) a tap block needs: frames < OFF + min(K, TB (blk + 1)) + FPS - 1
   static constexpr int qend(int blk) {
     const int k1 = TB * (blk + 1) < K ? TB * (blk + 1) : K;
-    return (OFF + k1 + 15 + 1) / 2;
+    return (OFF + k1 + FPS - 1 + 1) / 2;
   }
 };
 
@@ -137,19 +153,24 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 // B image: element (plane, k-step ks, k-half kh, column n) is one 16-byte slot (8 consecutive channels of one frame).
-// The column index is swizzled inside its aligned group of 16 -- low4 ^= (n >> 4) | (kh << 3) -- so that the producers'
-// 4-byte writes (8 lanes of one pair sit 16 columns apart: the same bank unswizzled) and the consumers' 16-byte reads
-// are both conflict free.
-__device__ __forceinline__ int bimg_slot(int n, int kh) { return (n & ~15) | ((n & 15) ^ ((n >> 4) | (kh << 3))); }
-__device__ __forceinline__ constexpr int bimg_off(int buf, int plane, int ks) { return (((buf * 2 + plane) * 4 + ks) * 2) * FBN * 16; }
+// The column index is swizzled inside its aligned group of 16 -- low4 ^= (n >> 4) | (kh << KHS) -- so that the producers'
+// 4-byte writes (8 lanes of one pair sit 16 (8) columns apart: the same bank(s) unswizzled) and the consumers' 16-byte
+// reads are both conflict free.  (BN = 64: the 8 lanes of a pair give low4 ^ j = {0, 8, 1, 9, 2, 10, 3, 11}, the other
+// k-half the same set ^ 4.)
+template <int BN>
+__device__ __forceinline__ int bimg_slot(int n, int kh) { return (n & ~15) | ((n & 15) ^ ((n >> 4) | (kh << FTile<BN>::KHS))); }
+template <int BN>
+__device__ __forceinline__ constexpr int bimg_off(int buf, int plane, int ks) { return (((buf * 2 + plane) * 4 + ks) * 2) * BN * 16; }
 
-template <int K, bool DUAL>
+template <int K, bool DUAL, int BN>
 __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int tiles_t, int n_blocks) {
-  using G = FGeom<K>;
+  using G = FGeom<K, BN>;
+  using TL = FTile<BN>;
+  constexpr int FPS = TL::FPS, NT = TL::NT, kWPitch = TL::kWPitch, kWWave = TL::kWWave;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* bimg = smem;
-  unsigned char* wins = smem + kBimgBytes;
-  unsigned char* tapl = smem + kBimgBytes + kWinBytes;
+  unsigned char* wins = smem + TL::kBimgBytes;
+  unsigned char* tapl = smem + TL::kBimgBytes + TL::kWinBytes;
 
   int bid = blockIdx.x;
   {   // XCD-aware order: consecutive tiles of an utterance on one XCD (its L2 then serves the neighbouring windows' halo)
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   }
   const int b = bid / tiles_t;
   const int tile = bid % tiles_t;
-  const int t0 = tile * FBN;
+  const int t0 = tile * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (VASR_FUSED_SWAP ? 4 : 0)) & 7;   // role index: < 4 consumes
   const int len_in = a.lens_in[b], len_out = a.lens_out[b];
@@ -203,18 +224,18 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
     constexpr int ksteps = NCH * 4;
     const uint4* __restrict__ ap = a.wt + ((int64_t)(wm / 32) * ksteps) * 2 * 64 + lane;
     const int64_t a_tile = (int64_t)ksteps * 2 * 64;
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (live) {
-      // B-fragment addresses of the four n-tiles (swizzled column, k-half): constant over the whole tile
-      int boff[4];
+      // B-fragment addresses of the n-tiles (swizzled column, k-half): constant over the whole tile
+      int boff[NT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) boff[j] = (kh * FBN + bimg_slot(32 * j + l31, kh)) * 16;
+      for (int j = 0; j < NT; ++j) boff[j] = (kh * BN + bimg_slot<BN>(32 * j + l31, kh)) * 16;
       uint4 aw[4][2][2];   // weight fragments, set = k-step % 4, requested three k-steps ahead: [set][m-tile][plane]
       auto aload = [&](int s, uint4 (&dst)[2][2]) {
         const int sc = s < ksteps ? s : ksteps - 1;
@@ -246,8 +267,8 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           uint4 bf[3][2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            bf[0][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off(cc, p, 0) + boff[0]);
-            bf[1][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off(cc, p, 0) + boff[1]);
+            bf[0][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off<BN>(cc, p, 0) + boff[0]);
+            bf[1][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off<BN>(cc, p, 1 / NT) + boff[1 % NT]);
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -256,12 +277,12 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
             __builtin_amdgcn_sched_barrier(0);
             uint4 (&cw)[2][2] = aw[s];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int g = s * 4 + j, cur_f = g % 3, nxt_f = (g + 2) % 3;
-              if (g + 2 < 16) {
+            for (int j = 0; j < NT; ++j) {
+              const int g = s * NT + j, cur_f = g % 3, nxt_f = (g + 2) % 3;
+              if (g + 2 < 4 * NT) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
-                  bf[nxt_f][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off(cc, p, (g + 2) / 4) + boff[(g + 2) % 4]);
+                  bf[nxt_f][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off<BN>(cc, p, (g + 2) / NT) + boff[(g + 2) % NT]);
               }
               __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to two MFMAs before their use)
               if (!(VASR_FUSED_ABLATE & 1)) {
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
     const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
     unsigned ymax = 0;
     const float relu_floor = (a.relu & 1) ? 0.f : -__builtin_inff();
-    float* stage = reinterpret_cast<float*>(wins + wave * kWWave);   // 2 x 8 rows x 128 columns = 8 KB of 13 KB
+    float* stage = reinterpret_cast<float*>(wins + wave * kWWave);   // 2 x 8 rows x BN columns = 8 KB of 13 KB (4 of 9)
     // every pass's BN scale / shift BEFORE the first store: stores count in vmcnt like loads, so a load issued between
     // two passes makes its consumer wait (vmcnt(0)) for every store before it -- eight store round trips in series
     v4f scv[2][4], shv[2][4];
@@ -300,27 +321,27 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float* buf = stage + ((i * 4 + q) & 1) * (8 * FBN);
+        float* buf = stage + ((i * 4 + q) & 1) * (8 * BN);
         const int mq = wm + i * 32 + 8 * q;
         const v4f sc = scv[i][q], sh = shv[i][q];
         wave_fence();
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            buf[(4 * kh + rr) * FBN + 32 * j + l31] = fmaf(acc[i][j][4 * q + rr] * out_scale, sc[rr], sh[rr]);
+          for (int j = 0; j < NT; ++j)
+            buf[(4 * kh + rr) * BN + 32 * j + l31] = fmaf(acc[i][j][4 * q + rr] * out_scale, sc[rr], sh[rr]);
         wave_fence();
         // straight-line pass (no uniform branch per piece: see encoder_pw_split.hip's epilogue): all row pieces requested
         // together, ReLU as a maximum with a uniform floor
-        v4f pv[4];
+        v4f pv[NT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int f = lane + 64 * k, row = f / (FBN / 4), c4 = f % (FBN / 4);
-          pv[k] = *reinterpret_cast<const v4f*>(buf + row * FBN + 4 * c4);
+        for (int k = 0; k < NT; ++k) {
+          const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
+          pv[k] = *reinterpret_cast<const v4f*>(buf + row * BN + 4 * c4);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int f = lane + 64 * k, row = f / (FBN / 4), c4 = f % (FBN / 4);
+        for (int k = 0; k < NT; ++k) {
+          const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
           const int m = mq + row, t = t0 + 4 * c4;
           const v4f v = __builtin_elementwise_max(pv[k], v4f{relu_floor, relu_floor, relu_floor, relu_floor});
           if (!(VASR_FUSED_ABLATE & 4)) *reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t) = v;
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   if (!live) return;
   if (VASR_FUSED_PRIO_P) __builtin_amdgcn_s_setprio(VASR_FUSED_PRIO_P);
   const int pw = wave - 4;                    // k-step of the chunk this wavefront produces
-  const int p = lane >> 3, s = lane & 7;      // channel pair, 16-frame segment
+  const int p = lane >> 3, s = lane & 7;      // channel pair, segment of FPS frames
   unsigned char* win = wins + pw * kWWave;
   // the rows of a chunk as (pair, float4 column) items: item = lane + 64 j
   auto item = [&](int j, int& sp, int& q) { const int idx = lane + 64 * j; sp = idx / G::W4; q = idx - sp * G::W4; };
@@ -360,11 +381,11 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
       st[j][1] = *reinterpret_cast<const v4f*>(r0 + a.ldx);
     }
   };
-  // residual chunks: 2 rows x 16 frames per lane, no halo (st[0..3] hold them)
+  // residual chunks: 2 rows x FPS frames per lane, no halo (st[0 .. FPS / 4) hold them)
   auto gload_x2 = [&](int c) {
-    const float* xb = a.x2 + ((int64_t)b * FC + (c - FC / FCH) * FCH + pw * 16 + 2 * p) * a.ldx2 + t0 + 16 * s;
+    const float* xb = a.x2 + ((int64_t)b * FC + (c - FC / FCH) * FCH + pw * 16 + 2 * p) * a.ldx2 + t0 + FPS * s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < FPS / 4; ++j) {
       st[j][0] = *reinterpret_cast<const v4f*>(xb + 4 * j);
       st[j][1] = *reinterpret_cast<const v4f*>(xb + a.ldx2 + 4 * j);
     }
@@ -381,31 +402,32 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   lds_barrier();   // tap table complete
 
   const int kh = p >> 2;
-  // address of this lane's 4 bytes in the B image, for frame j of its segment: column n = 16 s + j
-  const int wbase = (kh * FBN) * 16 + 4 * (p & 3);
-  const int nsw = (16 * s) | 0;   // aligned group of the lane's columns; low4 = j ^ (s | 8 kh)
-  const int sx = (s | (kh << 3)) << 4;
-  // converts the 16 (pair, frame) results of this lane and writes them into B image `buf`, k-step pw
-  auto emit = [&](int buf, const v2f (&d)[16], int nvalid) {
+  // address of this lane's 4 bytes in the B image, for frame j of its segment: column n = FPS s + j (bimg_slot: the bits
+  // of j sit below FPS, so low4 = j ^ const and the aligned group is the segment's)
+  const int wbase = (kh * BN) * 16 + 4 * (p & 3);
+  const int nsw = (FPS * s) & ~15;
+  const int sx = (((FPS * s) & 15) ^ (((FPS * s) >> 4) | (kh << TL::KHS))) << 4;
+  // converts the FPS (pair, frame) results of this lane and writes them into B image `buf`, k-step pw
+  auto emit = [&](int buf, const v2f (&d)[FPS], int nvalid) {
     if (VASR_FUSED_ABLATE & 32) {
       if (d[0].x == 12345.678f) *reinterpret_cast<unsigned*>(bimg + wbase) = 1u;
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < FPS; ++j) {
       const float sj = j < nvalid ? xs : 0.f;              // MaskedConv1d: the pointwise conv sees zeros past lens_out
       const v2f v = {d[j].x * sj, d[j].y * sj};
       const f16x2 hv = __builtin_convertvector(v, f16x2);
       const v2f r = v - __builtin_convertvector(hv, v2f);   // exact: the residual of a round-to-nearest conversion
       const f16x2 lv = __builtin_convertvector(r, f16x2);
       const int off = wbase + ((nsw << 4) | ((j << 4) ^ sx));
-      *reinterpret_cast<unsigned*>(bimg + bimg_off(buf, 0, 0) + pw * (2 * FBN * 16) + off) = __builtin_bit_cast(unsigned, hv);
-      *reinterpret_cast<unsigned*>(bimg + bimg_off(buf, 1, 0) + pw * (2 * FBN * 16) + off) = __builtin_bit_cast(unsigned, lv);
+      *reinterpret_cast<unsigned*>(bimg + bimg_off<BN>(buf, 0, 0) + pw * (2 * BN * 16) + off) = __builtin_bit_cast(unsigned, hv);
+      *reinterpret_cast<unsigned*>(bimg + bimg_off<BN>(buf, 1, 0) + pw * (2 * BN * 16) + off) = __builtin_bit_cast(unsigned, lv);
     }
   };
 
-  const unsigned char* rd = win + p * kWPitch + 144 * s;            // this lane's window region
-  const int nvalid = len_out - (t0 + 16 * s);
+  const unsigned char* rd = win + p * kWPitch + TL::kSegBytes * s;   // this lane's window region
+  const int nvalid = len_out - (t0 + FPS * s);
 #pragma unroll 1
   for (int c = 0; c < FC / FCH; c += 2) {
 #pragma unroll
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
         }
         if ((VASR_FUSED_ABLATE & 128) && u.x + w.y == 12345.678f) *reinterpret_cast<v4f*>(win) = u;
         if (sp < 8 && !(VASR_FUSED_ABLATE & 128)) {
-          unsigned char* dst = win + sp * kWPitch + (4 * q) * 8 + (q >> 2) * 16;
+          unsigned char* dst = win + sp * kWPitch + (4 * q) * 8 + ((4 * q) / FPS) * 16;   // 16 bytes of pad per FPS frames
           *reinterpret_cast<v4f*>(dst) = v4f{u.x, w.x, u.y, w.y};
           *reinterpret_cast<v4f*>(dst + 16) = v4f{u.z, w.z, u.w, w.w};
         }
@@ -442,14 +464,14 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
 #pragma unroll
         for (int qq = qa; qq < qb; ++qq) {
           const v4f v = (VASR_FUSED_ABLATE & 128) ? v4f{st[0][0].x, st[0][1].y, (float)qq, 1.f}
-                                                   : *reinterpret_cast<const v4f*>(rd + qq * 16 + (qq >> 3) * 16);   // frames 2 qq, 2 qq + 1
+                                                   : *reinterpret_cast<const v4f*>(rd + qq * 16 + (qq / (FPS / 2)) * 16);   // frames 2 qq, 2 qq + 1
           xw[2 * qq] = v.xy;
           xw[2 * qq + 1] = v.zw;
         }
       };
-      v2f acc[16];
+      v2f acc[FPS];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = v2f{0.f, 0.f};
+      for (int j = 0; j < FPS; ++j) acc[j] = v2f{0.f, 0.f};
       load_units(0, G::qend(0));
       v2f wn[G::TB];   // taps of the NEXT block: their LDS round trip runs under this block's FMAs
       auto load_taps = [&](int blk) {
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
 #pragma unroll
           for (int k = G::TB * blk; k < G::TB * (blk + 1) && k < K; ++k) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < FPS; ++j) {
 #if VASR_FUSED_PLAINFMA
               acc[j].x = __builtin_fmaf(wt[k - G::TB * blk].x, xw[G::OFF + j + k].x, acc[j].x);
               acc[j].y = __builtin_fmaf(wt[k - G::TB * blk].y, xw[G::OFF + j + k].y, acc[j].y);
@@ -484,10 +506,10 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
               acc[j] = __builtin_elementwise_fma(wt[k - G::TB * blk], xw[G::OFF + j + k], acc[j]);
 #endif
             }
-            // one tap at a time over all 16 accumulators: left alone, the scheduler turns the loops inside out (one output
+            // one tap at a time over all FPS accumulators: left alone, the scheduler turns the loops inside out (one output
             // at a time, its taps as a dependent chain with a wait state between links) to save registers
 #pragma unroll
-            for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(acc[j]));
+            for (int j = 0; j < FPS; ++j) asm volatile("" : "+v"(acc[j]));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -497,15 +519,15 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
     }
   }
   if constexpr (DUAL) {
-    const int nv2 = len2 - (t0 + 16 * s);
+    const int nv2 = len2 - (t0 + FPS * s);
 #pragma unroll 1
     for (int c = FC / FCH; c < NCH; c += 2) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         const int ch = c + cc;
-        v2f d[16];
+        v2f d[FPS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FPS / 4; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) d[4 * j + e] = v2f{st[j][0][e], st[j][1][e]};
         if (ch + 1 < NCH) gload_x2(ch + 1);
@@ -516,16 +538,16 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   }
 }
 
-template <int K, bool DUAL>
+template <int K, bool DUAL, int BN>
 int launch_fused_t(const FusedArgs& a, hipStream_t st, int* amax_n) {
-  using G = FGeom<K>;
-  const int tiles_t = (int)(a.ldy / FBN);
+  using G = FGeom<K, BN>;
+  const int tiles_t = (int)(a.ldy / BN);
   const int n_blocks = tiles_t * a.batch;
   if (a.amax_y.p) {
     if (tiles_t * 4 > a.amax_y.stride) return (int)hipErrorInvalidValue;
     if (amax_n) *amax_n = tiles_t * 4;
   }
-  auto kern = dwpw_fused_kernel<K, DUAL>;
+  auto kern = dwpw_fused_kernel<K, DUAL, BN>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   if (attr != hipSuccess) return (int)attr;
@@ -565,8 +587,13 @@ int launch_fused_dwpw(const FusedLaunch& f, hipStream_t st, int* amax_n) {
   a.lens_y = f.lens_y; a.x2 = f.x2; a.ldx2 = f.ldx2; a.lens2 = f.lens2; a.amax_x2 = f.amax_x2; a.batch = f.batch;
   a.nt_store = f.nt_store;
   const bool dual = f.x2 != nullptr;
-  if (f.kernel == 33) return dual ? launch_fused_t<33, true>(a, st, amax_n) : launch_fused_t<33, false>(a, st, amax_n);
-  if (f.kernel == 39) return dual ? launch_fused_t<39, true>(a, st, amax_n) : launch_fused_t<39, false>(a, st, amax_n);
+  if (f.tile_cols == 64) {
+    if (f.kernel == 33) return dual ? launch_fused_t<33, true, 64>(a, st, amax_n) : launch_fused_t<33, false, 64>(a, st, amax_n);
+    if (f.kernel == 39) return dual ? launch_fused_t<39, true, 64>(a, st, amax_n) : launch_fused_t<39, false, 64>(a, st, amax_n);
+    return -1;
+  }
+  if (f.kernel == 33) return dual ? launch_fused_t<33, true, 128>(a, st, amax_n) : launch_fused_t<33, false, 128>(a, st, amax_n);
+  if (f.kernel == 39) return dual ? launch_fused_t<39, true, 128>(a, st, amax_n) : launch_fused_t<39, false, 128>(a, st, amax_n);
   return -1;
 }
 

@@ -612,16 +612,23 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       static const bool fused_on = !(dev_env("VASR_FUSED") && atoi(dev_env("VASR_FUSED")) == 0);
       // One workgroup per CU (159 KB of LDS), one 128-frame tile each: it pays when the tiles fill whole rounds of the chip
       // (measured, fused vs two kernels: 64 x 10 s = 256 tiles -3.4 % per step, 512 x 30 s = 6144 tiles -4 %; but 32 x 10 s = 128
-      // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  VASR_FUSED_MIN_TILES=n forces
-      // the fused form from n tiles on, whatever the fill (tests).
+      // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  Smaller batches take the kernel's
+      // 64-frame form (round 4) while THOSE tiles fit one round and occupy at least 3/8 of the chip -- 12 to 32 utterances of
+      // 10 s; measured against two kernels, ms per step: 15x5 B = 12 / 16 / 20 / 24 / 32: -3.8 / -4.8 / -8.3 / -7.7 / -6.7 %, 12x1
+      // (BASELINE configs[1]) B = 16 / 20 / 24 / 32: -3.1 / -5.1 / -5.0 / -4.3 %; B = 8: +-0; B = 1-4: +5 ... +9 % (one tile is 14 us
+      // of latency against 4 + 7 us for the two kernels spread over the chip); 36-44 utterances (1.1-1.4 rounds): +0.8 ... +1.6 %.
       static const int fused_min_tiles = dev_env("VASR_FUSED_MIN_TILES") ? atoi(dev_env("VASR_FUSED_MIN_TILES")) : 0;
+      static const int fused_tile = dev_env("VASR_FUSED_TILE") ? atoi(dev_env("VASR_FUSED_TILE")) : 0;
       const int n_cu = h->n_cu;
       // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- take no workgroups: 256 tiles on the
       // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
       const int f_cus = h->busy_cus > 0 && h->busy_cus < n_cu - 32 ? n_cu - h->busy_cus : n_cu;
       const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile), f_rounds = (f_tiles + f_cus - 1) / f_cus;
+      const bool f_fill128 = f_tiles >= 3 * f_cus / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * f_cus);
+      const bool f_fill64 = !f_fill128 && 2 * f_tiles >= 3 * f_cus / 8 && 2 * f_tiles <= f_cus;
+      const int f_cols = fused_tile == 64 || fused_tile == 128 ? fused_tile : (f_fill64 ? 64 : 128);
       const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles
-                                              : (f_tiles >= 3 * f_cus / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * f_cus));
+                                              : (fused_tile == 64 ? f_fill64 : fused_tile == 128 ? f_fill128 : (f_fill128 || f_fill64));
       const bool fuse_res = last_sub && B.fused_res;
       const ConvLayer& WF = fuse_res ? B.fused : S.pw;
       // (not in row-independent mode: whether a sub-block is fused depends on the batch's tile count, and the two forms
@@ -643,6 +650,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         if (fuse_res) { f.x2 = blk_in; f.ldx2 = blk_ld; f.lens2 = lens(B.first_step); f.amax_x2 = blk_amax; }
         f.batch = batch; f.kernel = S.dw.kernel;
         f.nt_store = stream_stores((size_t)batch * WF.cout * cur_ld * 4);
+        f.tile_cols = f_cols;
         int e;
         {
           ProfScope ps(h, kProfFused, st, 2.0 * WF.cin * WF.cout * (double)cur_T * batch,

@@ -210,6 +210,7 @@ struct FusedLaunch {
   const float* x2; int64_t ldx2; const int32_t* lens2; AmaxTab amax_x2;   // residual source (nullptr = none)
   int32_t batch, kernel;
   int32_t nt_store;                            // output stored with non-temporal hints (stream_stores)
+  int32_t tile_cols;                           // frames per workgroup: 128 (0 = default) or 64
 };
 bool fused_dwpw_supported(int channels, int cout, int kernel, int stride, int dilation);
 int fused_dwpw_taps_per_pair(int kernel);
