@@ -172,10 +172,13 @@ def test_full_size_properties(gpu):
     assert (torch.logsumexp(r1["logp"], -1).abs().max() < 1e-4)                            # rows are log-distributions
     assert torch.equal(r1["logp"].argmax(-1), r1["pred"])
     assert r1["enc_len"].tolist() == [float((int(np.ceil(l / 160)) - 1) // 2 + 1) for l in lens]
-    # batch independence up to the padded-row reflect quirk (Q5): full-length rows do not depend on the others
+    # batch independence up to the padded-row reflect quirk (Q5): full-length rows do not depend on the others.  (Within the
+    # parity tolerance, not to the bit: since round 4 a batch of this size runs its 256-channel sub-blocks through the fused
+    # kernel's 64-frame form and a lone utterance does not -- the two round differently, measured 2e-5 at |log-prob| 40;
+    # bit-identical rows whatever the batch is what vasr_set_row_independent promises, test_row_independent_*.)
     full = [b for b in range(32) if lens[b] == 160000][:1]
     solo = eng.forward(wav[full], ln[full], want_logp=True)
-    assert (solo["logp"][0] - r1["logp"][full[0]]).abs().max() <= 1e-5
+    assert (solo["logp"][0] - r1["logp"][full[0]]).abs().max() <= logp_tol(solo["logp"][0].cpu()) / 4
     # collapse is idempotent on its own output re-expanded with blanks
     ids, n = r1["ids"], r1["id_len"]
     row = ids[0, : n[0]].long()
@@ -344,13 +347,17 @@ def test_alternate_kernel_paths_match_goldens(gpu, env):
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3"])
 def test_results_do_not_depend_on_batch_size_or_tile_shape(gpu, gemm):
     """An utterance gives bit-identical log-probs alone (64x32 GEMM tiles, self-paired depthwise) and inside an odd
-    batch of 67 equal-length clips (256x128 / 512x128 tiles, utterance pairs): every reduction runs in the same order
-    whatever the launch shape.  This is what lets the serving queue merge requests without changing answers."""
+    batch of 67 equal-length clips (256x128 / 512x128 tiles, utterance pairs): every reduction of the two-kernel
+    sub-blocks runs in the same order whatever the launch shape.  (The batch is sized so that neither call takes the fused
+    depthwise + pointwise kernel -- 67 x 3 s = 134 tiles of 128 frames, 268 of 64: between its two fill rules; that kernel
+    derives the split scale from a bound and rounds differently, within the parity tolerance.  Bit-identical rows for
+    EVERY batch is what row-independent mode promises -- it never fuses -- and what the serving queue runs on:
+    test_row_independent_batches_equal_unbatched_calls_bit_for_bit.)"""
     from viet_asr_amd import configs, synth
     cfg = configs.builtin("quartznet15x5")
     jas = cfg["JasperEncoder"]["jasper"]
     eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 9), synth.decoder_state_dict(1024, 29, 9), gemm)
-    sig, lens = synth.audio_batch(67, 24000, 9)
+    sig, lens = synth.audio_batch(67, 48000, 9)
     sig[5] *= 1e-3                                     # rows at very different levels: the fp16 split scales per utterance
     sig[66] *= 40.0
     r = eng.forward(torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), want_logp=True)
