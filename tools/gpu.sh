@@ -437,6 +437,29 @@ for cfg in ${FUSED64_CASES:-2:24 2:32 2:48 3:24 3:32 3:40}; do
 done | tee $O/matrix.txt
 }
 
+# ---- final_r04b: after the 64-frame fused kernel: the two re-sized tests, default bench line, configs[1] on its own + its kernel stats
+task_final_r04b() {
+set -u
+O=$R/gpurun_out/r04b; mkdir -p $O; cd $R
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "full_size_properties or results_do_not_depend" 2>&1 | tail -3
+timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 300 python bench.py --config 2 --steps 20 --warmup 3 --no-other-gemm --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 300 python bench.py --config 3 --batch 24 --steps 20 --warmup 3 --no-other-gemm --no-cpu-baseline --no-side-configs > $O/bench_15x5_b24.json 2> /dev/null
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --no-other-gemm --no-side-configs > /dev/null 2> $O/stats.err
+f=$(find $O/stats -name '*kernel_stats.csv' | head -1); cp "$f" $O/c2_kernel_stats.csv
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete; rm -rf $O/stats
+python - <<PY
+import json,csv
+for n in ("bench_n1","bench_c2","bench_15x5_b24"):
+    j=json.loads([l for l in open("$O/%s.json"%n).read().splitlines() if l.startswith("{")][-1])
+    print(n, j["ms_per_step"], j["value"], "fused", j["fused"]["ms_per_step"], "roofline", j["roofline"]["frac"], "dw", j["depthwise"]["frac"])
+    if "configs" in j: print({k:(v["ms_per_step"], v.get("fused_ms_per_step")) for k,v in j["configs"].items()})
+for r in list(csv.DictReader(open("$O/c2_kernel_stats.csv")))[:12]:
+    print("%-100s calls %5s avg %8.1f ns" % (r["Name"][:100], r["Calls"], float(r["AverageNs"])))
+PY
+}
+
 # ---- final_r04: round-4 record: full GPU suite, kernel stats + PMC traffic of the bench, bench lines (default with every config,
 #      10.3 s, configs 2 / 4 / 5 on their own), kernel stats of the reference's serving shape (batch 1, 12x1_vi, greedy + beam)
 task_final_r04() {
