@@ -17,6 +17,9 @@ extern "C" {
  * done -> this kernel done", i.e. the kernel plus its dispatch gap; bench.py reports class times both raw and with
  * launches x this value removed (the latter is what rocprofv3 --kernel-trace reports as kernel duration). */
 VASR_API int vasr_profile_bracket_overhead(vasr_stream stream, int n, double* out_us);
+/* The form a 256-channel separable sub-block takes (csrc/vasr_internal.h fused_tile_choice; pure host arithmetic): 128 / 64 =
+ * the fused depthwise + pointwise kernel on tiles of that many frames, 0 = two kernels.  tiles128 = batch x padded frames / 128. */
+VASR_API int vasr_fused_tile_choice(int64_t tiles128, int compute_units);
 /* Run ONE encoder layer kind in isolation for benchmarking/roofline measurement:
  * kind 0 = depthwise (K, stride 1, dilation 1), 1 = pointwise GEMM (+BN+ReLU epilogue).
  * Buffers are caller provided [B][C][Tp] with Tp = vasr_padded_frames(T). */

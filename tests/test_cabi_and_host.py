@@ -101,6 +101,25 @@ def test_pointwise_weight_packing_layout():
         _lib.check(L.vasr_pack_pointwise(w.ctypes.data, cout, 63, m_pad, out.ctypes.data), L)
 
 
+def test_fused_sub_block_form_by_batch_size():
+    """Which form a 256-channel sub-block takes (csrc/vasr_internal.h fused_tile_choice, host arithmetic only): the fused
+    kernel on 128-frame tiles when those fill the 256 CUs in whole rounds, on 64-frame tiles for the batches in between,
+    two kernels where a lone tile's latency would lose -- the sizes DESIGN section 4 measured."""
+    L = _lib.dev_lib()
+    pick = lambda batch, frames: L.vasr_fused_tile_choice(batch * (int(L.vasr_padded_frames(frames)) // 128), 256)
+    assert pick(64, 501) == 128                     # the headline batch: 256 tiles, one round
+    assert pick(512, 1501) == 128                   # configs[4]: 6144 tiles, 24 rounds
+    assert pick(52, 501) == 128 and pick(48, 501) == 0     # 208 tiles: 81 % of a round; 192 tiles: 75 %, under the 80 % line
+    assert pick(32, 501) == 64                      # configs[1]: 128 tiles of 128 frames would fill half the chip
+    assert [pick(b, 501) for b in (12, 16, 24)] == [64, 64, 64]
+    assert [pick(b, 501) for b in (1, 4, 8, 11)] == [0, 0, 0, 0]          # latency of a lone tile loses to two kernels
+    assert [pick(b, 501) for b in (36, 40, 44)] == [0, 0, 0]              # 1.1-1.4 rounds of 64-frame tiles lose as well
+    assert pick(64, 516) == 0                       # 64 x 10.3 s = 320 tiles = 1.25 rounds
+    assert pick(103, 501) == 128 and pick(80, 501) == 0                   # last round >= 80 % full or not at all
+    assert L.vasr_fused_tile_choice(256, 192) == 0 and L.vasr_fused_tile_choice(96, 192) == 64   # CUs held by a running search
+    assert L.vasr_fused_tile_choice(0, 256) == 0
+
+
 def test_presplit_tensor_layout_and_its_lds_image():
     """The "P4" layout of the pre-split-input GEMM prototype (csrc/encoder_pw_p4.hip, devtools build) and the index algebra of
     its LDS image, replayed in numpy: vasr_pack_p4 writes [4 x hi | 4 x lo] groups (halves swapped on channels with

@@ -95,6 +95,7 @@ DEV_SIGNATURES = {
     "vasr_pack_depthwise_taps": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "vasr_bench_depthwise_mfma": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vasr_profile_bracket_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    "vasr_fused_tile_choice": (C.c_int, [C.c_int64, C.c_int]),
     "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_pack_pointwise_bf16x3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_bench_pointwise_bf16x3": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),

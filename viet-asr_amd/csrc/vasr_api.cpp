@@ -623,12 +623,10 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- take no workgroups: 256 tiles on the
       // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
       const int f_cus = h->busy_cus > 0 && h->busy_cus < n_cu - 32 ? n_cu - h->busy_cus : n_cu;
-      const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile), f_rounds = (f_tiles + f_cus - 1) / f_cus;
-      const bool f_fill128 = f_tiles >= 3 * f_cus / 4 && (double)f_tiles >= 0.8 * (double)(f_rounds * f_cus);
-      const bool f_fill64 = !f_fill128 && 2 * f_tiles >= 3 * f_cus / 8 && 2 * f_tiles <= f_cus;
-      const int f_cols = fused_tile == 64 || fused_tile == 128 ? fused_tile : (f_fill64 ? 64 : 128);
-      const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles
-                                              : (fused_tile == 64 ? f_fill64 : fused_tile == 128 ? f_fill128 : (f_fill128 || f_fill64));
+      const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile);
+      const int f_rule = fused_tile_choice(f_tiles, f_cus);
+      const int f_cols = fused_tile == 64 || fused_tile == 128 ? fused_tile : (f_rule ? f_rule : 128);
+      const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles : (fused_tile ? f_rule == fused_tile : f_rule != 0);
       const bool fuse_res = last_sub && B.fused_res;
       const ConvLayer& WF = fuse_res ? B.fused : S.pw;
       // (not in row-independent mode: whether a sub-block is fused depends on the batch's tile count, and the two forms
@@ -755,6 +753,9 @@ const char* vasr_last_error(void) { return g_err.c_str(); }
 const char* vasr_version(void) { return "vasr-hip 0.4 (gfx950)"; }
 int vasr_abi_version(void) { return VASR_ABI_VERSION; }
 int64_t vasr_padded_frames(int64_t frames) { return pad_frames(frames); }
+#ifdef VASR_DEVTOOLS
+int vasr_fused_tile_choice(int64_t tiles128, int compute_units) { return vasr::fused_tile_choice(tiles128, compute_units); }
+#endif
 
 int vasr_create(const vasr_model_desc* d, vasr_handle** out) {
   if (!d || !out) return fail(VASR_ERR_INVALID, "null argument");

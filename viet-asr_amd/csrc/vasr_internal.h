@@ -213,6 +213,18 @@ struct FusedLaunch {
   int32_t tile_cols;                           // frames per workgroup: 128 (0 = default) or 64
 };
 bool fused_dwpw_supported(int channels, int cout, int kernel, int stride, int dilation);
+// Which form a 256-channel sub-block takes for `tiles128` tiles of 128 frames (batch x padded frames / 128) on `cus` free
+// compute units: 128 or 64 = the fused kernel on tiles of that many frames, 0 = depthwise and GEMM as two kernels.
+// One workgroup per CU and tile, so a launch is whole rounds of lock-stepped workgroups (measurements: vasr_api.cpp
+// run_encoder): 128-frame tiles from 3/4 of a round up when the last round is >= 80 % full; otherwise
+// 64-frame tiles while THOSE fit one round and occupy >= 3/8 of the chip; otherwise two kernels.
+static inline int fused_tile_choice(int64_t tiles128, int cus) {
+  if (tiles128 <= 0 || cus <= 0) return 0;
+  const int64_t rounds = (tiles128 + cus - 1) / cus;
+  if (tiles128 >= 3 * (int64_t)cus / 4 && (double)tiles128 >= 0.8 * (double)(rounds * cus)) return 128;
+  if (2 * tiles128 >= 3 * (int64_t)cus / 8 && 2 * tiles128 <= cus) return 64;
+  return 0;
+}
 int fused_dwpw_taps_per_pair(int kernel);
 // host: [C][K] -> [C / 2][taps_per_pair][2]; returns the bound max_c sum_k |w[c][k]| (rounded up)
 float pack_fused_taps(const float* w, int channels, int kernel, float* out);
