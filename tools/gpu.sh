@@ -437,6 +437,28 @@ for cfg in ${FUSED64_CASES:-2:24 2:32 2:48 3:24 3:32 3:40}; do
 done | tee $O/matrix.txt
 }
 
+# ---- pwlat: the small-batch latency GEMM (encoder_pw_lat.hip): bit-identity and golden tests, then batch-1 / batch-4 / batch-8
+#      call latencies with the kernel off (VASR_PW_LAT=0), on (default) and extended to the 128 x 64 tile's batches (=2)
+task_pwlat() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/pwlat; mkdir -p $O
+if [ "${1:-all}" != time ]; then
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round3.py -m gpu -q -p no:cacheprovider -x \
+  -k "results_do_not_depend or fused_path_matches_reference_goldens or row_independent or neural_module_dag or edge_cases or random_architectures or split_gemms" 2>&1 | tail -6
+fi
+[ "${1:-all}" = test ] && return
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+for v in 0 1 2; do
+  echo "== VASR_PW_LAT=$v"
+  VASR_PW_LAT=$v python tools/b1_serving.py --no-beam 2>/dev/null | tail -1
+  VASR_PW_LAT=$v python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam 2>/dev/null | tail -1
+  for b in 1 2 4 8; do
+    echo -n "15x5 batch $b: "; VASR_PW_LAT=$v python bench.py --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-other-gemm --no-side-configs 2>/dev/null | python -c "
+import sys,json
+j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('%.4f ms  gemm %.4f (%s)  dw %.4f' % (j['ms_per_step'], j['roofline']['ms_per_step'], j['roofline'].get('launches_per_step'), j['depthwise']['ms_per_step']))"
+  done
+done 2>&1 | tee $O/lat.txt
+}
+
 # ---- final_r04b: after the 64-frame fused kernel: the two re-sized tests, default bench line, configs[1] on its own + its kernel stats
 task_final_r04b() {
 set -u

@@ -706,6 +706,15 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
   if (force >= 1 && force <= 8 && a.M % rows[force] == 0) tile = force;
+  // Small batches (the 64 x 32 tile's territory: <= 5 utterances of 10 s at 512 channels): the whole K range in ONE trip to
+  // memory instead of K / 64 dependent chunk steps -- encoder_pw_lat.hip, same bits.  VASR_PW_LAT=0 keeps the chunked kernel,
+  // =2 extends the latency kernel to the 128 x 64 tile's batches (dev: A/B runs).
+  static const int lat = dev_env("VASR_PW_LAT") ? atoi(dev_env("VASR_PW_LAT")) : 1;
+  if (arith == kF16x2 && !force && lat > 0 && (tile == 4 || (lat >= 2 && tile == 3)) &&
+      pointwise_latency_supported(a.M, a.K, a.x2 ? a.K1 : 0)) {
+    const int e = launch_pointwise_latency(a, st, amax_n);
+    if (e >= 0) return e;
+  }
   static const int phase_delay = dev_env("VASR_PW_PHASE") ? atoi(dev_env("VASR_PW_PHASE")) : 0;   // 10 ns ticks (dev)
   a.phase_delay = phase_delay;
   switch (tile) {

@@ -170,6 +170,9 @@ void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float*
 bool pointwise_split_supported(int M, int K, int K1);
 double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st);
 int launch_pointwise_split(const PwArgs& a, int arith, hipStream_t st, int* amax_n = nullptr);
+// the 2 x fp16 arithmetic on the small-batch latency kernel (encoder_pw_lat.hip), bit-identical results; -1: shape not covered
+bool pointwise_latency_supported(int M, int K, int K1);
+int launch_pointwise_latency(const PwArgs& a, hipStream_t st, int* amax_n);
 int pointwise_amax_slots(int M, int64_t ld);   // slots per utterance the split kernel may use for that shape
 void pack_pointwise_weights_bf16x3(const float* w, int cout, int cin, int m_pad, unsigned short* out);
 float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad, unsigned short* out);   // returns 1 / scale
