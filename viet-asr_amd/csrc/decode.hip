@@ -5,9 +5,9 @@
 //   ctc_collapse      : inner loop of __ctc_decoder_predictions_tensor     (helpers.py:20-31)
 //
 // The GEMM leaves logits class-major [B][V+1][ld] (time contiguous).  One workgroup takes 64
-// consecutive frames: each lane walks the classes of its own frame (coalesced across lanes),
-// builds max / sum-exp / arg-max in registers, then the [64][V+1] tile is transposed through
-// LDS so that the frame-major log-prob tensor is written as one contiguous block.
+// consecutive frames, four threads per frame (a quarter of the classes each, coalesced across the
+// frames), builds max / sum-exp / arg-max, then the [64][V+1] tile is transposed through
+// LDS so that the frame-major log-prob tensor is written as contiguous rows.
 #include "vasr_internal.h"
 
 namespace vasr {
@@ -15,47 +15,73 @@ namespace vasr {
 namespace {
 
 
-// grid (ceil(T/64), B), block 64.  VMAX = classes rounded up to 32: every logit of the lane's frame is requested ONCE, all
-// requests in flight together, and max / sum-exp / log-probs / arg-max run out of registers.  (Rounds 1-3 walked the classes
-// three times with dependent loads: 14 us per batch-1 call at 29 classes, 41 us at the Vietnamese head's 91 -- a tenth of the
-// whole batch-1 pass of QuartzNet12x1.)
+// grid (ceil(T/64), B), block 256 = 64 frames x 4 class quarters (a wavefront per quarter).  VMAX = classes rounded up to 32,
+// VQ = VMAX / 4 per thread: every logit is requested ONCE, all requests in flight together, and max / exp / log-probs /
+// arg-max run out of registers.  (Rounds 1-3 walked the classes three times with dependent loads: 14 us per batch-1 call
+// at 29 classes, 41 us at the Vietnamese head's 91; round 4's first form -- one lane per frame, all classes in its
+// registers -- took 16 us there: 91 exponentials and a 91-iteration transposing store loop with an integer division per
+// element, executed by ONE wavefront per 64 frames.)  The arithmetic and its ORDER are those of the one-lane form, so the
+// bits are too: the maximum is order-free, the exponentials go through LDS and are summed by one lane per frame in
+// ascending class order, the arg-max keeps the first maximum (strict > within a quarter, quarters combined in order).
 template <int VMAX>
-__global__ __launch_bounds__(64) void logsoftmax_argmax_kernel(const float* __restrict__ logits, int64_t row_ld,
-                                                               int64_t batch_stride, int frames, int V,
-                                                               float* __restrict__ logp,
-                                                               int64_t* __restrict__ pred) {
-  extern __shared__ float tile[];  // [64][V + 1]
-  const int lane = threadIdx.x, b = blockIdx.y;
-  const int t0 = blockIdx.x * 64, t = t0 + lane;
+__global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float* __restrict__ logits, int64_t row_ld,
+                                                                int64_t batch_stride, int frames, int V,
+                                                                float* __restrict__ logp,
+                                                                int64_t* __restrict__ pred) {
+  constexpr int VQ = VMAX / 4;
+  extern __shared__ float tile[];  // [64][VP] | red[4][64] | bestq[4][64] | argq[4][64]
+  const int VP = (V + 1) | 1;      // odd pitch: a lane walking its frame's classes meets every bank
+  float* red = tile + 64 * VP;
+  float* bestq = red + 256;
+  int* argq = reinterpret_cast<int*>(bestq + 256);
+  const int tid = threadIdx.x, f = tid & 63, b = blockIdx.y;
+  const int cq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t0 = blockIdx.x * 64, t = t0 + f;
   const float* x = logits + (int64_t)b * batch_stride + min(t, frames - 1);
   const int n_t = min(64, frames - t0);
-  float xv[VMAX];
+  const int v0 = cq * VQ;
+  float xv[VQ];
 #pragma unroll
-  for (int v = 0; v < VMAX; ++v) xv[v] = x[(int64_t)min(v, V - 1) * row_ld];
-  if (t < frames) {
-    float mx = -INFINITY;
+  for (int j = 0; j < VQ; ++j) xv[j] = x[(int64_t)min(v0 + j, V - 1) * row_ld];
+  float mx = -INFINITY;
 #pragma unroll
-    for (int v = 0; v < VMAX; ++v) if (v < V) mx = fmaxf(mx, xv[v]);
+  for (int j = 0; j < VQ; ++j) if (v0 + j < V) mx = fmaxf(mx, xv[j]);
+  red[cq * 64 + f] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[f], red[64 + f]), fmaxf(red[128 + f], red[192 + f]));
+#pragma unroll
+  for (int j = 0; j < VQ; ++j) if (v0 + j < V) tile[f * VP + v0 + j] = expf(xv[j] - mx);
+  __syncthreads();
+  if (cq == 0) {
     float s = 0.f;
+    for (int v = 0; v < V; ++v) s += tile[f * VP + v];   // ascending, one accumulator: the order of the sum is the result's bits
+    red[f] = logf(s);
+  }
+  __syncthreads();
+  const float ls = red[f];
+  float best = -INFINITY;
+  int arg = 0;
 #pragma unroll
-    for (int v = 0; v < VMAX; ++v) if (v < V) s += expf(xv[v] - mx);
-    const float ls = logf(s);
-    float best = -INFINITY;
-    int arg = 0;
-#pragma unroll
-    for (int v = 0; v < VMAX; ++v) {
-      if (v < V) {
-        const float lp = (xv[v] - mx) - ls;
-        if (lp > best) { best = lp; arg = v; }  // strict >: first maximum wins (quirk Q6)
-        if (logp) tile[lane * (V + 1) + v] = lp;
-      }
+  for (int j = 0; j < VQ; ++j) {
+    if (v0 + j < V) {
+      const float lp = (xv[j] - mx) - ls;
+      if (lp > best) { best = lp; arg = v0 + j; }  // strict >: first maximum wins (quirk Q6)
+      if (logp) tile[f * VP + v0 + j] = lp;
     }
-    if (pred) pred[(int64_t)b * frames + t] = arg;
+  }
+  bestq[cq * 64 + f] = best;
+  argq[cq * 64 + f] = arg;
+  __syncthreads();
+  if (cq == 0 && pred && t < frames) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (bestq[q * 64 + f] > best) { best = bestq[q * 64 + f]; arg = argq[q * 64 + f]; }
+    pred[(int64_t)b * frames + t] = arg;
   }
   if (logp) {
-    __syncthreads();
     float* out = logp + ((int64_t)b * frames + t0) * V;
-    for (int i = lane; i < n_t * V; i += 64) out[i] = tile[(i / V) * (V + 1) + (i % V)];
+    for (int r = cq; r < n_t; r += 4)
+      for (int c = f; c < V; c += 64) out[(int64_t)r * V + c] = tile[r * VP + c];
   }
 }
 
@@ -117,9 +143,9 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int64_t* __restr
 void launch_logsoftmax_argmax(const float* logits, int64_t row_ld, int64_t batch_stride, int batch, int frames,
                               int num_classes, float* logp, int64_t* pred, hipStream_t st) {
   dim3 grid((frames + 63) / 64, batch);
-  const size_t lds = logp ? (size_t)64 * (num_classes + 1) * sizeof(float) : 0;
+  const size_t lds = ((size_t)64 * ((num_classes + 1) | 1) + 3 * 256) * sizeof(float);
   auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, logits, row_ld, batch_stride, frames, num_classes, logp, pred);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, logits, row_ld, batch_stride, frames, num_classes, logp, pred);
   };
   if (num_classes <= 32) go(logsoftmax_argmax_kernel<32>);
   else if (num_classes <= 64) go(logsoftmax_argmax_kernel<64>);

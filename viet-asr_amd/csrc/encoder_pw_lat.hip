@@ -4,11 +4,11 @@
 // A batch-1 call of QuartzNet is a chain of ~150 dependent kernels, and the throughput kernel spends a GEMM's 8-13 us on
 // it as K / 64 DEPENDENT chunk steps (rows requested two chunks ahead, converted, a workgroup barrier, four k-steps of
 // MFMAs, next chunk): with 4 of 256 CUs' worth of work per layer every step is a round trip to L2 / HBM, not work.
-// This kernel makes ONE trip: a workgroup (4 wavefronts, 128 rows x 32 columns) requests ALL K rows of its 32 columns
-// at once -- K x 128 bytes as 16-byte loads, K / 32 of them per thread in flight --, converts them to the fp16 hi / lo B image of the
-// WHOLE K range in LDS as they arrive (K = 1024: 128 KB), passes one barrier and then runs the K / 16 k-steps as one
-// uninterrupted MFMA chain per wavefront (one 32 x 32 tile each; weight fragments from L2 eight k-steps ahead, B
-// fragments from LDS two k-steps ahead).
+// This kernel makes ONE trip: a workgroup (128 rows x 32 columns) requests ALL K rows of its 32 columns at once -- K x 128
+// bytes as 16-byte loads, K / 32 of them per staging thread in flight --, converts them to the fp16 hi / lo B image of the
+// WHOLE K range in LDS as they arrive (K = 1024: 128 KB) and runs the K / 16 k-steps as one MFMA chain per multiplying
+// wavefront (one 32 x 32 tile each; weight fragments from L2 eight k-steps ahead, B fragments from LDS two k-steps
+// ahead), 256 rows of K behind the staging.
 //
 // Results are BIT-IDENTICAL to pw_gemm_split_kernel<..., kF16x2> on the same operands: same scale from the producers'
 // maxima, same conversion, same three products per k-step in the same order into the same single accumulator chain,
@@ -31,8 +31,8 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int LBN = 32;          // columns per workgroup
-constexpr int LNW = 4;           // wavefronts = 32-row m-tiles: 128 rows per workgroup
-constexpr int LNT = 64 * LNW;
+constexpr int LNW = 4;           // multiplying wavefronts = 32-row m-tiles: 128 rows per workgroup
+constexpr int LNT = 128 * LNW;   // + as many staging wavefronts
 constexpr int LAD = 8;           // weight fragments requested this many k-steps ahead
 constexpr int LBD = 2;           // B fragments read from LDS this many k-steps ahead
 
@@ -42,10 +42,16 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// KS = K / 16 k-steps (16, 32, 64); a thread owns PI = K / 256 items (8 consecutive k rows x four adjacent columns)
+// KS = K / 16 k-steps (16, 32, 64).  Wavefronts 0-3 MULTIPLY (one 32-row m-tile each), wavefronts 4-7 STAGE: a staging thread
+// owns PI = K / 256 items (8 consecutive k rows x four adjacent columns), requests them all at once and converts them in
+// request order, one item = 256 rows of K = one PHASE; a barrier hands each phase's quarter or half of the B image to the
+// multipliers, which run its 16 k-steps while the next items are still arriving.  The roles keep the two request streams
+// on different wavefronts: s_waitcnt counts in order, and a multiplier that waited for its next weight fragments would
+// otherwise wait for every row requested before them.
 template <int KS, bool DUAL, bool RES>
 __global__ __launch_bounds__(LNT, 1) void pw_gemm_latency_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
-  constexpr int PI = KS / 16;
+  constexpr int PI = KS / 16;          // items per staging thread = phases
+  constexpr int SPH = 16;              // k-steps per phase
   extern __shared__ __attribute__((aligned(16))) uint4 Bl[];   // [plane][KS][2][LBN]
   auto bs = [&](int plane, int s, int kb, int n) -> uint4& { return Bl[((plane * KS + s) * 2 + kb) * LBN + n]; };
 
@@ -61,46 +67,26 @@ __global__ __launch_bounds__(LNT, 1) void pw_gemm_latency_kernel(PwArgs a, int b
   const int m0 = mb * (32 * LNW);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave * 32;
+  const bool mul = wave < LNW;
+  const int wm = (wave & (LNW - 1)) * 32;
   const int kh = lane >> 5, l31 = lane & 31;
   const bool masked1 = !DUAL && a.lens != nullptr;   // (a dual launch masks its second source only, as the throughput kernel)
   const int len = masked1 ? a.lens[b] : 0;
   const int len2 = DUAL ? a.lens2[b] : 0;
   const int K1 = DUAL ? a.K1 : a.K;
 
-  const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * KS) * 2 * 64 + lane;
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // the epilogue's operands ride along with the first requests: BN scale / shift of this lane's rows (both epilogue forms
-  // read the same eight float4), the residual pieces of the float4 form
-  v4f scv[4], shv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    scv[q] = *reinterpret_cast<const v4f*>(a.scale + m0 + wm + 8 * q + 4 * kh);
-    shv[q] = *reinterpret_cast<const v4f*>(a.shift + m0 + wm + 8 * q + 4 * kh);
-  }
-  const bool full = (t0 + LBN <= a.store_cols) && (m0 + 32 * LNW <= a.m_store);
-  const bool vec = full && ((a.ldy | a.ldr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
-  const int erow = lane / (LBN / 4), ec4 = lane % (LBN / 4);
-  v4f rv[4];
-  if (RES && vec) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      rv[q] = *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m0 + wm + 8 * q + erow) * a.ldr + t0 + 4 * ec4);
-  }
-
   // a time tile on which every input is zero has nothing to reduce (as in the throughput kernel)
   const int zf = a.zero_from ? max(a.zero_from[b], DUAL ? len2 : 0) : 0x7fffffff;
-  float out_scale = 1.f;
-  if (t0 < zf) {
+  const bool live = t0 < zf;
+
+  if (!mul) {
+    // =========================================== staging wavefronts ==================================================
+    if (!live) return;
     unsigned amv[8], amv2[8];
     amax_request(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
     if (DUAL) amax_request(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2);
-    // ---- every row of the tile, requested at once.  Item i of this thread = k rows 8 g .. 8 g + 7 of the column quad c4
-    //      (four adjacent columns: one 16-byte load per row, 8 lanes = a row's 128 bytes); g = g0 + 32 i ----
-    const int c4 = tid & 7, g0 = tid >> 3;
+    // item i = k rows 8 g .. 8 g + 7 (g = g0 + 32 i) of the column quad c4: one 16-byte load per row, 8 lanes = a row's 128 bytes
+    const int st = tid - 64 * LNW, c4 = st & 7, g0 = st >> 3;
     v4f xr[PI][8];
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
@@ -112,22 +98,13 @@ __global__ __launch_bounds__(LNT, 1) void pw_gemm_latency_kernel(PwArgs a, int b
 #pragma unroll
       for (int e = 0; e < 8; ++e) xr[i][e] = *reinterpret_cast<const v4f*>(src + (int64_t)e * ld);
     }
-    // the first weight fragments (younger than the rows: waiting for the rows leaves them in flight)
-    uint4 aw[LAD][2];
-#pragma unroll
-    for (int s = 0; s < LAD; ++s)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) aw[s][p] = ap[((int64_t)s * 2 + p) * 64];
     __builtin_amdgcn_sched_barrier(0);   // every request above is issued before anything below waits for one
     float xs, inv;
     {
       unsigned mx = amax_collect(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
       if (DUAL) mx = max(mx, amax_collect(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2));
       f16_scale(mx, &xs, &inv);
-      out_scale = inv * a.w_inv_scale;
     }
-    // ---- conversion, item by item in request order (s_waitcnt counts down as the rows arrive): per column the 8 k values
-    //      become one 16-byte B-fragment slot per plane ----
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
       const int g = g0 + 32 * i;
@@ -149,30 +126,77 @@ __global__ __launch_bounds__(LNT, 1) void pw_gemm_latency_kernel(PwArgs a, int b
         bs(0, g >> 1, g & 1, n) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
         bs(1, g >> 1, g & 1, n) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
       }
+      __syncthreads();   // phase i of the B image is complete
     }
-    __syncthreads();
-    // ---- one MFMA chain over all k-steps ----
+    __syncthreads();     // (the multipliers' epilogue reuses the image)
+    return;
+  }
+
+  // ============================================= multiplying wavefronts ==============================================
+  const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(a.wt) + ((int64_t)((m0 + wm) / 32) * KS) * 2 * 64 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // the epilogue's operands ride along with the first requests: BN scale / shift of this lane's rows (both epilogue forms
+  // read the same eight float4), the residual pieces of the float4 form
+  v4f scv[4], shv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    scv[q] = *reinterpret_cast<const v4f*>(a.scale + m0 + wm + 8 * q + 4 * kh);
+    shv[q] = *reinterpret_cast<const v4f*>(a.shift + m0 + wm + 8 * q + 4 * kh);
+  }
+  const bool full = (t0 + LBN <= a.store_cols) && (m0 + 32 * LNW <= a.m_store);
+  const bool vec = full && ((a.ldy | a.ldr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
+  const int erow = lane / (LBN / 4), ec4 = lane % (LBN / 4);
+  v4f rv[4];
+  if (RES && vec) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rv[q] = *reinterpret_cast<const v4f*>(a.res + ((int64_t)b * a.M + m0 + wm + 8 * q + erow) * a.ldr + t0 + 4 * ec4);
+  }
+  float out_scale = 1.f;
+  if (live) {
+    unsigned amv[8], amv2[8];
+    amax_request(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
+    if (DUAL) amax_request(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2);
+    uint4 aw[LAD][2];
+#pragma unroll
+    for (int s = 0; s < LAD; ++s)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) aw[s][p] = ap[((int64_t)s * 2 + p) * 64];
+    {
+      unsigned mx = amax_collect(a.amax_x.p, a.amax_x.stride, a.amax_x.n, b, lane, amv);
+      if (DUAL) mx = max(mx, amax_collect(a.amax_x2.p, a.amax_x2.stride, a.amax_x2.n, b, lane, amv2));
+      float xs, inv;
+      f16_scale(mx, &xs, &inv);
+      out_scale = inv * a.w_inv_scale;
+    }
     uint4 bf[LBD + 1][2];
 #pragma unroll
-    for (int s = 0; s < LBD; ++s)
+    for (int ph = 0; ph < PI; ++ph) {
+      __syncthreads();   // phase ph of the B image is complete
+      const int s0 = ph * SPH;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) bf[s][p] = bs(p, s, kh, l31);
+      for (int s = 0; s < LBD; ++s)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + LBD < KS) {
+        for (int p = 0; p < 2; ++p) bf[(s0 + s) % (LBD + 1)][p] = bs(p, s0 + s, kh, l31);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bf[(s + LBD) % (LBD + 1)][p] = bs(p, s + LBD, kh, l31);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const uint4 w0 = aw[s % LAD][0], w1 = aw[s % LAD][1];
-      const uint4 b0 = bf[s % (LBD + 1)][0], b1 = bf[s % (LBD + 1)][1];
-      // cross terms, smallest first -- the order of pw_gemm_split_kernel
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, b0), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, b1), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, b0), acc, 0, 0, 0);
-      if (s + LAD < KS) {   // the set this step has just released
+      for (int s = s0; s < s0 + SPH; ++s) {
+        if (s + LBD < s0 + SPH) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) aw[s % LAD][p] = ap[((int64_t)(s + LAD) * 2 + p) * 64];
+          for (int p = 0; p < 2; ++p) bf[(s + LBD) % (LBD + 1)][p] = bs(p, s + LBD, kh, l31);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4 w0 = aw[s % LAD][0], w1 = aw[s % LAD][1];
+        const uint4 b0 = bf[s % (LBD + 1)][0], b1 = bf[s % (LBD + 1)][1];
+        // cross terms, smallest first -- the order of pw_gemm_split_kernel
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, b0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, b1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, b0), acc, 0, 0, 0);
+        if (s + LAD < KS) {   // the set this step has just released
+#pragma unroll
+          for (int p = 0; p < 2; ++p) aw[s % LAD][p] = ap[((int64_t)(s + LAD) * 2 + p) * 64];
+        }
       }
     }
     __syncthreads();   // the epilogue reuses the LDS image
