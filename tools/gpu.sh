@@ -459,6 +459,29 @@ j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]
 done 2>&1 | tee $O/lat.txt
 }
 
+# ---- final_r04c: HEAD after the latency GEMM and the four-thread log-softmax: full GPU suite, default bench line, the serving-shape
+#      latencies, configs[1]
+task_final_r04c() {
+set -u
+O=$R/gpurun_out/r04c; rm -rf $O; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl; cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+cp $R/gpurun_out/parity_errors.jsonl $O/parity_errors.jsonl 2>/dev/null
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python tools/b1_serving.py > $O/b1_vi.json 2> $O/b1_vi.err
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_15x5.json 2>> $O/b1_vi.err
+timeout 300 python bench.py --config 2 --steps 20 --warmup 3 --no-other-gemm --no-cpu-baseline > $O/bench_c2.json 2> /dev/null
+tail -4 $O/pytest.log; tail -2 $O/smoke.log; tail -1 $O/b1_vi.json; tail -1 $O/b1_15x5.json
+python - <<PY
+import json
+for n in ("bench_n1","bench_c2"):
+    j=json.loads([l for l in open("$O/%s.json"%n).read().splitlines() if l.startswith("{")][-1])
+    print(n, j["ms_per_step"], j["value"], "fused", j["fused"]["ms_per_step"], "roofline", j["roofline"]["frac"], "dw", j["depthwise"]["frac"])
+    if "latency" in j: print({k:v for k,v in j["latency"].items() if not isinstance(v,dict)}); print(j["latency"]["vi12x1_b1"]["vi12x1_b1_6.6s"])
+PY
+}
+
 # ---- final_r04b: after the 64-frame fused kernel: the two re-sized tests, default bench line, configs[1] on its own + its kernel stats
 task_final_r04b() {
 set -u
