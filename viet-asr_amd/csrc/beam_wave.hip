@@ -773,7 +773,11 @@ size_t beam_wave_lds_bytes() { return sizeof(WaveLds); }
 
 // utterances per workgroup (= per compute unit): a lone utterance gets a workgroup of its own; a batch is packed four to a
 // compute unit so that the search of batch k leaves the rest of the chip to the acoustic pass of batch k + 1
-int beam_wave_utts_per_workgroup(int batch) { return batch >= 4 ? 4 : (batch >= 2 ? 2 : 1); }
+int beam_wave_utts_per_workgroup(int batch) {
+  static const int force = dev_env("VASR_BEAM_UPW") ? atoi(dev_env("VASR_BEAM_UPW")) : 0;   // 1 | 2 | 4 (dev: A/B runs)
+  if (force == 1 || force == 2 || force == 4) return force;
+  return batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
+}
 
 int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
                             float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
