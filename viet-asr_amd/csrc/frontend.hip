@@ -3,9 +3,9 @@
 //
 // Replaces FilterbankFeatures.forward (reference nemo/collections/asr/parts/features.py:245-301).
 //
-// One workgroup = 32 consecutive frames of one utterance.  The 5472-sample window those
-// frames cover is staged ONCE into LDS with coalesced loads (62.5 % frame overlap is served
-// from LDS, not HBM); each of the 8 wavefronts then runs 4 real 512-point FFTs as a
+// One workgroup = 32 consecutive frames of one utterance (8 for small batches, see the kernel).  The 5472-sample
+// window those frames cover is staged ONCE into LDS with coalesced loads (62.5 % frame overlap is served
+// from LDS, not HBM); each of the 8 wavefronts then runs 4 (1) real 512-point FFTs as a
 // 256-point complex radix-4 Stockham FFT (4 LDS-exchanged stages, 4 points per lane) and the
 // even/odd split.  The 64 mel filters map one-per-lane; the [64 mel][32 frame] tile goes
 // back to HBM as 128-byte row segments.
@@ -16,10 +16,8 @@ namespace vasr {
 
 namespace {
 
-constexpr int kFramesPerBlock = 32;
 constexpr int kWaves = 8;                       // 4 wavefronts x 8 frames left the LDS round trips of a frame exposed
 constexpr int kThreads = 64 * kWaves;
-constexpr int kFramesPerWave = kFramesPerBlock / kWaves;
 constexpr int kNfft = 512;
 
 struct cf { float re, im; };
@@ -37,12 +35,17 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// grid (ceil(T/32), B), block kThreads
+// grid (ceil(T / kFramesPerBlock), B), block kThreads.  kFramesPerBlock = 32 (four frames per wavefront, one after the other:
+// the throughput form, 62.5 % of the staged samples shared) or 8 (one frame per wavefront: a small batch's few workgroups
+// -- 21 for a 6.6 s clip -- are a chain of four dependent FFTs each, 16.5 us at batch 1; four times as many workgroups
+// of a quarter of the length fill more of the idle chip).  A frame's arithmetic does not depend on the block it is in.
+template <int kFramesPerBlock>
 __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
                                                           int64_t samples, const int64_t* __restrict__ row_len,
                                                           int hop, float preemph,
                                                           float log_guard, float* __restrict__ mel,
                                                           int64_t mel_ld, int frames) {
+  constexpr int kFramesPerWave = kFramesPerBlock / kWaves;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int seg_len = (kFramesPerBlock - 1) * hop + kNfft;
   float* seg = smem;                                   // [seg_len]
@@ -251,12 +254,18 @@ __global__ __launch_bounds__(256) void normalize_chain_kernel(float* __restrict_
 void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, const int64_t* row_len,
                         int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st) {
-  const int seg_len = (kFramesPerBlock - 1) * hop + kNfft;
-  size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kWaves * 256 * 8 + kWaves * (260 + kMelTaps) * 4 +
-               64 * (kFramesPerBlock + 1) * 4;
-  dim3 grid((frames + kFramesPerBlock - 1) / kFramesPerBlock, batch);
-  hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(kThreads), lds, st, tb, wav, samples, row_len, hop, preemph,
-                     log_guard, mel, mel_ld, frames);
+  auto go = [&](auto kern, int fpb) {
+    const int seg_len = (fpb - 1) * hop + kNfft;
+    const size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kWaves * 256 * 8 + kWaves * (260 + kMelTaps) * 4 + 64 * (fpb + 1) * 4;
+    dim3 grid((frames + fpb - 1) / fpb, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, tb, wav, samples, row_len, hop, preemph, log_guard, mel, mel_ld,
+                       frames);
+  };
+  // fewer 32-frame workgroups than half the chip's compute units: the one-frame-per-wavefront form
+  static const int force = dev_env("VASR_STFT_FPB") ? atoi(dev_env("VASR_STFT_FPB")) : 0;   // 8 | 32 (dev: A/B runs)
+  const bool small = force ? force == 8 : (int64_t)((frames + 31) / 32) * batch < 128;
+  if (small) go(stft_logmel_kernel<8>, 8);
+  else go(stft_logmel_kernel<32>, 32);
 }
 
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st) {
