@@ -283,7 +283,7 @@ int launch_lat_s(const PwArgs& a, hipStream_t st, int* amax_n) {
 
 }  // namespace
 
-// shapes the latency kernel covers: 128-row blocks, K = 256 / 512 / 1024 (and the halves of a dual source on the 64-row grid)
+// shapes the latency kernel covers: 128-row blocks, K = 256 / 512 / 1024 (a dual source splits K on the 256-row grid of the items)
 bool pointwise_latency_supported(int M, int K, int K1) {
   return M % (32 * LNW) == 0 && (K == 256 || K == 512 || K == 1024) && (K1 == 0 || K1 % 256 == 0);
 }
