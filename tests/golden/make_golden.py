@@ -144,7 +144,7 @@ def build_reference(cfg, labels):
     return nf, pre, enc, dec, greedy
 
 
-def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None):
+def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, band_hz=0):
     pkg = _load_pkg()
     synth = pkg.synth
     from nemo.collections.asr.helpers import post_process_predictions
@@ -161,7 +161,7 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None):
     assert not missing, sorted(missing)[:8]
     enc.load_state_dict({k: torch.as_tensor(v) for k, v in enc_sd.items()})
     dec.load_state_dict({k: torch.as_tensor(v) for k, v in dec_sd.items()})
-    sig, lens = synth.audio_batch(batch, samples, seed, ragged)
+    sig, lens = synth.audio_batch(batch, samples, seed, ragged, band_hz=band_hz or None)
     # the executor's call convention: pmodule(force_pt=True, **ports)  (actions.py:419-428)
     enc.eval(); dec.eval(); greedy.eval()                      # actions.py:412-415 (nn.Modules only: Q1)
     with torch.no_grad():
@@ -182,6 +182,23 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None):
         min_margin=np.float32(margin.min().item()),
         fb=pre.filter_banks[0].numpy(),
     )
+    if band_hz:   # (only the round-5 cases carry these keys: the older fixtures regenerate bit-identically without them)
+        out["band_hz"] = band_hz
+        out["sig_abs_sum"] = np.float64(np.abs(sig.astype(np.float64)).sum())
+        out["margin"] = margin.numpy()          # per frame: the tests may excuse a frame only by ITS margin
+        if real_decoder:
+            # the shipped head answers blank on every frame of an untrained encoder (empty transcripts): the same encoder output
+            # also goes through a seeded head whose transcripts bite (as run_real_audio_case does)
+            with torch.no_grad():
+                dec.load_state_dict({k: torch.as_tensor(v) for k, v in synth.decoder_state_dict(jas[-1]["filters"], len(labels) + 1, seed).items()})
+                logp_syn = dec(force_pt=True, encoder_output=e)
+                pred_syn = greedy(force_pt=True, log_probs=logp_syn)
+            t2 = torch.topk(logp_syn, 2, dim=-1).values
+            out["logp_syn"] = logp_syn.numpy()
+            out["pred_syn"] = pred_syn.numpy()
+            out["margin_syn"] = (t2[..., 0] - t2[..., 1]).numpy()
+            out["hyp_syn"] = np.array(post_process_predictions([pred_syn], labels), dtype=object).astype("U")
+            print("   hyp_syn[0][:60] =", repr(str(out["hyp_syn"][0])[:60]), f"min_margin_syn={out['margin_syn'].min():.3e}")
     if real_decoder:  # the shipped CTC-head checkpoint is data; carry it so the GPU box can replay the case
         out["dec_weight"] = dec_sd["decoder_layers.0.weight"]
         out["dec_bias"] = dec_sd["decoder_layers.0.bias"]
@@ -259,6 +276,9 @@ if __name__ == "__main__":
     run_case("vi12x1_b1_tiny", "quartznet12x1_vi.yaml", 1, 4000, 4, False)
     run_case("en12x1_b4_hopmult", "quartznet12x1.yaml", 4, 160 * 150, 5, True)     # third shipped config; L % hop == 0
     run_case("en15x5_b1_10s", "quartznet15x5.yaml", 1, 160000, 6, False)           # one full BASELINE-length clip
+    # round 5: the band-limited regime of 8 kHz-sourced audio, batched and ragged
+    run_case("vi12x1_b4_band4k_ragged", "quartznet12x1_vi.yaml", 4, 40000, 9, True, real_decoder=VI_DEC, band_hz=4000)
+    run_case("en15x5_b2_band4k", "quartznet15x5.yaml", 2, 30000, 10, False, band_hz=4000)
     # BASELINE config 1 plumbing: real recordings of the reference's audio_samples/ (16 kHz broadcast, 8 kHz call centre)
     run_real_audio_case("real16k_thoisu_5", "V1 1 11 12H00 THOI SU 2019_5.wav", 7)
     run_real_audio_case("real8k_external_2", "external_1202_771_20191118_093137_1574044304_22681_2.wav", 8)

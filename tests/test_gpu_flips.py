@@ -96,7 +96,7 @@ def _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict):
     return rec
 
 
-def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0):
+def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0, measured=None):
     from viet_asr_amd.engine import QuartzNetCTC
     from viet_asr_amd import synth
     from oracle import quartznet_oracle as O
@@ -121,21 +121,23 @@ def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0):
     cross = int((res["f16x2"]["pred"] != res["fp32"]["pred"]).sum())
     _record("flips_f16x2_vs_fp32_mode", tag=tag, frames=int(res["fp32"]["pred"].numel()), flips=cross)
     if head_gain == 1.0:
-        # BASELINE shapes: the split arithmetic must not be noisier than the exact-fp32 MFMA mode of the same library
-        # (a frame or two either way on ties inside float32 rounding), and both stay at the float32 oracle's own level
-        assert rec["f16x2"]["flips"] <= rec["fp32"]["flips"] + 2, rec
-        assert max(v["flips"] for v in rec.values()) <= 4, rec
+        # BASELINE shapes: the split arithmetic must not be noisier than the exact-fp32 MFMA mode of the same library, and
+        # the counts are the MEASURED ones (rounds 4 and 5; the kernels are deterministic, so a different count is a changed
+        # kernel, to be looked at and re-recorded -- not noise): `measured` = flips of (f16x2, bf16x3, fp32)
+        assert rec["f16x2"]["flips"] <= rec["fp32"]["flips"], rec
+        for g, n in zip(ARITHMETICS, measured):
+            assert rec[g]["flips"] <= n, (g, rec)
 
 
 def test_config3_every_frame_of_the_whole_batch(gpu):
     """BASELINE configs[2]: QuartzNet15x5, 64 x 10 s -- 64 x 501 = 32 064 frames per arithmetic."""
-    _whole_batch(gpu, "configs[2] 15x5 64x10s", "quartznet15x5", 29, 3, 64, ragged=False)
+    _whole_batch(gpu, "configs[2] 15x5 64x10s", "quartznet15x5", 29, 3, 64, ragged=False, measured=(1, 1, 2))
 
 
 def test_config3_ragged_every_frame_padded_frames_included(gpu):
     """The same shape with lengths U[0.5 L, L] (SURVEY section 8d's ragged variant): padded-batch semantics Q4 / Q5 -- a short
     row's STFT sees the zeros of the padded row and its padded frames are decoded like any other."""
-    _whole_batch(gpu, "configs[2] 15x5 64x10s ragged", "quartznet15x5", 29, 13, 64, ragged=True)
+    _whole_batch(gpu, "configs[2] 15x5 64x10s ragged", "quartznet15x5", 29, 13, 64, ragged=True, measured=(0, 0, 0))
 
 
 def test_config3_near_tie_head_every_frame(gpu):
@@ -148,7 +150,7 @@ def test_config3_near_tie_head_every_frame(gpu):
 
 def test_config2_every_frame_of_the_whole_batch(gpu):
     """BASELINE configs[1]: QuartzNet12x1 with the 91-class Vietnamese head shape, 32 x 10 s -- 16 032 frames."""
-    _whole_batch(gpu, "configs[1] 12x1_vi 32x10s", "quartznet12x1_vi", 91, 2, 32, ragged=False)
+    _whole_batch(gpu, "configs[1] 12x1_vi 32x10s", "quartznet12x1_vi", 91, 2, 32, ragged=False, measured=(0, 0, 0))
 
 
 def test_config5_every_eighth_row_every_frame(gpu):
@@ -215,8 +217,22 @@ def test_config5_every_eighth_row_every_frame(gpu):
     tag = "configs[4] shard 512x30s, rows 0::8"
     res = {"f16x2": _compare(tag, "f16x2", sub, ref)}
     rec = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=True)
-    assert rec["f16x2"]["flips"] <= 4, rec
-    if rec["f16x2"]["flips"] == 0:
-        assert eng.texts(r["ids"][rg], r["id_len"][rg]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
+    assert rec["f16x2"]["flips"] == 0, rec      # measured (rounds 4, 5): none in 96 064 frames
+    assert eng.texts(r["ids"][rg], r["id_len"][rg]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
+    # ---- (c) RECORDED, not asserted: the same 64 rows end to end, wav -> prediction, against the oracle
+    # run on ITS OWN features -- what the conditioning of the normalisation (above) costs in this regime, in frames
+    enc_e, _ = O.encoder_forward(mel_o, seq_o, enc_sd, jas)
+    logp_e = O.decoder_forward(enc_e, dec_sd)
+    pred_e = O.greedy_argmax(logp_e)
+    t2 = logp_e.topk(2, -1).values
+    marg = t2[..., 0] - t2[..., 1]
+    dev_p, dev_l = sub["pred"].cpu(), sub["logp"].cpu()
+    flip = dev_p != pred_e
+    err_e = float((dev_l - logp_e).abs().max())
+    rows_err = (dev_l - logp_e).abs().amax(dim=(1, 2))
+    _record("config5_end_to_end", rows=len(rows), frames=int(pred_e.numel()), end_to_end_flips=int(flip.sum()),
+            rows_with_a_flip=int(flip.any(dim=1).sum()), logp_err=err_e, logp_scale=float(logp_e.abs().max()),
+            median_row_err=float(rows_err.median()), flips_outside_twice_the_rows_error=int((flip & (marg > 2 * rows_err[:, None])).sum()),
+            transcripts_equal=sum(a == b for a, b in zip(eng.texts(r["ids"][rg], r["id_len"][rg]), O.ctc_decode_strings(pred_e, cfg["labels"]))))
     del r, x16
     torch.cuda.empty_cache()

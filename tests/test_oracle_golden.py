@@ -2,12 +2,12 @@
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden
+from conftest import BAND_CASES, GOLDEN_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden
 from oracle import audio_oracle as AO
 from oracle import quartznet_oracle as O
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + BAND_CASES)
 def test_oracle_matches_reference_outputs(name):
     g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
     assert (lens == g["lens"]).all()
@@ -23,6 +23,26 @@ def test_oracle_matches_reference_outputs(name):
     assert np.abs(r["logp"].numpy() - g["logp"]).max() <= 2e-4
     assert (r["pred"].numpy() == g["pred"]).all()
     assert O.ctc_decode_strings(r["pred"], cfg["labels"]) == [str(s) for s in g["hyp"]]
+    if "logp_syn" in g.files:   # band-limited vi case: the same encoder output through the seeded head
+        from viet_asr_amd import synth
+        syn = synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, int(g["seed"]))
+        r2 = O.forward_all(sig, lens, enc_sd, syn, cfg["JasperEncoder"]["jasper"])
+        assert np.abs(r2["logp"].numpy() - g["logp_syn"]).max() <= 2e-4
+        assert (r2["pred"].numpy() == g["pred_syn"]).all()
+        assert O.ctc_decode_strings(r2["pred"], cfg["labels"]) == [str(s) for s in g["hyp_syn"]] and len(str(g["hyp_syn"][0])) > 10
+
+
+def test_band_limited_fixtures_are_band_limited():
+    """The round-5 fixtures really are in the regime they are named after: nothing above 4 kHz but the filter's floor,
+    i.e. the upper mel bins (no weight below 4.2 kHz: the last 12 of 64) see only that floor."""
+    for name in BAND_CASES:
+        g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
+        spec = np.abs(np.fft.rfft(sig[0, : lens[0]].astype(np.float64))) ** 2
+        f = np.fft.rfftfreq(int(lens[0]), 1 / 16000.0)
+        assert spec[f > 4400].sum() < 1e-5 * spec[f < 3600].sum()      # (what is left is the leakage of the row's own edges)
+        fb = g["fb"]
+        upper = [m for m in range(64) if fb[m, : int(4200 / 8000 * 256)].sum() == 0]
+        assert len(upper) >= 12
 
 
 @pytest.mark.parametrize("name", REAL_AUDIO_CASES)

@@ -532,6 +532,25 @@ cd $R/tools/probes
 for p in place_probe tr_probe; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $p.hip -o $p && ./$p; done
 }
 
+# ---- r5probe: round 5, kill criterion of the fused 512-channel kernel: (a) matrix / vector wavefronts sharing a SIMD, register-resident
+#      (tools/probes/coissue_probe.hip); (b) the 512 x 64 GEMM tile with 4 extra wavefronts issuing a depthwise producer's FMAs
+task_r5probe() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5probe}; mkdir -p $O; cd $R/tools/probes
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 coissue_probe.hip -o coissue_probe && ./coissue_probe > $O/coissue.txt 2>&1
+cd $R
+{
+echo "== default library, tile rule (512 x 128)"; python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+echo "== default library, 512 x 64 tile (VASR_PW3_TILE=8)"; VASR_PW3_TILE=8 python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+for f in $R/viet-asr_amd/lib/var_x*.so; do
+  echo "== $(basename $f), 512 x 64 tile"; VASR_LIB_PATH=$f VASR_PW3_TILE=8 python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+done
+echo "== x0_ns (no activation staging), 512 x 128 tile"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_x0_ns.so python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+echo "== depthwise alone"; python tools/bench_dw.py 51 63 75 2>&1 | grep -v amdgpu
+echo "== normalisers"; python tools/mfma_sustained.py 2>&1 | grep -v amdgpu; python tools/copy_bw.py 2>&1 | grep -v amdgpu
+} > $O/probe.txt 2>&1
+cat $O/coissue.txt $O/probe.txt
+}
+
 task=${1:-list}; shift || true
 if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
 if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi

@@ -128,9 +128,26 @@ struct Geom {
   static_assert(PATCHES % NT == 0 && PPT >= 1, "staging patches must divide evenly over the threads");
 };
 
+// Dev experiment of round 5 (profiles/r05_fused512_probe.txt): VASR_PW_XWAVES extra wavefronts join the 512 x 64 tile's
+// workgroup, take part in its barriers and execute VASR_PW_XFILL packed FMAs per K chunk each -- the vector work the
+// depthwise PRODUCER wavefronts of a fused 512-channel kernel would issue next to this GEMM stream (8 K per lane and
+// chunk for 16 channels x 64 frames per wavefront: 408 at K = 51, 504 at 63, 600 at 75).  Results stay correct.
+#ifndef VASR_PW_XWAVES
+#define VASR_PW_XWAVES 0
+#endif
+#ifndef VASR_PW_XFILL
+#define VASR_PW_XFILL 408
+#endif
+#ifndef VASR_PW_XPLAIN
+#define VASR_PW_XPLAIN 0   // 1: two v_fma_f32 instead of one v_pk_fma_f32
+#endif
+template <int NW, int TM, int TN>
+constexpr int extra_waves() { return (NW == 8 && TM == 2 && TN == 2) ? VASR_PW_XWAVES : 0; }
+
 template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, int ARITH>
-__global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+__global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_waves<NW, TM, TN>() ? 1 : 2)) void pw_gemm_split_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
   using G = Geom<NW, TM, TN, ARITH>;
+  constexpr int XW = extra_waves<NW, TM, TN>();
   constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT, PL = G::PL, PLW = G::PLW;
   extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][PL][STEPS][2][BN]
   auto bs = [&](int buf, int plane, int s, int kb, int n) -> uint4& {
@@ -312,6 +329,35 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int
   // (A separate tail for the odd chunk was tried first: a second conditional copy of the chunk body next to the
   // final-pair block makes the register allocator spill ~160 registers around the merge of the 128 accumulators.)
   const int odd = nchunks & 1;
+  if constexpr (XW > 0) {
+    if (wave >= NW) {
+      v2f fa[8], fx[8], fw[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { fa[j] = v2f{0.f, 0.f}; fx[j] = v2f{(float)(tid + j), 1e-3f * lane}; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fw[k] = v2f{1e-3f * (k + 1), 1e-4f * tid};
+      __syncthreads();
+      for (int c = 0; c < nchunks + (nchunks ? odd : 0); ++c) {
+        for (int it = 0; it < VASR_PW_XFILL / 8; ++it) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (VASR_PW_XPLAIN) {
+              asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fa[j].x) : "v"(fw[j & 3].x), "v"(fx[j].x));
+              asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fa[j].y) : "v"(fw[j & 3].y), "v"(fx[j].y));
+            } else {
+              asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(fa[j]) : "v"(fw[j & 3]), "v"(fx[j]));
+            }
+          }
+        }
+        __syncthreads();
+      }
+      float fsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fsum += fa[j].x + fa[j].y;
+      if (fsum == 12345.678f) a.y[0] = fsum;
+      return;
+    }
+  }
   unsigned amv[8], amv2[8];
   if (nchunks) {
     if constexpr (ARITH == kF16x2) {
@@ -632,7 +678,7 @@ int launch_k(const PwArgs& a, hipStream_t st, int* amax_n) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   if (attr != hipSuccess) return (int)attr;
-  VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
+  VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT + 64 * extra_waves<NW, TM, TN>()), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
   return 0;
 }
 

@@ -98,12 +98,27 @@ def decoder_state_dict(feat_in, num_classes_with_blank, seed=0):
     return sd
 
 
-def audio_batch(batch, samples, seed=0, ragged=False, amp=0.1):
+def band_limit(x, band_hz, rate=16000, taps=255, beta=8.6):
+    """Rows of ``x`` low-passed at ``band_hz`` by a Kaiser-windowed sinc (about -85 dB in the stop band), float64
+    accumulation in a fixed order (no FFT: the result must be the same bits wherever the fixtures are replayed).
+    This is what 8 kHz-sourced audio looks like after its conversion to the model's 16 kHz (the reference's stated
+    domain, README.md:21): the upper third of the mel bins holds nothing but the filter's floor."""
+    n = np.arange(taps, dtype=np.float64) - (taps - 1) / 2
+    h = 2.0 * band_hz / rate * np.sinc(2.0 * band_hz / rate * n) * np.kaiser(taps, beta)
+    h /= h.sum()
+    out = np.empty_like(x)
+    for b in range(x.shape[0]):
+        out[b] = np.convolve(x[b].astype(np.float64), h, mode="same").astype(np.float32)
+    return out
+
+
+def audio_batch(batch, samples, seed=0, ragged=False, amp=0.1, band_hz=None):
     """(signal [B,L] f32 zero-padded past each length, length [B] i64).
 
     Smoothed uniform noise (a 3-tap low-pass over U(-amp, amp)); with ``ragged`` the
     lengths are uniform in [L/2, L] and the longest row is forced to L, mirroring the
-    zero-pad-to-max collate of parts/dataset.py:14-53.
+    zero-pad-to-max collate of parts/dataset.py:14-53.  ``band_hz``: additionally
+    low-passed there (``band_limit``) and brought back to the same peak level.
     """
     r = np.random.RandomState(1234567 + seed)
     x = r.uniform(-amp, amp, size=(batch, samples + 2)).astype(np.float32)
@@ -112,6 +127,9 @@ def audio_batch(batch, samples, seed=0, ragged=False, amp=0.1):
     t = np.arange(samples, dtype=np.float32) / 16000.0
     env = (0.6 + 0.4 * np.sin(2 * np.pi * (0.7 + 0.1 * np.arange(batch)[:, None]) * t[None, :])).astype(np.float32)
     x = (x * env).astype(np.float32)
+    if band_hz:
+        x = band_limit(x, float(band_hz))
+        x = (x * np.float32(amp / max(float(np.abs(x).max()), 1e-9))).astype(np.float32)
     if ragged:
         lens = r.randint(samples // 2, samples + 1, size=batch).astype(np.int64)
         lens[r.randint(0, batch)] = samples
