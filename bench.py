@@ -40,6 +40,9 @@ Prints ONE JSON line on rank 0 with the driver contract keys plus
   fused         -- the fused depthwise + pointwise launches on their own
   beam          -- (--config 4) the search kernel: ms per batch, workgroups (= CUs) it occupies
   cpu_baseline  -- the CPU oracle (same ATen ops as the reference) on this box's host cores, bounded sample
+  box           -- what THIS box sustains, measured after the timed region (bare MFMA stream, float4 streaming pass beyond and
+                   inside the Infinity Cache); roofline.frac_of_measured / depthwise.frac_of_measured_copy* and the sol floors
+                   are quoted against them, so that lines from different boxes can be compared
 """
 import argparse
 import json
@@ -425,11 +428,61 @@ def model_traffic_bytes(jas, feat_in, classes, batch, T):
     return unf + w, fus + w
 
 
-def sol_block(cfg, work, batch, samples, step_ms, launches_b1):
+def box_normalisers(dev):
+    """What THIS box sustains, measured right after the timed region (chip warm) so that rounds on different boxes can be
+    compared (three of four rounds' headline deltas were inside the box-to-box spread):
+      * measured_mfma_tflops: the GEMM's instruction stream with everything but its MFMAs removed (8 wavefronts per CU, 48
+        16-bit MFMAs per k-step on 8 accumulators, operands of realistic bit patterns resident in registers;
+        csrc/encoder_pw_split.hip mfma_bf16_sustained_kernel through the devtools build), 4 launches of ~8 ms;
+      * measured_copy_gbs: read + write rate of a float4 streaming pass over 2 x 1 GiB (far beyond the 256 MiB Infinity
+        Cache: HBM itself); measured_copy_gbs_cache_resident: the same over 2 x 67 MB -- the size of the headline workload's
+        512-channel activations, which is what its depthwise layers are really bounded by.
+    Measurement plumbing only (torch.clamp_min as the streaming pass): nothing here is on the product path."""
+    import ctypes
+    out = {}
+    try:
+        D = _lib.dev_lib()
+        sink = torch.zeros(16, device=dev)
+        fl = ctypes.c_double()
+        st = torch.cuda.current_stream().cuda_stream
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        run = lambda: _lib.check(D.vasr_bench_mfma_bf16_sustained(n_cu, 4000, sink.data_ptr(), ctypes.byref(fl), st), D)
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        out["measured_mfma_tflops"] = round(4 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    except Exception as e:  # noqa: BLE001 -- a normaliser must not take the bench line down
+        out["measured_mfma_error"] = repr(e)[:200]
+    for key, n in (("measured_copy_gbs", 1 << 28), ("measured_copy_gbs_cache_resident", 64 * 512 * 512)):
+        x = torch.randn(n, device=dev)
+        y = torch.empty_like(x)
+        for _ in range(3):
+            torch.clamp_min(x, 0, out=y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10 if n > (1 << 26) else 50
+        e0.record()
+        for _ in range(reps):
+            torch.clamp_min(x, 0, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        out[key] = round(reps * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def sol_block(cfg, work, batch, samples, step_ms, launches_b1, norm=None):
     """Speed-of-light table of the headline step, so that the measured step can be read against its floors without redoing
     the arithmetic.  MFMA floor: 3 fp16 products per multiply at the nominal 2.5 PFLOP/s and at the
-    ~1.75 PFLOP/s the part sustains under dense MFMA load (power-limited: DESIGN section 4, profiles/r02_clock_probe.txt
-    1.83 PF bare stream, 1.66 PF with realistic operands).  HBM floors at the guide's achievable 6.3 TB/s."""
+    rate THIS box's bare MFMA stream sustains (power-limited: DESIGN section 4; round 4 used the constant 1.75 PFLOP/s here).
+    HBM floors at the box's measured streaming rate (the guide's achievable 6.3 TB/s when the measurement failed)."""
+    norm = norm or {}
+    mfma = norm.get("measured_mfma_tflops") or 1750.0
+    copy = norm.get("measured_copy_gbs") or 6300.0
     jas = cfg["JasperEncoder"]["jasper"]
     T = 1 + samples // 160
     unf, fus = model_traffic_bytes(jas, 64, len(cfg["labels"]) + 1, batch, T)
@@ -438,14 +491,16 @@ def sol_block(cfg, work, batch, samples, step_ms, launches_b1):
     exec_flops = 3.0 * (work["pointwise_flops"] + work["decoder_flops"])
     return {"step_ms_measured": round(step_ms, 3),
             "mfma_floor_ms_at_2500_tflops": round(exec_flops / 2.5e15 * 1e3, 3),
-            "mfma_floor_ms_at_sustained_1750_tflops": round(exec_flops / 1.75e15 * 1e3, 3),
-            "hbm_floor_ms_unfused_graph_at_6300_gbs": round(unf / 6.3e12 * 1e3, 3),
-            "hbm_floor_ms_fully_fused_graph_at_6300_gbs": round(fus / 6.3e12 * 1e3, 3),
+            "measured_mfma_tflops": norm.get("measured_mfma_tflops"), "measured_copy_gbs": norm.get("measured_copy_gbs"),
+            "measured_copy_gbs_cache_resident": norm.get("measured_copy_gbs_cache_resident"),
+            "mfma_floor_ms_at_measured_sustained": round(exec_flops / (mfma * 1e12) * 1e3, 3),
+            "hbm_floor_ms_unfused_graph_at_measured_copy": round(unf / (copy * 1e9) * 1e3, 3),
+            "hbm_floor_ms_fully_fused_graph_at_measured_copy": round(fus / (copy * 1e9) * 1e3, 3),
             "bytes_unfused_graph": unf, "bytes_fully_fused_graph": fus, "executed_mfma_flops": exec_flops,
             "b1_launches": launches_b1,
             "b1_launch_floor_ms": round(launches_b1 * 1.45e-3, 3) if launches_b1 else None,
-            "step_over_mfma_floor_sustained": round(step_ms / (exec_flops / 1.75e15 * 1e3), 2),
-            "note": "floors are not additive (MFMA and HBM phases can overlap); b1_launch_floor = launches of a batch-1 call x the "
+            "step_over_mfma_floor_sustained": round(step_ms / (exec_flops / (mfma * 1e12) * 1e3), 2),
+            "note": "measured_* = this box, right after the timed region (box_normalisers); floors are not additive (MFMA and HBM phases can overlap); b1_launch_floor = launches of a batch-1 call x the "
                     "1.45 us dependent-kernel boundary of MI355X_MICROARCH.md's price list"}
 
 
@@ -789,6 +844,17 @@ def main():
             out.update(rccl)
         if other is not None:
             out["other_gemm_arithmetic"] = other
+        norm = box_normalisers(dev)
+        if norm.get("measured_mfma_tflops") and gemm != "fp32":
+            out["roofline"]["measured_sustained_peak"] = norm["measured_mfma_tflops"]
+            out["roofline"]["frac_of_measured"] = round(cr["exec_tflops"] / norm["measured_mfma_tflops"], 4)
+            out["roofline"]["gemm_family"]["frac_of_measured"] = round(cr["fam_exec_tflops"] / norm["measured_mfma_tflops"], 4)
+        if norm.get("measured_copy_gbs"):
+            out["depthwise"]["measured_copy_gbs"] = norm["measured_copy_gbs"]
+            out["depthwise"]["measured_copy_gbs_cache_resident"] = norm["measured_copy_gbs_cache_resident"]
+            out["depthwise"]["frac_of_measured_copy"] = round(cr["dw_gbs"] / norm["measured_copy_gbs"], 4)
+            out["depthwise"]["frac_of_measured_copy_cache_resident"] = round(cr["dw_gbs"] / norm["measured_copy_gbs_cache_resident"], 4)
+        out["box"] = norm
         if headline and world == 1 and not a.no_side_configs:
             side = {}
             for key, cid, rag in (("2", 2, False), ("3r", 3, True), ("4", 4, False), ("5", 5, False)):
@@ -809,9 +875,10 @@ def main():
             eng.forward(w1, l1, want_logp=False, want_pred=False)
             torch.cuda.synchronize()
             p1 = eng.handle.profile_end()
-            # front end = 3 launches, head = GEMM + log-softmax/argmax + collapse, + the length chain
-            launches_b1 = sum(p1[k]["launches"] for k in ("depthwise", "pointwise", "fused")) + 3 + 3 + 1
-            out["sol"] = sol_block(cfg, work, batch, samples, elapsed / a.steps * 1e3, launches_b1)
+            # front end = stft_logmel + normalize_chain (which carries seq and the length chain), head = GEMM + log-softmax /
+            # argmax + collapse; the class counters come from the library, so only these five are counted by hand
+            launches_b1 = sum(p1[k]["launches"] for k in ("depthwise", "pointwise", "fused")) + 2 + 3
+            out["sol"] = sol_block(cfg, work, batch, samples, elapsed / a.steps * 1e3, launches_b1, norm)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, seed, decoder, lm_path, batch=batch, clip_seconds=seconds)
         if dist is not None:
