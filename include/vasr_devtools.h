@@ -56,14 +56,6 @@ VASR_API int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16,
                                const float* d_shift, int batch, int cin, int cout, int64_t frames, float* d_y,
                                uint32_t* d_amax, int amax_stride, vasr_stream stream);
 
-/* The same layer on a PRE-SPLIT ("P4") input tensor (csrc/encoder_pw_p4.hip): vasr_pack_p4 is the host restatement of the
- * layout for one utterance -- x [rows][ld] fp32, `scale` a power of two -> [rows][ld / 4][8] fp16 bit patterns; d_x_inv
- * holds 1 / scale per utterance.  d_amax_y: one maxima table [B][amax_stride] (or NULL). */
-VASR_API int vasr_pack_p4(const float* h_x, int rows, int64_t ld, float scale, uint16_t* h_out);
-VASR_API int vasr_bench_pointwise_p4(const uint16_t* d_x_p4, const float* d_x_inv, const uint16_t* d_w16, float w_inv_scale,
-                            const float* d_scale, const float* d_shift, int batch, int cin, int cout, int64_t frames,
-                            float* d_y, uint32_t* d_amax_y, int amax_stride, vasr_stream stream);
-
 /* 3 x bf16 split variants of the two helpers above (fragments: [m_pad/32][cin/16][3][64 lanes][8] bf16 bits). */
 VASR_API int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out);
 VASR_API int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,

@@ -55,8 +55,15 @@ def run_case(case):
     path = [None, toy, abc][lm_kind]
     dec = BeamSearchDecoder(T.LABELS, lm_path=path, alpha=alpha, beta=beta)
     x = torch.from_numpy(lp[None]).cuda()
-    ids, n, score = dec.decode_ids(x, bw)
+    ids, n, score = dec.decode_ids(x, bw)          # batch 1: the latency form, an utterance on four wavefronts (beam_group.hip)
     text = dec.decode_batch(x, bw)[0]
+    # the same utterance as rows of a batch of 16: one wavefront per utterance (beam_wave.hip) -- must give the SAME BITS
+    ids16, n16, score16 = dec.decode_ids(x.expand(16, -1, -1).contiguous(), bw)
+    for row in (0, 15):
+        k = int(n[0])
+        if int(n16[row]) != k or not torch.equal(ids16[row, :k], ids[0, :k]) or float(score16[row]) != float(score[0]):
+            return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind}: the one-wavefront kernel (row {row} of 16) and the "
+                    f"four-wavefront kernel disagree: lengths {int(n16[row])} / {k}, scores {float(score16[row])!r} / {float(score[0])!r}")
     lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=alpha, beta=beta) if path else None
     ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm)
     close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3

@@ -69,6 +69,16 @@ def test_arpa_round_trip_and_backoff(tmp_path):
         f.write(b"mmap lm http://kheafield.com/code format version 5\n\0")
     with pytest.raises(NotImplementedError):
         read_arpa(os.path.join(str(tmp_path), "x.binary"))
+    # the reference's default lm_path IS such a file (infer.py:184): a decoder built on it must not lose the LM silently
+    from viet_asr_amd.beam import BeamSearchDecoder
+    with pytest.raises(ValueError, match="ARPA"):
+        BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "x.binary"))
+    with pytest.raises(ValueError, match="lmplz"):
+        BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "no_such_file.arpa"))
+    with pytest.warns(UserWarning, match="without a language model"):
+        d = BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "x.binary"), allow_missing_lm=True)
+    assert d.lm_path is None
+    assert BeamSearchDecoder(LABELS, lm_path=path).lm_path == path
 
 
 def test_lm_changes_the_ranking(tmp_path):
@@ -347,31 +357,34 @@ np.save({dst!r}, np.array([(a.tobytes(), b.tobytes(), c.tobytes()) for a, b, c i
 
 
 @pytest.mark.gpu
-def test_wave_kernel_and_workgroup_kernel_agree(gpu, tmp_path):
-    """beam_wave.hip (one wavefront per utterance, the product kernel) against beam.hip (one 512-thread workgroup per
-    utterance, rounds 1-3, devtools build, VASR_BEAM_WG=1): the same merge arithmetic (ordered-int max, fixed-point sums)
-    in a different schedule -- hypotheses, lengths and scores identical bit for bit on CTC-like, flat and peaked posteriors,
-    widths 8 ... 128, with and without the LM.  Each kernel runs in its own process (the switch is read once)."""
+def test_wave_kernel_and_group_kernel_agree(gpu, tmp_path):
+    """beam_wave.hip (one wavefront per utterance: batches) against beam_group.hip (an utterance on 4 or 2 wavefronts of a
+    compute unit: the serving latency; VASR_BEAM_GROUP pins the form in the devtools build): the same keys, merge arithmetic
+    (ordered-int max, fixed-point sums), prune, radix select and rank rules on a different schedule -- hypotheses, lengths and
+    scores identical bit for bit on CTC-like, flat and peaked posteriors, widths 8 ... 128, with and without the LM (flat
+    posteriors at width 100-128 take several passes per frame and a radix select on most).  Each form runs in its own
+    process (the switch is read once)."""
     import subprocess, sys
     from conftest import ROOT
     dev = os.path.join(ROOT, "viet-asr_amd", "lib", "libvasr_hip_dev.so")
     res = []
-    for tag, extra in (("wave", {}), ("wg", {"VASR_BEAM_WG": "1"})):
+    for tag, extra in (("wave", {"VASR_BEAM_GROUP": "0"}), ("group4", {"VASR_BEAM_GROUP": "4"}), ("group2", {"VASR_BEAM_GROUP": "2"})):
         dst = str(tmp_path / f"{tag}.npy")
         env = dict(os.environ, VASR_LIB_PATH=dev, **extra)
         r = subprocess.run([sys.executable, "-c", _AB_SNIPPET.format(root=ROOT, tmp=str(tmp_path), dst=dst)], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(dst, allow_pickle=True))
-    assert len(res[0]) == len(res[1]) == 8
-    for k, (a, b) in enumerate(zip(res[0], res[1])):
-        n_a, n_b = np.frombuffer(a[1], np.int32), np.frombuffer(b[1], np.int32)
-        assert (n_a == n_b).all(), k
-        ids_a = np.frombuffer(a[0], np.int32).reshape(len(n_a), -1)
-        ids_b = np.frombuffer(b[0], np.int32).reshape(len(n_b), -1)
-        for r_ in range(len(n_a)):
-            assert (ids_a[r_, : n_a[r_]] == ids_b[r_, : n_b[r_]]).all(), (k, r_)
-        assert a[2] == b[2], k            # scores, bit for bit
+    assert len(res[0]) == len(res[1]) == len(res[2]) == 8
+    for other in (1, 2):
+        for k, (a, b) in enumerate(zip(res[0], res[other])):
+            n_a, n_b = np.frombuffer(a[1], np.int32), np.frombuffer(b[1], np.int32)
+            assert (n_a == n_b).all(), (other, k)
+            ids_a = np.frombuffer(a[0], np.int32).reshape(len(n_a), -1)
+            ids_b = np.frombuffer(b[0], np.int32).reshape(len(n_b), -1)
+            for r_ in range(len(n_a)):
+                assert (ids_a[r_, : n_a[r_]] == ids_b[r_, : n_b[r_]]).all(), (other, k, r_)
+            assert a[2] == b[2], (other, k)            # scores, bit for bit
 
 
 @pytest.mark.gpu

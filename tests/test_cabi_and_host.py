@@ -120,54 +120,6 @@ def test_fused_sub_block_form_by_batch_size():
     assert L.vasr_fused_tile_choice(0, 256) == 0
 
 
-def test_presplit_tensor_layout_and_its_lds_image():
-    """The "P4" layout of the pre-split-input GEMM prototype (csrc/encoder_pw_p4.hip, devtools build) and the index algebra of
-    its LDS image, replayed in numpy: vasr_pack_p4 writes [4 x hi | 4 x lo] groups (halves swapped on channels with
-    c & 2); the DMA puts source group p of chunk row r into slot p ^ 8 (r & 1); the transposing reads -- lane L supplies
-    8 bytes of row L % 16 / 4, quad L % 4, and receives column L % 16 of the four rows (tools/probes/tr_probe.hip) -- must
-    hand lane (n, kh) the channels 8 kh .. 8 kh + 7 of column n, and a half wave must touch 64 distinct banks."""
-    L = _lib.dev_lib()
-    rows, ld, scale = 64, 128, 4.0
-    rng = np.random.default_rng(3)
-    x = rng.standard_normal((rows, ld)).astype(np.float32)
-    out = np.empty((rows, ld // 4, 8), dtype=np.uint16)
-    _lib.check(L.vasr_pack_p4(x.ctypes.data, rows, ld, scale, out.ctypes.data), L)
-    hi = (x * scale).astype(np.float16)
-    lo = (x * scale - hi.astype(np.float32)).astype(np.float16)
-    for c in range(rows):
-        a, b = (lo, hi) if c & 2 else (hi, lo)
-        assert np.array_equal(out[c, :, :4].view(np.float16), a[c].reshape(-1, 4))
-        assert np.array_equal(out[c, :, 4:].view(np.float16), b[c].reshape(-1, 4))
-    # LDS image of one chunk: 64 rows x 32 slots of 16 bytes, as the DMA leaves it
-    img = np.zeros((64, 32, 8), dtype=np.uint16)
-    for r in range(64):
-        for p in range(32):
-            img[r, p ^ (8 * (r & 1))] = out[r, p]
-    flat = img.reshape(-1)                                   # 2-byte elements; byte address = 2 * index
-    for s, j, plane in [(0, 0, 0), (1, 3, 1), (3, 2, 0), (2, 1, 1)]:
-        frag = np.zeros((64, 8), dtype=np.uint16)
-        banks = [set(), set()]
-        for h in range(2):                                   # the two reads of a fragment: rows +0..3, +4..7
-            addr = np.zeros(64, dtype=np.int64)
-            for lane in range(64):
-                g, i = lane >> 4, lane & 15
-                r, q = i >> 2, i & 3
-                base = (8 * (g >> 1) + r) * 512 + 64 * (g & 1) + 16 * q
-                base += ((-128 if j & 1 else 128) if r & 1 else 0) + 8 * (plane ^ ((r >> 1) & 1))
-                addr[lane] = base + s * 16 * 512 + 128 * j + h * 4 * 512
-                banks[lane >> 5] |= {(addr[lane] // 4 + d) % 64 + 64 * h for d in range(2)}
-            for lane in range(64):                           # receive: element e <- the piece supplied by lane 4 e + l / 4 of the group
-                g, l = lane >> 4, lane & 15
-                for e in range(4):
-                    src = addr[16 * g + 4 * e + l // 4] // 2 + l % 4
-                    frag[lane, 4 * h + e] = flat[src]
-        assert all(len(b) == 128 for b in banks)             # 2 reads x 64 banks, no bank twice per half wave and read
-        want = (hi, lo)[plane]
-        for lane in range(64):
-            n, kh = lane & 31, lane >> 5
-            assert np.array_equal(frag[lane].view(np.float16), want[16 * s + 8 * kh:16 * s + 8 * kh + 8, 32 * j + n])
-
-
 @pytest.mark.parametrize("K,dil", [(33, 1), (39, 1), (51, 1), (63, 1), (75, 1), (87, 2)])
 def test_depthwise_tap_tables_form_the_toeplitz_product(K, dil):
     """vasr_pack_depthwise_taps (host side of encoder_dw_mfma.hip): the [hi | lo] fp16 table of a channel, read the way the

@@ -165,6 +165,11 @@ def _worker(rank, world, port, q):
         #    a fixed-shape batch, ranks deliberately out of step (rank r sleeps r x 5 ms before each submit), two shapes;
         #    every gathered buffer must hold every rank's batch of THAT step when it is read after the next submit
         ring = vdist.AsyncIdGather(world, torch.device("cpu"))
+        try:
+            ring.last()
+            raise AssertionError("last() before submit() must raise")
+        except RuntimeError:
+            pass
         import time as _t
         seen = []
         for step in range(7):
@@ -190,6 +195,12 @@ def _worker(rank, world, port, q):
         ring.drain()
         assert ring._bufs[(2, 3)][s0][0][:, 0, 0].tolist() == [10 + r for r in range(world)]
         assert ring._bufs[(2, 3)][s1][1][:, 0].tolist() == [7 + r for r in range(world)]
+        # shapes no longer in flight are dropped once more than max_shapes buffer sets exist (a loop over drifting [B, T'])
+        for k in range(8):
+            ring.submit(torch.full((2, 10 + k), rank, dtype=torch.int32), torch.full((2,), k, dtype=torch.int32))
+        g_ids, g_n = ring.last()
+        assert g_ids.shape == (world, 2, 17) and g_n[:, 0].tolist() == [7] * world
+        assert len(ring._bufs) <= ring.max_shapes + 1, len(ring._bufs)
         NeuralModuleFactory.reset_default_factory()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -57,10 +57,12 @@ def test_fused_path_matches_reference_goldens(gpu, name, gemm):
     assert eng.texts(r["ids"], r["id_len"]) == [str(s) for s in g["hyp"]]
 
 
-# Band-limited audio (nothing above 4 kHz): the upper mel bins sit at the log guard and the reference's normalisation
-# (x - mean) / (std + 1e-5), parts/features.py:17-30, divides any float32 front end's rounding by their tiny std (DESIGN
-# section 2; the real 8 kHz recording below is held to the same factor).  Measured on the two fixtures: see the records.
-BAND_LOGP_FACTOR = 10
+# Band-limited audio (nothing above 4 kHz but the anti-alias filter's -85 dB floor).  Measured on the two fixtures (round 5,
+# profiles/r05_parity_errors.jsonl): log-prob error 1.6e-4 ... 5.2e-4 at |log-prob| 46 ... 83, features 1.8e-5 / 3.6e-5 over
+# ALL bins, 0 of 692 frames differ -- inside the ordinary goldens' tolerance, so they get no allowance.  (What DOES need
+# one is a recording whose upper bins sit exactly at the log guard -- the real 8 kHz file below, the 512 x 30 s shard of
+# test_gpu_flips.py -- where the reference's (x - mean) / (std + 1e-5) divides by a std of 1e-3)
+BAND_LOGP_FACTOR = 1
 
 
 @pytest.mark.parametrize("gemm", ["f16x2", "fp32"])
@@ -100,7 +102,7 @@ def test_band_limited_reference_goldens(gpu, name, gemm):
     e_low = float(np.abs(mel[:, lower] - g["mel"][:, lower]).max())
     e_all = float(np.abs(mel - g["mel"]).max())
     _record("band_goldens_mel", name=name, err_bins_below_4k=e_low, err_all_bins=e_all, bins_below=int(lower.sum()))
-    assert e_low <= MEL_TOL, e_low
+    assert e_low <= MEL_TOL and e_all <= MEL_TOL, (e_low, e_all)
 
 
 def _oracle(cfg, sig, lens, enc_sd, dec_sd):
@@ -411,6 +413,36 @@ def test_results_do_not_depend_on_batch_size_or_tile_shape(gpu, gemm):
         r1 = eng.forward(torch.from_numpy(sig[b:b + 1]).to(gpu), torch.from_numpy(lens[b:b + 1]).to(gpu), want_logp=True)
         assert torch.equal(r["logp"][b], r1["logp"][0])
         assert torch.equal(r["pred"][b], r1["pred"][0])
+
+
+def test_default_mode_rows_across_batch_sizes_through_the_fused_kernel(gpu):
+    """in the DEFAULT mode a row's log-probs depend (slightly) on the batch it sits in, because the 256-channel
+    sub-blocks take the fused depthwise + pointwise kernel for some batch shapes (10 s clips: 64-frame tiles at 12-32
+    utterances, 128-frame tiles from ~52) and two kernels for the others, and the fused form derives its fp16 split scale
+    from a bound instead of the measured maximum.  This pins HOW MUCH: one 10 s clip alone (two kernels, latency GEMM),
+    inside a batch of 16 (64-frame fused form) and inside a batch of 64 (128-frame form) -- identical predictions, log-probs
+    within a quarter of the parity tolerance (measured ~2e-5 at |log-prob| 40).  Bit-identical rows for EVERY batch shape
+    are what vasr_set_row_independent promises (it never fuses), not the default mode: include/vasr.h says so."""
+    from viet_asr_amd import configs, synth
+    cfg = configs.builtin("quartznet15x5")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = _engine(cfg, synth.encoder_state_dict(jas, 64, 21), synth.decoder_state_dict(1024, 29, 21))
+    sig, lens = synth.audio_batch(64, 160000, 21)
+    wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    eng.handle.profile_begin()
+    r1 = eng.forward(wav[:1], ln[:1], want_logp=True)
+    torch.cuda.synchronize()
+    assert eng.handle.profile_end()["fused"]["launches"] == 0
+    tol = logp_tol(r1["logp"].cpu().numpy()) / 4
+    for B in (16, 64):
+        eng.handle.profile_begin()
+        rb = eng.forward(wav[:B], ln[:B], want_logp=True)
+        torch.cuda.synchronize()
+        assert eng.handle.profile_end()["fused"]["launches"] == 30          # every 256-channel sub-block went through the fused kernel
+        err = float((rb["logp"][0] - r1["logp"][0]).abs().max())
+        _record("default_mode_batch_dependence", batch=B, err=err, scale=float(r1["logp"].abs().max()), tol=tol)
+        assert err <= tol, (B, err, tol)
+        assert torch.equal(rb["pred"][0], r1["pred"][0])
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)

@@ -245,51 +245,3 @@ def test_fused_depthwise_pointwise_kernel_on_random_shapes(gpu, tile):
     assert "FUSED_FUZZ_OK" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
 
 
-def test_presplit_gemm_prototype_is_bit_identical_to_the_shipped_gemm(gpu):
-    """csrc/encoder_pw_p4.hip (devtools build only; VERDICT r02 item 2's plan -- activations pre-split by their producer,
-    LDS-DMA staging, ds_read_b64_tr_b16 fragments -- built and measured in round 3): on operands split
-    with the scale the shipped kernel derives itself it must give the SAME BITS as pw_gemm_split_kernel (same products,
-    same accumulation order), including the output maxima it publishes, on a ragged-magnitude batch."""
-    import ctypes as C
-    from viet_asr_amd import _lib
-    L = _lib.dev_lib()
-    B, T, cin, cout = 6, 501, 256, 512
-    ld = int(L.vasr_padded_frames(T))
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, cin, ld, generator=g) * torch.logspace(-3, 2, B).view(B, 1, 1)
-    x[:, :, T:] = 0.0
-    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).contiguous()
-    sc, sh = (0.5 + torch.rand(cout, generator=g)).to(gpu), torch.randn(cout, generator=g).to(gpu)
-    pk = torch.empty(cout * cin * 2, dtype=torch.int16)
-    inv = C.c_float()
-    _lib.check(L.vasr_pack_pointwise_f16x2(w.data_ptr(), cout, cin, cout, pk.data_ptr(), C.byref(inv)), L)
-    amax = x.abs().amax(dim=(1, 2)).numpy()
-    e = np.clip((amax.view(np.uint32) >> 23).astype(np.int64), 16, 254)            # vasr_device.h f16_scale
-    scale, xinv = (np.uint32((268 - e) << 23)).view(np.float32), (np.uint32((e - 14) << 23)).view(np.float32)
-    p4 = torch.empty(B, cin, ld // 4, 8, dtype=torch.int16)
-    for b in range(B):
-        _lib.check(L.vasr_pack_p4(x[b].contiguous().data_ptr(), cin, ld, float(scale[b]), p4[b].data_ptr()), L)
-    # the host restatement of the layout, checked against numpy on one row: group g of channel c = [hi4 | lo4], swapped if c & 2
-    xs = (x[1, 6, :8].numpy() * scale[1]).astype(np.float32)
-    hi = xs.astype(np.float16)
-    lo = (xs - hi.astype(np.float32)).astype(np.float16)
-    assert p4[1, 6, 0].numpy().view(np.float16).tolist() == lo[:4].tolist() + hi[:4].tolist()     # channel 6: c & 2 -> swapped
-    assert p4[1, 5, 1].numpy().view(np.float16).tolist()[:4] == (x[1, 5, 4:8].numpy() * scale[1]).astype(np.float16).tolist()
-    xd, p4d, w16 = x.to(gpu), p4.to(gpu), pk.to(gpu)
-    xinvd = torch.from_numpy(xinv.copy()).to(gpu)
-    stride = 1024
-    am = torch.zeros(2, B, stride, dtype=torch.int32, device=gpu)
-    amy = torch.zeros(B, stride, dtype=torch.int32, device=gpu)
-    y0, y1 = torch.empty(B, cout, ld, device=gpu), torch.full((B, cout, ld), -7.0, device=gpu)
-    st = torch.cuda.current_stream().cuda_stream
-    _lib.check(L.vasr_bench_pointwise_f16x2(xd.data_ptr(), w16.data_ptr(), inv.value, sc.data_ptr(), sh.data_ptr(), B, cin, cout,
-                                            T, y0.data_ptr(), am.data_ptr(), stride, st), L)
-    _lib.check(L.vasr_bench_pointwise_p4(p4d.data_ptr(), xinvd.data_ptr(), w16.data_ptr(), inv.value, sc.data_ptr(),
-                                         sh.data_ptr(), B, cin, cout, T, y1.data_ptr(), amy.data_ptr(), stride, st), L)
-    torch.cuda.synchronize()
-    assert torch.equal(y0, y1)
-    assert torch.equal(am[1].max(dim=1).values, amy.max(dim=1).values)
-    ref = torch.relu(torch.einsum("mk,bkt->bmt", w.double(), x.double()) * sc.cpu().double().view(1, -1, 1) + sh.cpu().double().view(1, -1, 1))
-    rel = ((y1.cpu().double() - ref).abs().amax(dim=(1, 2)) / ref.abs().amax(dim=(1, 2))).max().item()
-    _record("presplit_gemm", rel_vs_fp64=rel)
-    assert rel < 2e-6

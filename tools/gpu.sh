@@ -219,15 +219,6 @@ PY
 done
 }
 
-# ---- p4: 
-task_p4() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-export VASR_BENCH_KEEP_AMAX=1
-for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_*.so; do
-  export VASR_LIB_PATH=$f; echo "== $(basename $f)"; timeout 300 python tools/probes/p4_gemm_probe.py 2>&1 | grep -v amdgpu | tail -2
-done
-}
-
 # ---- phase: phase-shift experiment: 256 x 128 tiles on four wavefronts (two workgroups per CU), second arrival delayed
 task_phase() {
 # phase-shift experiment: 256 x 128 tiles on four wavefronts (two workgroups per CU), second arrival delayed
@@ -549,6 +540,37 @@ echo "== depthwise alone"; python tools/bench_dw.py 51 63 75 2>&1 | grep -v amdg
 echo "== normalisers"; python tools/mfma_sustained.py 2>&1 | grep -v amdgpu; python tools/copy_bw.py 2>&1 | grep -v amdgpu
 } > $O/probe.txt 2>&1
 cat $O/coissue.txt $O/probe.txt
+}
+
+# ---- r5b: round 5, call B: the four-wavefront beam search (beam_group.hip): device-vs-oracle tests, fuzz, A/B against the one-wavefront
+#      kernel, latencies at the reference's serving shape for VASR_BEAM_GROUP = 0 / 2 / 4; the band-limited goldens and the flip tests
+#      (new bounds); the fused-512 probe again WITHOUT the bench entry's maxima pre-pass (kernel-only times)
+task_r5b() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5b}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_beam.py -x -q -m gpu > $O/pytest_beam.log 2>&1; tail -5 $O/pytest_beam.log
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+for g in 0 2 4; do
+  echo "== VASR_BEAM_GROUP=$g: beam_lat (B = 1)"; VASR_BEAM_GROUP=$g BATCHES=1 python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
+  echo "== VASR_BEAM_GROUP=$g: serving shape"; VASR_BEAM_GROUP=$g python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -3
+done > $O/beam_lat.txt 2>&1
+unset VASR_LIB_PATH
+cat $O/beam_lat.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "band_limited or goldens" > $O/pytest_band.log 2>&1; tail -5 $O/pytest_band.log
+timeout 900 python -m pytest tests/test_gpu_flips.py -x -q -m gpu > $O/pytest_flips.log 2>&1; tail -5 $O/pytest_flips.log
+{
+export VASR_BENCH_KEEP_AMAX=1
+echo "== kernel-only times (VASR_BENCH_KEEP_AMAX=1: no maxima pre-pass in the bench entry)"
+echo "== default library, tile rule (512 x 128)"; python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+echo "== default library, 512 x 64 tile (VASR_PW3_TILE=8)"; VASR_PW3_TILE=8 python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+for f in $R/viet-asr_amd/lib/var_x*.so; do
+  echo "== $(basename $f), 512 x 64 tile"; VASR_LIB_PATH=$f VASR_PW3_TILE=8 python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+done
+echo "== x0_ns (no activation staging), 512 x 128 tile"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_x0_ns.so python tools/bench_pw.py 512 512 2>&1 | grep -v amdgpu
+echo "== depthwise alone"; python tools/bench_dw.py 51 63 75 2>&1 | grep -v amdgpu
+unset VASR_BENCH_KEEP_AMAX
+} > $O/probe_kernel_only.txt 2>&1
+cat $O/probe_kernel_only.txt
+cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
 }
 
 task=${1:-list}; shift || true

@@ -88,9 +88,6 @@ DEV_SIGNATURES = {
     "vasr_pack_pointwise_f16x2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
     "vasr_bench_pointwise_f16x2": (C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P,
                                              C.c_int, _P]),
-    "vasr_pack_p4": (C.c_int, [_P, C.c_int, C.c_int64, C.c_float, _P]),
-    "vasr_bench_pointwise_p4": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P,
-                                          C.c_int, _P]),
     "vasr_depthwise_mfma_table_size": (C.c_int, [C.c_int, C.c_int]),
     "vasr_pack_depthwise_taps": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "vasr_bench_depthwise_mfma": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, _P]),

@@ -287,13 +287,14 @@ class BeamSearchDecoderWithLM(NonTrainableNM):
         return {"predictions": NeuralType(("B", "T"), PredictionsType())}
 
     def __init__(self, lm_path, vocab, beam_width, alpha, beta, num_cpus=1, cutoff_prob=1.0, cutoff_top_n=40,
-                 input_tensor=True):
+                 input_tensor=True, allow_missing_lm=False):
         super().__init__()
         if self._factory is not None and self._factory.world_size > 1:
             raise ValueError("BeamSearchDecoderWithLM does not run in distributed mode")   # :79-80
         from .beam import BeamSearchDecoder
         self.vocab, self.beam_width = list(vocab), beam_width
-        self.decoder = BeamSearchDecoder(self.vocab, lm_path=lm_path, alpha=alpha, beta=beta)
+        # an lm_path that cannot be read (KenLM binaries, a missing file) raises unless allow_missing_lm (beam.LM_HELP)
+        self.decoder = BeamSearchDecoder(self.vocab, lm_path=lm_path, alpha=alpha, beta=beta, allow_missing_lm=allow_missing_lm)
         self.num_cpus, self.cutoff_prob, self.cutoff_top_n, self.input_tensor = num_cpus, cutoff_prob, cutoff_top_n, \
             input_tensor
 

@@ -1,4 +1,4 @@
-"""Host side of the device prefix beam search (csrc/beam.hip): n-gram tables, launch, id -> text.
+"""Host side of the device prefix beam search (csrc/beam_wave.hip, csrc/beam_group.hip): n-gram tables, launch, id -> text.
 
 Counterpart of what ``BeamSearchDecoderWithLM.__init__`` builds with ``pyctcdecode.build_ctcdecoder(vocab,
 kenlm_model_path, alpha, beta)`` (nemo/collections/asr/beam_search_decoder.py:82-87).  The language model is
@@ -179,18 +179,28 @@ def lm_file_usable(path):
     return True, ""
 
 
+LM_HELP = ("this library reads n-gram models as ARPA text only.  The reference's default `models/language_model/3-gram-lm.binary` "
+           "(infer.py:184, app.py:20) is a KenLM binary, a third-party layout that cannot be turned back into ARPA: keep (or "
+           "rebuild) the ARPA file it was compiled from -- `lmplz -o 3 < corpus.txt > 3-gram-lm.arpa` -- and pass that path.  "
+           "Pass allow_missing_lm=True to search without a language model instead.")
+
+
 class BeamSearchDecoder:
-    def __init__(self, labels, lm_path=None, alpha=0.5, beta=1.5, token_min_logp=-5.0, beam_prune_logp=-10.0):
+    def __init__(self, labels, lm_path=None, alpha=0.5, beta=1.5, token_min_logp=-5.0, beam_prune_logp=-10.0,
+                 allow_missing_lm=False):
         self.labels = list(labels)
         if len(self.labels) + 1 > 128:
             raise NotImplementedError("beam search supports at most 127 labels + blank")
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
         self.token_min_logp, self.beam_prune_logp = token_min_logp, beam_prune_logp
-        # An LM that cannot be used is decided HERE, not at the first decode: the reference checks at construction and
-        # falls back to searching without a language model (infer.py:117-128, kenlm import failure -> lm_path = None).
+        # An LM that cannot be used is decided HERE, not at the first decode, and it is an ERROR (round 5): a drop-in user
+        # with the reference's shipped paths must not silently lose the language model.  allow_missing_lm=True restores the
+        # reference's own fall-back (infer.py:117-128: kenlm not importable -> lm_path = None, search without an LM).
         if lm_path:
             ok, why = lm_file_usable(lm_path)
             if not ok:
+                if not allow_missing_lm:
+                    raise ValueError(f"language model {lm_path!r} not usable ({why}); {LM_HELP}")
                 import warnings
                 warnings.warn(f"language model {lm_path!r} not usable ({why}); beam search runs without a language model")
                 lm_path = None

@@ -1,5 +1,5 @@
-// Device-side pieces shared by the beam-search kernels (beam_wave.hip: one wavefront per utterance, the product kernel;
-// beam.hip: one 512-thread workgroup per utterance, rounds 1-3, kept in the devtools build for A/B runs): hashing,
+// Device-side pieces shared by the beam-search kernels (beam_wave.hip: one wavefront per utterance, batches;
+// beam_group.hip: an utterance on four wavefronts of a compute unit, the serving latency): hashing,
 // order-preserving score bits, the hashed back-off n-gram model (KenLM BaseScore semantics, pyctcdecode's LanguageModel.score
 // on top), log(r >= 1) in fp64 without the library call, and wavefront-wide scans / reductions on the DPP data path.
 #pragma once

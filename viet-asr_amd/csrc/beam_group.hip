@@ -1,0 +1,758 @@
+// CTC prefix beam search with optional back-off n-gram LM: ONE UTTERANCE ON W WAVEFRONTS OF ONE COMPUTE UNIT (gfx950) --
+// the latency form of beam_wave.hip, for the shape the reference SERVES: batch 1, beam width 50 (app.py:27) or 100
+// (infer.py:191) + LM, reference nemo/collections/asr/beam_search_decoder.py:95-102 (pyctcdecode on the host, one utterance
+// at a time; third-party, parity unpinned: the algorithm restated is oracle/beam_oracle.py).
+//
+// beam_wave.hip gives an utterance to one wavefront: right for a batch (four utterances per compute unit, the rest of the
+// chip free for the next acoustic pass), but a lone utterance then runs on one SIMD of one CU out of 256, issuing a
+// dependent instruction stream at ~10 cycles per instruction (profiles/r04_beam_sq_counters.txt): 4.3 ms at beam 100 on
+// 331 frames, 91-95 % of the serving latency.  Here the SAME algorithm -- same keys, same merge arithmetic (ordered-int
+// max, 2^-44 fixed-point sums: associative, hence independent of who adds first), same prune / radix select / rank rules,
+// hence the same bits (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree) -- is dealt over W = 4 (or 2)
+// wavefronts, one per SIMD:
+//
+//   * (beam, character) pair p lives in wavefront (p >> 6) % W, lane p & 63: a lane carries ceil(pairs / 64 W) pairs (1-2
+//     instead of 5-6) through expand / score / select; beams (LM refresh, children) are dealt one per THREAD;
+//   * the merge table, the beams and the radix histogram are shared in LDS (LDS atomics work across the wavefronts of a
+//     workgroup); what one wavefront needs from the others crosses in small mailboxes at LDS-only barriers:
+//       B1 after the claims (all pairs sit in the table; merged slots know their contributors' maximum)
+//       B3 after the contributors' fixed-point adds            -- only on frames where two pairs merged
+//       B4 the best combined score (prune threshold)
+//       B5 live entries + differing key bits                   -- only when more entries than beam_width were claimed
+//       R  one per radix digit of the select (histogram buffers rotate: no clearing barrier)
+//       B6 per-block (greater, equal) counts -> every wavefront computes every rank offset itself
+//       Z  end of frame (children complete)
+//     5-7 barriers of 4 wavefronts per general frame against ~20 of 8 in the workgroup kernel of rounds 1-3;
+//   * a claimer leaves its score in the slot (tsc) so that a contributor can form max(contributors, claimer) itself: the
+//     single-wavefront kernel's "claimer raises the maximum" step and its barrier are gone, the sums are the same integers;
+//   * selected pairs of a frame's LAST pass build their children straight from the registers of the lane that owns them
+//     (no survivor records through LDS); frames of a blank run touch one beam per thread and skip every barrier;
+//   * log-probs and the candidate list are per-wavefront copies (each wavefront stages its own batch of eight frames): no
+//     barrier for either;
+//   * the final pass (commit pending words, merge identical texts, trace-back) is wavefront 0 alone, as in beam_wave.hip.
+//
+// Workgroup = 64 W threads = one utterance; LDS ~52 KB (W = 4).  Used for batches of < 16 utterances (vasr_api.cpp).
+#include <cstdlib>
+#include <type_traits>
+
+#include "beam_common.h"
+
+namespace vasr {
+
+namespace {
+using namespace beam_detail;
+
+constexpr int kTab = 512;                 // merge-table slots (as beam_wave.hip: the pass structure decides tie order)
+constexpr int kFill = kTab * 7 / 10;
+constexpr int kTbRows = 12;
+constexpr int kLpFrames = 8;
+constexpr int kLpRegs = kLpFrames * kMaxClasses / 64;
+constexpr int kChars = 3072;
+constexpr int kMaxBlocks = 10;            // block indices W j + w of a pass (W PPL <= 8) + 2 blocks of carried survivors
+
+template <int W>
+struct GroupLds {
+  unsigned long long key[2][kMaxBeams];
+  unsigned long long whash[2][kMaxBeams];
+  double logit[2][kMaxBeams];
+  float lm_text[2][kMaxBeams];
+  unsigned int meta[2][kMaxBeams];
+  int ctx[2][kMaxBeams][kMaxCtx];
+  float commit_lmd[2][kMaxBeams];
+  int commit_wid[2][kMaxBeams];
+  unsigned long long tkey[kTab];
+  long long tmx[kTab];                     // ordered bits of the CONTRIBUTORS' maximum (-1e300: none)
+  unsigned long long tsum[kTab];
+  double tsc[kTab];                        // the claimer's score
+  int tsrc[kTab];
+  long long sel_lgt[kMaxBeams], sel_tot[kMaxBeams];
+  int sel_src[kMaxBeams];
+  double fin[kMaxBeams];
+  unsigned long long cmix[kMaxClasses];
+  float lpq[W][kLpFrames * kMaxClasses];   // per wavefront
+  unsigned char cand[W][kMaxClasses];      // per wavefront
+  int hist[3][256];
+  // mailboxes
+  long long mb_best[W];
+  int mb_claimed[W];
+  int mb_live[W];
+  unsigned long long mb_diff[W];
+  int mb_gt[kMaxBlocks], mb_eq[kMaxBlocks];
+  int merge_epoch, anychar_epoch;
+  int n_log;
+};
+static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
+static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
+static_assert(sizeof(GroupLds<4>) <= 64 * 1024, "fits the default dynamic LDS limit");
+
+constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25;
+__device__ inline int meta_last(unsigned m) { return (int)(m & 0xffu) - 1; }
+__device__ inline int meta_wlen(unsigned m) { return (int)((m >> 8) & 0xffffu); }
+__device__ inline unsigned make_meta(int last, int wlen, unsigned flags) {
+  return (unsigned)(last + 1) | ((unsigned)min(wlen, 0xffff) << 8) | flags;
+}
+
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// LDS-only workgroup barrier: __syncthreads() would also drain the vector-memory counter, i.e. wait for the back-pointer
+// stores and the prefetched log-probs at every phase boundary
+__device__ inline void group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ inline int rank_in(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// grid (B), block 64 W: workgroup g searches utterance g
+template <int W>
+__global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restrict__ logp, int batch, int frames_ld,
+                                                             const int32_t* __restrict__ row_frames, int V1, int space_id,
+                                                             int beam_width, float token_min_logp, float beam_prune_logp,
+                                                             LmView lm, int use_lm, unsigned int* __restrict__ bp_all,
+                                                             unsigned long long* __restrict__ eoslog_all,
+                                                             int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
+                                                             float* __restrict__ out_score) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Lds = GroupLds<W>;
+  Lds& S = *reinterpret_cast<Lds*>(smem);
+  const int tid = (int)threadIdx.x, lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = (int)blockIdx.x;
+  const int V = V1 - 1;
+  const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
+  const float* lrow = logp + (int64_t)b * frames_ld * V1;
+  unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
+  unsigned long long* eoslog = eoslog_all + (int64_t)b * frames_ld * kMaxBeams;
+
+  for (int i = tid; i < kTab; i += 64 * W) { S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0; }
+  for (int c = tid; c < kMaxClasses; c += 64 * W) S.cmix[c] = hmix(hmix(kFnvOffset, (unsigned long long)(c + 7)), 0x9e3779b9ull);
+  for (int i = tid; i < 3 * 256; i += 64 * W) (&S.hist[0][0])[i] = 0;
+  if (tid == 0) {
+    S.key[0][0] = kFnvOffset; S.whash[0][0] = kFnvOffset; S.logit[0][0] = 0.0; S.lm_text[0][0] = 0.f;
+    S.meta[0][0] = make_meta(-1, 0, 0);
+    for (int i = 0; i < kMaxCtx; ++i) S.ctx[0][0][i] = -1;
+    if (use_lm) S.ctx[0][0][kMaxCtx - 1] = lm.bos;
+    S.commit_lmd[0][0] = 0.f; S.commit_wid[0][0] = 0;
+    S.merge_epoch = -1; S.anychar_epoch = -1; S.n_log = 0;
+  }
+  group_sync();
+  int cur = 0, nb = 1, epoch = 0;
+  int hd = 0;                  // radix digits histogrammed so far: digit hd uses hist[hd % 3] (uniform)
+  bool all_blank = false;      // every live beam ends in blank (uniform)
+  bool dirty = false;          // frames of a blank run have updated beams without a barrier (uniform)
+
+  // log-probs: every wavefront stages its own copy of the batch of kLpFrames frames (beam_wave.hip says why they come
+  // through LDS and why the loads are unconditional)
+  float q[kLpRegs];
+  const int lp_batch = kLpFrames * V1;
+  auto lp_request = [&](int t0) __attribute__((always_inline)) {
+    const int n = min(lp_batch, (frames - t0) * V1);
+    if (n <= 0) return;
+    const float* src = lrow + (int64_t)t0 * V1;
+#pragma unroll
+    for (int k = 0; k < kLpRegs; ++k) q[k] = src[min(64 * k + lane, n - 1)];
+  };
+  lp_request(0);
+  float* lpq = S.lpq[wv];
+  unsigned char* cand = S.cand[wv];
+
+  // One new beam at rank r from pair (parent bi, character c) with merged logit bits lgt
+  auto build_child = [&](int t, int r, int src, long long lgt, bool has_space) __attribute__((always_inline)) {
+    const int nxt = cur ^ 1;
+    const int bi = src >> 8, c = src & 255;
+    const unsigned m = S.meta[cur][bi];
+    const int last = meta_last(m), wlen = meta_wlen(m);
+    const bool stay = (c == V || c == last);
+    unsigned long long key = S.key[cur][bi], whash = S.whash[cur][bi];
+    float lm_text = S.lm_text[cur][bi];
+    const int4 ctx_p = *reinterpret_cast<const int4*>(&S.ctx[cur][bi][0]);
+    int4 ctx_n = ctx_p;
+    const float p_lmd = S.commit_lmd[cur][bi];
+    const int p_wid = S.commit_wid[cur][bi];
+    int wlen_new = wlen;
+    unsigned int appended = 0;
+    unsigned flags = 0;
+    if (stay) {
+      if ((m & kMetaCached) || (has_space && wlen > 0)) flags |= kMetaCached;
+      flags |= m & kMetaCommit;
+    } else if (c == space_id) {
+      if (wlen > 0) {
+        key = hmix(key, (unsigned long long)c);
+        appended = c + 1;
+        if (use_lm) {
+          lm_text += p_lmd;
+          ctx_n = make_int4(ctx_p.y, ctx_p.z, ctx_p.w, p_wid);
+        }
+        wlen_new = 0; whash = kFnvOffset;
+      }
+    } else {
+      key = hmix(key, (unsigned long long)c);
+      whash = hmix(whash, (unsigned long long)c);
+      wlen_new = wlen + 1;
+      appended = c + 1;
+    }
+    if (c != V) S.anychar_epoch = t;                 // (every writer stores the same value)
+    S.key[nxt][r] = key; S.whash[nxt][r] = whash;
+    S.logit[nxt][r] = __longlong_as_double(lgt);
+    S.lm_text[nxt][r] = lm_text;
+    S.meta[nxt][r] = make_meta(c, wlen_new, flags);
+    *reinterpret_cast<int4*>(&S.ctx[nxt][r][0]) = ctx_n;
+    S.commit_lmd[nxt][r] = p_lmd;
+    S.commit_wid[nxt][r] = p_wid;
+    bp[(int64_t)t * kMaxBeams + r] = ((unsigned)bi << 8) | appended;
+  };
+
+  for (int t = 0; t < frames; ++t) {
+    // ---- 1. candidate characters (every wavefront for itself: same values everywhere) ----
+    const int c0 = lane, c1 = lane + 64;
+    if ((t & (kLpFrames - 1)) == 0) {
+#pragma unroll
+      for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) lpq[64 * k + lane] = q[k];
+      lp_request(t + kLpFrames);
+      wave_sync();
+    }
+    const float* lq = lpq + (t & (kLpFrames - 1)) * V1;
+    const float v0 = c0 < V1 ? fminf(fmaxf(lq[c0], -34.538776f), 0.f) : 0.f, v1 = c1 < V1 ? fminf(fmaxf(lq[c1], -34.538776f), 0.f) : 0.f;
+    auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
+    const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+    const unsigned kmax = wave_max_u32(max(key0, key1));
+    const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+    const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
+    const bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
+    const bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    if (k0) cand[rank_in(m0)] = (unsigned char)c0;
+    if (k1) cand[__popcll(m0) + rank_in(m1)] = (unsigned char)c1;
+    const int nc_all = __popcll(m0) + __popcll(m1);
+    const bool has_space = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
+    const bool only_blank = nc_all == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
+    wave_sync();
+
+    // a blank-only frame met by beams that all end in blank: one beam per thread, nothing crosses wavefronts
+    if (only_blank && all_blank) {
+      const double add = (double)fminf(lq[V], 0.f);
+      for (int i = tid; i < nb; i += 64 * W) {
+        S.logit[cur][i] += add;
+        bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
+      }
+      dirty = true;
+      continue;
+    }
+    if (dirty) { group_sync(); dirty = false; }
+
+    // ---- 2. ' ' is a candidate: LM cache log + commit scores, one beam per thread ----
+    if (use_lm && has_space) {
+      for (int i0 = 0; i0 < nb; i0 += 64 * W) {
+        const int i = i0 + tid;
+        bool put = false;
+        unsigned long long h = 0;
+        if (i < nb) {
+          const unsigned m = S.meta[cur][i];
+          if (meta_wlen(m) > 0) {
+            put = !(m & kMetaCached);
+            h = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+            if (!(m & kMetaCommit)) {
+              int ctx[kMaxCtx];
+#pragma unroll
+              for (int qq = 0; qq < kMaxCtx; ++qq) ctx[qq] = S.ctx[cur][i][qq];
+              int w;
+              S.commit_lmd[cur][i] = lm_word_score(lm, ctx, S.whash[cur][i], false, &w);
+              S.commit_wid[cur][i] = w;
+              S.meta[cur][i] = m | kMetaCommit;
+            }
+          }
+        }
+        const unsigned long long pm = __ballot(put);
+        if (pm) {                                    // the log is a SET of keys: its order does not matter
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&S.n_log, __popcll(pm));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (put) eoslog[base + rank_in(pm)] = h;
+        }
+      }
+      // (the commit scores are read after barrier B1)
+    }
+
+    const int cap = max(1, (int)(((float)kFill + 0.5f) * __builtin_amdgcn_rcpf((float)nb)));
+    // survivors carried from the earlier passes of this frame (wavefront 0 only): ranks lane and lane + 64
+    long long c_tot[2] = {ord64(-1e300), ord64(-1e300)}, c_lgt[2] = {0, 0};
+    int c_src[2] = {0, 0};
+    int n_sel = 0;
+
+    auto pass = [&](auto ppl_tag, int c_lo, int nc, bool last_pass) __attribute__((always_inline)) {
+      constexpr int PPL = decltype(ppl_tag)::value;
+      const int npairs = nb * nc;
+      const float inv_nc = __builtin_amdgcn_rcpf((float)nc);
+      ++epoch;
+      int slot[PPL], src[PPL];
+      double score[PPL];
+      unsigned claimed = 0, act = 0;
+      unsigned long long kk[PPL];
+      int stride[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int p = 64 * (W * j + wv) + lane;
+        if (p < npairs) act |= 1u << j;
+        const int pp = min(p, npairs - 1);
+        const int bi = (int)(((float)pp + 0.5f) * inv_nc);
+        const int c = cand[c_lo + pp - bi * nc];
+        const unsigned m = S.meta[cur][bi];
+        const int last = meta_last(m);
+        unsigned long long key = S.key[cur][bi];
+        score[j] = S.logit[cur][bi] + (double)fminf(lq[c], 0.f);
+        src[j] = (bi << 8) | c;
+        const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
+        const unsigned long long kx = hmix(key, (unsigned long long)c);
+        key = grows ? kx : key;
+        const unsigned long long k = (key ^ S.cmix[c]) | 1ull;
+        kk[j] = k;
+        slot[j] = (int)((k >> 17) & (kTab - 1));
+        stride[j] = (int)((k >> 40) & (kTab - 1)) | 1;
+      }
+      unsigned long long seen[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) seen[j] = S.tkey[slot[j]];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+        if ((act >> j & 1) && seen[j] == 0ull) {
+          seen[j] = atomicCAS(&S.tkey[slot[j]], 0ull, kk[j]);
+          if (seen[j] == 0ull) { claimed |= 1u << j; seen[j] = kk[j]; }
+        }
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        if (act >> j & 1) {
+          int i = slot[j];
+          const unsigned long long k = kk[j];
+          if (seen[j] != k) {
+            while (true) {
+              i = (i + stride[j]) & (kTab - 1);
+              const unsigned long long e = S.tkey[i];
+              if (e == k) break;
+              if (e == 0) {
+                const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
+                if (old == 0ull) { claimed |= 1u << j; break; }
+                if (old == k) break;
+              }
+            }
+          }
+          if (claimed >> j & 1) S.tsc[i] = score[j];                   // the claimer's score stays with the slot
+          else atomicMax(&S.tmx[i], ord64(score[j]));                  // a contributor: the contributors' maximum
+          slot[j] = i;
+        }
+      }
+      if (__ballot((act & ~claimed) != 0u) != 0ull && lane == 0) S.merge_epoch = epoch;
+      {
+        int n_cl = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) n_cl += __popcll(__ballot(claimed >> j & 1));
+        if (lane == 0) S.mb_claimed[wv] = n_cl;
+      }
+      group_sync();                                                     // ---- B1
+      const bool any_merge = S.merge_epoch == epoch;                    // uniform over the workgroup
+      if (any_merge) {
+        // a contributor adds exp(score - max(contributors, claimer)) as a 2^-44 fixed-point integer
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          if ((act & ~claimed) >> j & 1) {
+            const long long mx = max(S.tmx[slot[j]], ord64(S.tsc[slot[j]]));
+            const float e = __builtin_amdgcn_exp2f((float)((score[j] - unord64(mx)) * 1.4426950408889634));
+            atomicAdd(&S.tsum[slot[j]], (unsigned long long)((double)e * kFix));
+          }
+        }
+        group_sync();                                                   // ---- B3
+      }
+      // ---- 3. merged prefixes, each in the lane that claimed its slot ----
+      long long tot[PPL], lgt[PPL];
+      long long my_best = max(c_tot[0], c_tot[1]);
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const bool mine = claimed >> j & 1;
+        const int i = slot[j], bi = src[j] >> 8, c = src[j] & 255;
+        float lmt = 0.f;
+        if (use_lm) {
+          const unsigned m = S.meta[cur][bi];
+          const int last = meta_last(m), wlen = meta_wlen(m);
+          const bool stay = (c == V || c == last);
+          const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
+          const float commit = S.commit_lmd[cur][bi];
+          lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new) + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
+        }
+        double logit = score[j];
+        if (mine) {
+          S.tkey[i] = 0;
+          if (any_merge) {
+            const long long mo = S.tmx[i];
+            if (mo != ord64(-1e300)) {
+              const double m = unord64(max(mo, ord64(score[j])));
+              const float e = __builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634));
+              const unsigned long long s8 = S.tsum[i] + (unsigned long long)((double)e * kFix);
+              S.tmx[i] = ord64(-1e300); S.tsum[i] = 0;
+              logit = m + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
+            }
+          }
+        }
+        tot[j] = mine ? ord64(logit + (double)lmt) : ord64(-1e300);
+        lgt[j] = __double_as_longlong(logit);
+        my_best = max(my_best, tot[j]);
+      }
+      {
+        const long long wb = wave_max_i64(my_best);
+        if (lane == 0) S.mb_best[wv] = wb;
+      }
+      group_sync();                                                     // ---- B4
+      long long best = S.mb_best[0];
+      int n_claimed_all = S.mb_claimed[0] + n_sel;                      // + the carried survivors
+#pragma unroll
+      for (int k = 1; k < W; ++k) { best = max(best, S.mb_best[k]); n_claimed_all += S.mb_claimed[k]; }
+      // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
+      const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
+      const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
+      unsigned live = 0;
+      int my_live = 0;
+      unsigned long long diff = 0;
+#pragma unroll
+      for (int j = 0; j < PPL + 2; ++j) {
+        const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
+        const bool lv = j < PPL ? ((claimed >> j & 1) && tt >= thr_prune) : (wv == 0 && lane + 64 * (j - PPL) < n_sel && tt >= thr_prune);
+        if (lv) { live |= 1u << j; diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest; }
+        my_live += __popcll(__ballot(lv));
+      }
+      unsigned long long prefix = 0, mask = 0;
+      int want = beam_width;
+      if (n_claimed_all > beam_width) {                                 // (uniform over the workgroup) only then can a select be needed
+        diff = ((unsigned long long)wave_or_u32((unsigned)(diff >> 32)) << 32) | wave_or_u32((unsigned)diff);
+        if (lane == 0) { S.mb_live[wv] = my_live; S.mb_diff[wv] = diff; }
+        group_sync();                                                   // ---- B5
+        int tot_live = 0;
+        diff = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) { tot_live += S.mb_live[k]; diff |= S.mb_diff[k]; }
+        if (tot_live > beam_width) {
+          const int same = diff ? __clzll((long long)diff) / 8 : 8;
+          if (same > 0) { mask = same == 8 ? ~0ull : (~0ull << (64 - 8 * same)); prefix = ubest & mask; }
+          // Histogram buffers rotate with a running digit count: digit hd adds into hist[hd % 3] -- cleared during digit
+          // hd - 1 (or at the start) -- and clears hist[(hd + 1) % 3], last READ during digit hd - 2, which every wavefront
+          // has left behind when it passed the barrier of digit hd - 1.  No clearing barrier.
+#pragma unroll 1
+          for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
+            int* h = S.hist[hd % 3];
+            int* hn = S.hist[(hd + 1) % 3];
+            ++hd;
+#pragma unroll
+            for (int j = 0; j < PPL + 2; ++j) {
+              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+              if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&h[(int)((u >> shift) & 255)], 1);
+            }
+            for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;          // the next digit's buffer (last read two digits ago)
+            group_sync();                                               // ---- R
+            int cnt[4], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cnt[j] = h[255 - (4 * lane + j)]; mine += cnt[j]; }
+            int above = wave_scan_incl(mine) - mine;
+            int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+              above += cnt[j];
+            }
+            const unsigned long long fm = __ballot(f_bucket >= 0);
+            const int fl = __ffsll((long long)fm) - 1;
+            const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+            want = __builtin_amdgcn_readlane(f_want, fl);
+            const int whole = __builtin_amdgcn_readlane(f_whole, fl);
+            prefix |= (unsigned long long)bucket << shift;
+            mask |= 0xFFull << shift;
+            if (whole) break;
+          }
+        }
+      }
+      // ---- selected: live and key > threshold prefix, plus the first `want` equal to it in PAIR ORDER (block = 64 pairs:
+      //      index W j + w; the carried survivors follow as blocks W PPL and W PPL + 1).  Every wavefront publishes its
+      //      blocks' (greater, equal) counts; after B6 each computes every block's offset itself ----
+      bool gt[PPL + 2], eq[PPL + 2];
+#pragma unroll
+      for (int j = 0; j < PPL + 2; ++j) {
+        const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
+        gt[j] = false; eq[j] = false;
+        if (live >> j & 1) {
+          const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
+          if (mask == 0 || u > prefix) gt[j] = true; else if (u == prefix) eq[j] = true;
+        }
+        const int ng = __popcll(__ballot(gt[j])), ne = __popcll(__ballot(eq[j]));
+        if (lane == 0) {
+          if (j < PPL) { S.mb_gt[W * j + wv] = ng; S.mb_eq[W * j + wv] = ne; }
+          else if (wv == 0) { S.mb_gt[W * PPL + (j - PPL)] = ng; S.mb_eq[W * PPL + (j - PPL)] = ne; }
+        }
+      }
+      group_sync();                                                     // ---- B6
+      int n_out = 0, eq_seen = 0;
+      int off_out[PPL + 2], off_eq[PPL + 2];
+#pragma unroll
+      for (int blk = 0; blk < W * PPL + 2; ++blk) {
+        const int ng = S.mb_gt[blk], ne = S.mb_eq[blk];
+        const int j = blk < W * PPL ? blk / W : PPL + (blk - W * PPL);
+        const bool own = blk < W * PPL ? (blk % W == wv) : (wv == 0);
+        if (own) { off_out[j] = n_out; off_eq[j] = eq_seen; }
+        n_out += ng + min(ne, max(0, want - eq_seen));
+        eq_seen += ne;
+      }
+#pragma unroll
+      for (int j = 0; j < PPL + 2; ++j) {
+        if (j >= PPL && wv != 0) continue;
+        const unsigned long long em = __ballot(eq[j]);
+        const bool take = gt[j] || (eq[j] && off_eq[j] + rank_in(em) < want);
+        const unsigned long long tm = __ballot(take);
+        const int dst = off_out[j] + rank_in(tm);
+        if (take && dst < kMaxBeams) {
+          const int sr = j < PPL ? src[j] : c_src[j - PPL];
+          const long long lg = j < PPL ? lgt[j] : c_lgt[j - PPL];
+          if (last_pass) build_child(t, dst, sr, lg, has_space);
+          else { S.sel_src[dst] = sr; S.sel_lgt[dst] = lg; S.sel_tot[dst] = j < PPL ? tot[j] : c_tot[j - PPL]; }
+        }
+      }
+      n_sel = min(n_out, kMaxBeams);
+      if (!last_pass) {
+        group_sync();                                                   // ---- B7 (multi-pass frames only)
+        if (wv == 0) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int r = lane + 64 * j;
+            if (r < n_sel) { c_tot[j] = S.sel_tot[r]; c_lgt[j] = S.sel_lgt[r]; c_src[j] = S.sel_src[r]; }
+            else { c_tot[j] = ord64(-1e300); c_lgt[j] = 0; c_src[j] = 0; }
+          }
+        }
+        // (the records are rewritten after the next pass's B6 only: wavefront 0 has long read them by then)
+      }
+    };
+
+#pragma unroll 1
+    for (int c_lo = 0; c_lo < nc_all; c_lo += cap) {
+      const int nc = min(cap, nc_all - c_lo);
+      const bool last_pass = c_lo + cap >= nc_all;
+      const int npairs = nb * nc;
+      const int ppl = (npairs + 64 * W - 1) / (64 * W);
+      if constexpr (W >= 4) {
+        if (ppl <= 1) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
+        else pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
+      } else {
+        if (ppl <= 1) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
+        else if (ppl == 2) pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
+        else pass(std::integral_constant<int, 3>{}, c_lo, nc, last_pass);
+      }
+    }
+    group_sync();                                                       // ---- Z: the new beams are complete
+    all_blank = S.anychar_epoch != t;
+    nb = n_sel;
+    cur ^= 1;
+  }
+  // every wavefront's back-pointer and log stores have reached L2 before wavefront 0 reads them back
+  __syncthreads();
+  if (wv != 0) return;
+  const int n_log = S.n_log;
+
+  // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best (as beam_wave.hip) ----
+  int in_cache[2] = {0, 0};
+  if (use_lm) {
+    int myslot[2] = {-1, -1};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nb) {
+        const unsigned m = S.meta[cur][i];
+        if (meta_wlen(m) > 0) {
+          in_cache[j] = (m & kMetaCached) ? 1 : 0;
+          if (!in_cache[j] && n_log > 0) {
+            const unsigned long long k = hmix(S.key[cur][i], (unsigned long long)space_id) | 1ull;
+            int q2 = (int)((k >> 17) & (kTab - 1));
+            while (true) {
+              const unsigned long long old = atomicCAS(&S.tkey[q2], 0ull, k);
+              if (old == 0ull || old == k) break;
+              q2 = (q2 + 1) & (kTab - 1);
+            }
+            myslot[j] = q2;
+          }
+        }
+      }
+    }
+    for (int i = lane; i < kTab; i += 64) S.tsrc[i] = 0;
+    wave_sync();
+    for (int q2 = lane; q2 < n_log; q2 += 64) {
+      const unsigned long long k = __hip_atomic_load(&eoslog[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = (int)((k >> 17) & (kTab - 1));; i = (i + 1) & (kTab - 1)) {
+        const unsigned long long e = S.tkey[i];
+        if (e == k) { S.tsrc[i] = 1; break; }
+        if (e == 0) break;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) if (myslot[j] >= 0) in_cache[j] = S.tsrc[myslot[j]];
+    wave_sync();
+  }
+  double* fin = S.fin;
+  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(S.sel_lgt);
+  double* frank = reinterpret_cast<double*>(S.sel_tot);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nb) {
+      const unsigned m = S.meta[cur][i];
+      const int wlen = meta_wlen(m);
+      double total = S.logit[cur][i];
+      if (use_lm) {
+        float lmv = S.lm_text[cur][i];
+        if (wlen > 0) {
+          int ctx[kMaxCtx], wid;
+#pragma unroll
+          for (int q2 = 0; q2 < kMaxCtx; ++q2) ctx[q2] = S.ctx[cur][i][q2];
+          lmv += lm_word_score(lm, ctx, S.whash[cur][i], !in_cache[j], &wid);
+        }
+        total += (double)lmv;
+      }
+      fin[i] = total;
+      fkey[i] = wlen > 0 ? hmix(S.key[cur][i], (unsigned long long)space_id) : S.key[cur][i];
+      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen)) : 0.0);
+    }
+  }
+  wave_sync();
+  double my_score = -1e300;
+  int my_first = 0x7fffffff;
+#pragma unroll 1
+  for (int i = lane; i < nb; i += 64) {
+    const unsigned long long k = fkey[i];
+    bool first = true;
+    for (int j = 0; j < i; ++j) if (fkey[j] == k) { first = false; break; }
+    if (!first) continue;
+    double m = S.logit[cur][i];
+    int rep = i;
+    for (int j = i + 1; j < nb; ++j)
+      if (fkey[j] == k) { m = fmax(m, S.logit[cur][j]); if (frank[j] < frank[rep]) rep = j; }
+    double ssum = 0;
+    for (int j = i; j < nb; ++j) if (fkey[j] == k) ssum += exp(S.logit[cur][j] - m);
+    const double merged = (fin[rep] - S.logit[cur][rep]) + m + log(ssum);
+    if (merged > my_score) { my_score = merged; my_first = i; }
+  }
+  const long long sbest = wave_max_i64(ord64(my_score));
+  const unsigned long long wm = __ballot(ord64(my_score) == sbest);
+  int bi_best = 0x7fffffff;
+  for (unsigned long long q2 = wm; q2; q2 &= q2 - 1) bi_best = min(bi_best, __builtin_amdgcn_readlane(my_first, __ffsll((long long)q2) - 1));
+  const double bs = unord64(sbest);
+
+  // ---- trace back (as beam_wave.hip: rows through LDS kTbRows at a time, characters collected in LDS) ----
+  unsigned int* rows = reinterpret_cast<unsigned int*>(S.tkey);
+  unsigned short* chars = reinterpret_cast<unsigned short*>(&S.key[0][0]);
+  int32_t* out = out_ids + (int64_t)b * frames_ld;
+  const bool in_lds = frames <= kChars;
+  int n = 0, cur_b = bi_best;
+  bool lead = true;
+  constexpr int kRowRegs = kTbRows * kMaxBeams / 4 / 64;
+  uint4 rr[kRowRegs];
+  const int nbatch = (frames + kTbRows - 1) / kTbRows;
+  auto tb_request = [&](int j) __attribute__((always_inline)) {
+    const int t_hi = frames - 1 - j * kTbRows, t_lo = max(0, t_hi - kTbRows + 1), nq = (t_hi - t_lo + 1) * (kMaxBeams / 4);
+    const uint4* g = reinterpret_cast<const uint4*>(bp + (int64_t)t_lo * kMaxBeams);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) rr[k] = 64 * k + lane < nq ? g[64 * k + lane] : make_uint4(0, 0, 0, 0);
+  };
+  auto tb_land = [&](int j) __attribute__((always_inline)) {
+    uint4* dst = reinterpret_cast<uint4*>(rows + (j & 1) * kTbRows * kMaxBeams);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) dst[64 * k + lane] = rr[k];
+  };
+  if (nbatch > 0) { tb_request(0); tb_land(0); }
+  for (int j = 0; j < nbatch; ++j) {
+    if (j + 1 < nbatch) tb_request(j + 1);
+    wave_sync();
+    const int t_hi = frames - 1 - j * kTbRows, t_lo = max(0, t_hi - kTbRows + 1);
+    const unsigned int* rb = rows + (j & 1) * kTbRows * kMaxBeams;
+    for (int tt = t_hi - t_lo; tt >= 0; --tt) {
+      const unsigned int e = rb[tt * kMaxBeams + cur_b];
+      const unsigned int ch = e & 255;
+      if (ch) {
+        const int id = (int)ch - 1;
+        if (!(lead && id == space_id)) {
+          lead = false;
+          if (in_lds) chars[n] = (unsigned short)id;
+          else if (lane == 0) out[frames_ld - 1 - n] = id;
+          ++n;
+        }
+      }
+      cur_b = (int)(e >> 8);
+    }
+    if (j + 1 < nbatch) tb_land(j + 1);
+    wave_sync();
+  }
+  if (in_lds) {
+    for (int j = lane; j < n; j += 64) out[j] = (int)chars[n - 1 - j];
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int off = frames_ld - n;
+    if (off > 0) {
+      for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        int v = 0;
+        if (j < n) v = __hip_atomic_load(&out[off + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (j < n) out[j] = v;
+      }
+    }
+  }
+  if (lane == 0) {
+    out_len[b] = n;
+    out_score[b] = (float)bs;
+  }
+}
+
+template <int W>
+int launch_group(const float* logp, int batch, int frames, int V1, int space_id, int beam_width, float token_min_logp,
+                 float beam_prune_logp, const LmView& v, int use_lm, unsigned int* bp, unsigned long long* eoslog,
+                 int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st, const int32_t* row_frames) {
+  hipLaunchKernelGGL(beam_group_kernel<W>, dim3(batch), dim3(64 * W), sizeof(GroupLds<W>), st, logp, batch, frames, row_frames,
+                     V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len,
+                     out_score);
+  return 0;
+}
+
+}  // namespace
+
+// wavefronts an utterance of a batch gets: 4 below 16 utterances (a lone utterance, a small serving batch: latency), 1 from
+// there on (beam_wave.hip: four utterances per compute unit, the chip left to the next acoustic pass)
+int beam_group_width(int batch) {
+  static const int force = dev_env("VASR_BEAM_GROUP") ? atoi(dev_env("VASR_BEAM_GROUP")) : -1;   // 0 | 1: never, 2, 4 (dev: A/B runs)
+  if (force == 0 || force == 1) return 1;
+  if (force == 2 || force == 4) return force;
+  return batch < 16 ? 4 : 1;
+}
+
+int launch_beam_search_group(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+                             float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
+                             int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
+                             const int32_t* row_frames) {
+  const int W = beam_group_width(batch);
+  if (W == 1) return launch_beam_search_wave(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, lm,
+                                             bp, out_ids, out_len, out_score, st, row_frames);
+  unsigned long long* eoslog = reinterpret_cast<unsigned long long*>(bp + (size_t)batch * frames * kMaxBeams);
+  LmView v{};
+  int use_lm = 0;
+  if (lm) {
+    use_lm = 1;
+    v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
+    v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
+    v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
+    v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
+  }
+  if (W == 2) return launch_group<2>(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp,
+                                     eoslog, out_ids, out_len, out_score, st, row_frames);
+  return launch_group<4>(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog,
+                         out_ids, out_len, out_score, st, row_frames);
+}
+
+}  // namespace vasr

@@ -795,8 +795,8 @@ int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, in
   }
   const int upw = beam_wave_utts_per_workgroup(batch);
   const size_t lds = sizeof(WaveLds) * (size_t)upw;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_wave_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(WaveLds) * 4));
+  static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)
+  const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(beam_wave_kernel), (int)(sizeof(WaveLds) * 4), lds_opted);
   if (attr != hipSuccess) return (int)attr;
   hipLaunchKernelGGL(beam_wave_kernel, dim3((batch + upw - 1) / upw), dim3(64 * upw), lds, st, logp, batch, frames,
                      row_frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids,

@@ -548,8 +548,8 @@ int launch_fused_t(const FusedArgs& a, hipStream_t st, int* amax_n) {
     if (amax_n) *amax_n = tiles_t * 4;
   }
   auto kern = dwpw_fused_kernel<K, DUAL, BN>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)
+  const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(kern), (int)G::LDS, lds_opted);
   if (attr != hipSuccess) return (int)attr;
   VASR_LAUNCH(kern, dim3(n_blocks), dim3(FNT), G::LDS, st, a, tiles_t, n_blocks);
   return 0;

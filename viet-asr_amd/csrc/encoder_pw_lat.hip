@@ -267,8 +267,8 @@ int launch_lat_k(const PwArgs& a, hipStream_t st, int* amax_n) {
   }
   constexpr size_t lds = (size_t)2 * KS * 2 * LBN * sizeof(uint4);   // >= the epilogue's 4 x 2 KB for every KS
   auto kern = pw_gemm_latency_kernel<KS, DUAL, RES>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)
+  const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(kern), (int)lds, lds_opted);
   if (attr != hipSuccess) return (int)attr;
   VASR_LAUNCH(kern, dim3(n_blocks), dim3(LNT), lds, st, a, blocks_m, tiles_t, n_blocks);
   return 0;

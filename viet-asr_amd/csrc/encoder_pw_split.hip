@@ -675,8 +675,8 @@ int launch_k(const PwArgs& a, hipStream_t st, int* amax_n) {
     if (amax_n) *amax_n = n;
   }
   auto kern = pw_gemm_split_kernel<NW, TM, TN, MASK, RES, DUAL, ARITH>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)
+  const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(kern), (int)G::LDS, lds_opted);
   if (attr != hipSuccess) return (int)attr;
   VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT + 64 * extra_waves<NW, TM, TN>()), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
   return 0;

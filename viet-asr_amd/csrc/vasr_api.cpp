@@ -1096,16 +1096,13 @@ int vasr_set_slices(vasr_handle* h, int slices) {
 }
 
 size_t vasr_beam_workspace_bytes(int batch, int64_t frames) {
-  // back-pointer rows [B][T][128] u32, then the LM-cache key log [B][T * 128] u64 (beam.hip: eoslog)
+  // back-pointer rows [B][T][128] u32, then the LM-cache key log [B][T * 128] u64 (beam_wave.hip: eoslog)
   return batch > 0 && frames > 0 ? (size_t)batch * frames * kBeamMax * (sizeof(unsigned int) + sizeof(uint64_t)) : 0;
 }
 
 int vasr_beam_workgroups(int batch) {
   if (batch <= 0) return 0;
-#ifdef VASR_DEVTOOLS
-  static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
-  if (wg_kernel) return batch;
-#endif
+  if (beam_group_width(batch) > 1) return batch;     // the latency form: a compute unit per utterance (beam_group.hip)
   const int upw = beam_wave_utts_per_workgroup(batch);
   return (batch + upw - 1) / upw;
 }
@@ -1129,15 +1126,10 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (space_id < -1 || space_id >= num_classes - 1) return fail(VASR_ERR_INVALID, "space_id out of range");
   const size_t need_bytes = vasr_beam_workspace_bytes(batch, frames);
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
-  // one wavefront per utterance (beam_wave.hip); VASR_BEAM_WG=1 (devtools build) keeps the workgroup-per-utterance kernel of
-  // rounds 1-3 for A/B runs
-#ifdef VASR_DEVTOOLS
-  static const bool wg_kernel = dev_env("VASR_BEAM_WG") && atoi(dev_env("VASR_BEAM_WG")) != 0;
-  const auto launch = wg_kernel ? launch_beam_search : launch_beam_search_wave;
-#else
-  const auto launch = launch_beam_search_wave;
-#endif
-  const int e = launch(
+  // < 16 utterances: an utterance on four wavefronts of a compute unit (beam_group.hip, the serving latency); from there on
+  // one wavefront per utterance, four utterances per compute unit (beam_wave.hip).  Same bits either way; VASR_BEAM_GROUP
+  // (devtools build: 0 | 2 | 4) pins the form for A/B runs.
+  const int e = launch_beam_search_group(
       d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width, token_min_logp, beam_prune_logp,
       lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws), d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream),
       d_row_frames);
@@ -1370,29 +1362,6 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   if (ax.n < amax_stride)
     HIP_TRY(hipMemset2DAsync(d_amax + ax.n, (size_t)amax_stride * 4, 0, (size_t)(amax_stride - ax.n) * 4, batch, st));
   return check_launch("bench_pointwise_f16x2");
-}
-
-int vasr_pack_p4(const float* h_x, int rows, int64_t ld, float scale, uint16_t* h_out) {
-  if (!h_x || !h_out || rows <= 0 || ld <= 0 || ld % 4) return fail(VASR_ERR_INVALID, "bad argument");
-  pack_p4_reference(h_x, rows, ld, scale, h_out);
-  return 0;
-}
-
-int vasr_bench_pointwise_p4(const uint16_t* d_x_p4, const float* d_x_inv, const uint16_t* d_w16, float w_inv_scale,
-                            const float* d_scale, const float* d_shift, int batch, int cin, int cout, int64_t frames,
-                            float* d_y, uint32_t* d_amax_y, int amax_stride, vasr_stream stream) {
-  if (!d_x_p4 || !d_x_inv || !d_w16 || !d_scale || !d_shift || !d_y) return fail(VASR_ERR_INVALID, "bad argument");
-  const int64_t ld = pad_frames(frames);
-  PwP4Args a{};
-  a.wt = reinterpret_cast<const uint4*>(d_w16); a.x = reinterpret_cast<const uint4*>(d_x_p4); a.x_inv_scale = d_x_inv;
-  a.scale = d_scale; a.shift = d_shift; a.y = d_y; a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld;
-  a.frames = (int)frames; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? 2 : 0); a.w_inv_scale = w_inv_scale;
-  if (d_amax_y) a.amax_y = AmaxTab{d_amax_y, amax_stride, 0};
-  int n_y = 0;
-  const int e = launch_pointwise_p4(a, static_cast<hipStream_t>(stream), &n_y);
-  if (e < 0) return fail(VASR_ERR_UNSUPPORTED, "shape not covered by the pre-split GEMM");
-  if (e) return fail(VASR_ERR_HIP, "pointwise GEMM (P4): %s", hipGetErrorString((hipError_t)e));
-  return check_launch("bench_pointwise_p4");
 }
 
 int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const float* d_scale, const float* d_shift,

@@ -1,6 +1,7 @@
 // Internal launch interface between vasr_api.cpp and the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,6 +33,19 @@ extern thread_local LaunchProbe g_probe;
       hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                         \
     }                                                                                                      \
   } while (0)
+
+// Opt-in of a kernel for more than 64 KB of dynamic LDS, once PER DEVICE (a function-local `static const` ran it
+// once per process, for whichever device was current at the first launch).  `done` is one bit per device ordinal, owned by
+// the call site (one per kernel instantiation): static std::atomic<uint64_t> done{0};
+inline hipError_t dyn_lds_opt_in(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
 
 // One logical layer issued as several launches (full tiles + tail): the first launch carries the probe's start event, the
 // last its stop event, so the bracket covers all of them (and the dispatch gaps between them).
@@ -180,26 +194,6 @@ float pack_pointwise_weights_f16x2(const float* w, int cout, int cin, int m_pad,
 void launch_amax(const float* x, int64_t ld, int rows, int frames, const int32_t* lens, int batch, AmaxTab* amax,
                  hipStream_t st);
 
-// ---- 1x1 conv on pre-split ("P4") activations (encoder_pw_p4.hip) ----
-// P4 tensor: same pitch as the fp32 tensor, row (b, c) = ld / 4 groups of 16 bytes: frames 4 g .. 4 g + 3 as
-// [4 x fp16 hi | 4 x fp16 lo] of scale_b * x (halves swapped on channels with c & 2); 1 / scale_b in a [B] float table.
-struct PwP4Args {
-  const uint4* wt;            // f16x2 fragment pack (pack_pointwise_weights_f16x2)
-  const uint4* x;             // [B][K][ldx / 4] groups
-  const float* x_inv_scale;   // [B]
-  const float* scale; const float* shift;   // [M] folded BN
-  float* y;                   // [B][M][ldy] fp32
-  int32_t M, K, batch;
-  int64_t ldx, ldy;
-  int32_t frames, relu;
-  const int32_t* zero_from;   // as PwArgs
-  float w_inv_scale;
-  AmaxTab amax_y; const int32_t* lens_y;
-};
-bool pointwise_p4_supported(int M, int K, int64_t ldx, int64_t ldy);
-int launch_pointwise_p4(const PwP4Args& a, hipStream_t st, int* amax_n);   // 0, a hipError_t, or -1 (shape not covered)
-void pack_p4_reference(const float* x, int rows, int64_t ld, float scale, unsigned short* out);   // host restatement of the layout
-
 // ---- fused depthwise + pointwise sub-block, 256 channels (encoder_fused.hip) ----
 struct FusedLaunch {
   const float* x; int64_t ldx;                 // [B][256][ldx] depthwise input
@@ -249,7 +243,7 @@ void launch_pcm16_to_f32(const short* in, int64_t n, float* out, hipStream_t st)
 void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int batch, const float* table, int nwin,
                      int num_table, double ratio, float* y, int64_t ld_out, int64_t* len_out, hipStream_t st);
 
-// ---- beam search (beam.hip) ----
+// ---- beam search (beam_wave.hip, beam_group.hip) ----
 struct BeamLm {  // device-resident hashed back-off n-gram model
   const void* vocab; int vcap;    // [vcap] 16-byte entries {u64 word hash | 1, i32 word id, i32 0}, vcap a power of two
   const void* ngram; int ncap;    // [ncap] 16-byte entries {u64 n-gram key | 1, f32 log10 p, f32 log10 back-off}
@@ -257,17 +251,20 @@ struct BeamLm {  // device-resident hashed back-off n-gram model
   float alpha, beta, unk_offset;
 };
 constexpr int kBeamMax = 128;  // beams kept per utterance at most
-int launch_beam_search(const float* logp,   // 0 or a hipError_t
-                        int batch, int frames, int V1, int space_id, int beam_width,
-                        float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
-                        int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
-                        const int32_t* row_frames = nullptr);   // [batch] frames searched per row, nullptr = all
-// beam_wave.hip: one wavefront per utterance, `beam_wave_utts_per_workgroup` utterances per workgroup (= compute unit)
+// beam_wave.hip: one wavefront per utterance, `beam_wave_utts_per_workgroup` utterances per workgroup (= compute unit);
+// returns 0 or a hipError_t; row_frames: [batch] frames searched per row, nullptr = all
 int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
                             float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
                             int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                             const int32_t* row_frames = nullptr);
 int beam_wave_utts_per_workgroup(int batch);
+// beam_group.hip: the latency form -- an utterance on `beam_group_width(batch)` wavefronts of one compute unit (4 below 16
+// utterances, else 1 = beam_wave.hip); same results bit for bit.  The entry point of vasr_beam_search_*.
+int launch_beam_search_group(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,
+                             float token_min_logp, float beam_prune_logp, const BeamLm* lm, unsigned int* bp,
+                             int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
+                             const int32_t* row_frames = nullptr);
+int beam_group_width(int batch);
 size_t beam_wave_lds_bytes();
 unsigned long long beam_hash_step(unsigned long long h, unsigned long long v);
 unsigned long long beam_hash_init();

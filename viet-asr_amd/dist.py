@@ -90,7 +90,8 @@ class AsyncIdGather:
 
     def __init__(self, world, device, group=None, slots=2):
         self.world, self.device, self.group, self.slots = world, device, group, slots
-        self._bufs, self._inflight, self._n = {}, [None] * slots, 0
+        self._bufs, self._inflight, self._n, self._last = {}, [None] * slots, 0, None
+        self.max_shapes = 4      # buffer sets kept: a loop that drifts through many [B, T'] shapes must not grow without bound
 
     def drain(self, slot=None):
         for k in (range(self.slots) if slot is None else (slot,)):
@@ -103,6 +104,12 @@ class AsyncIdGather:
         """Enqueue the gather of this rank's batch; returns the slot it went into."""
         shape = tuple(ids.shape)
         if shape not in self._bufs:
+            # drop the buffer sets of shapes that have nothing in flight any more, oldest first (dict order = insertion order)
+            busy = {f[4] for f in self._inflight if f is not None}
+            for old in [k for k in self._bufs if k not in busy and (self._last is None or k != self._last[0])]:
+                if len(self._bufs) < self.max_shapes:
+                    break
+                del self._bufs[old]
             # (the rank-major concatenation along dim 0: the output form both RCCL and gloo accept; read as [world, B, ...])
             self._bufs[shape] = [(torch.empty((self.world * shape[0],) + shape[1:], dtype=ids.dtype, device=self.device).view((self.world,) + shape),
                                   torch.empty((self.world * shape[0],), dtype=id_len.dtype, device=self.device).view(self.world, shape[0]))
@@ -118,6 +125,8 @@ class AsyncIdGather:
 
     def last(self):
         """(ids [world, B, T'], id_len [world, B]) of the most recent submit, waited for."""
+        if self._last is None:
+            raise RuntimeError("AsyncIdGather.last() before the first submit()")
         shape, slot = self._last
         self.drain(slot)
         return self._bufs[shape][slot]

@@ -22,7 +22,7 @@ from .helpers import post_process_predictions
 
 class VietASR:
     def __init__(self, config_file, encoder_checkpoint, decoder_checkpoint, device="gpu", lm_path=None,
-                 beam_width=20, lm_alpha=0.5, lm_beta=1.5, decoder="beam"):
+                 beam_width=20, lm_alpha=0.5, lm_beta=1.5, decoder="beam", allow_missing_lm=False):
         if os.path.exists(str(config_file)):
             model_definition = configs.load_model_definition(config_file)
         else:
@@ -54,10 +54,9 @@ class VietASR:
             self.greedy = nemo_asr.GreedyCTCDecoder()
             self.infer_tensors = [self.greedy(log_probs=log_probs)]
         elif decoder == "beam":
-            if lm_path and not os.path.exists(lm_path):
-                lm_path = None
+            # a given lm_path that is missing or not ARPA text is an error unless allow_missing_lm (round 5; beam.LM_HELP)
             self.beam = nemo_asr.BeamSearchDecoderWithLM(vocab=labels, beam_width=beam_width, alpha=lm_alpha,
-                                                         beta=lm_beta, lm_path=lm_path,
+                                                         beta=lm_beta, lm_path=lm_path, allow_missing_lm=allow_missing_lm,
                                                          num_cpus=max(1, os.cpu_count()))
             self.infer_tensors = [self.beam(log_probs=log_probs, log_probs_length=encoded_len)]
         else:
