@@ -358,25 +358,25 @@ np.save({dst!r}, np.array([(a.tobytes(), b.tobytes(), c.tobytes()) for a, b, c i
 
 @pytest.mark.gpu
 def test_wave_kernel_and_group_kernel_agree(gpu, tmp_path):
-    """beam_wave.hip (one wavefront per utterance: batches) against beam_group.hip (an utterance on 4 or 2 wavefronts of a
+    """beam_wave.hip (one wavefront per utterance: batches) against beam_group.hip (an utterance on four wavefronts of a
     compute unit: the serving latency; VASR_BEAM_GROUP pins the form in the devtools build): the same keys, merge arithmetic
-    (ordered-int max, fixed-point sums), prune, radix select and rank rules on a different schedule -- hypotheses, lengths and
-    scores identical bit for bit on CTC-like, flat and peaked posteriors, widths 8 ... 128, with and without the LM (flat
-    posteriors at width 100-128 take several passes per frame and a radix select on most).  Each form runs in its own
-    process (the switch is read once)."""
+    (ordered-int max, fixed-point sums), prune, radix select and rank rules on a different schedule and with twice the pairs
+    per pass -- hypotheses, lengths and scores identical bit for bit on CTC-like, flat and peaked posteriors, widths 8 ... 128,
+    with and without the LM (flat posteriors at width 100-128 take several passes per frame and a radix select on most).
+    Each form runs in its own process (the switch is read once)."""
     import subprocess, sys
     from conftest import ROOT
     dev = os.path.join(ROOT, "viet-asr_amd", "lib", "libvasr_hip_dev.so")
     res = []
-    for tag, extra in (("wave", {"VASR_BEAM_GROUP": "0"}), ("group4", {"VASR_BEAM_GROUP": "4"}), ("group2", {"VASR_BEAM_GROUP": "2"})):
+    for tag, extra in (("wave", {"VASR_BEAM_GROUP": "0"}), ("group4", {"VASR_BEAM_GROUP": "4"})):
         dst = str(tmp_path / f"{tag}.npy")
         env = dict(os.environ, VASR_LIB_PATH=dev, **extra)
         r = subprocess.run([sys.executable, "-c", _AB_SNIPPET.format(root=ROOT, tmp=str(tmp_path), dst=dst)], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(dst, allow_pickle=True))
-    assert len(res[0]) == len(res[1]) == len(res[2]) == 8
-    for other in (1, 2):
+    assert len(res[0]) == len(res[1]) == 8
+    for other in (1,):
         for k, (a, b) in enumerate(zip(res[0], res[other])):
             n_a, n_b = np.frombuffer(a[1], np.int32), np.frombuffer(b[1], np.int32)
             assert (n_a == n_b).all(), (other, k)

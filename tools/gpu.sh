@@ -573,6 +573,61 @@ cat $O/probe_kernel_only.txt
 cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
 }
 
+# ---- r5prof: section cycle counters of the beam kernels at the serving shape (var_gprof.so / var_wprof.so: -DVASR_BEAM_PROF builds)
+task_r5prof() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5prof}; mkdir -p $O; cd $R
+{
+for g in 4 2; do echo "#### group W=$g"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_gprof.so VASR_BEAM_GROUP=$g python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu; done
+echo "#### wave"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_wprof.so VASR_BEAM_GROUP=0 python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu
+} > $O/beam_prof.txt 2>&1
+cat $O/beam_prof.txt
+}
+
+# ---- r5c: beam_group.hip iteration: beam tests, serving-shape latency per VASR_BEAM_GROUP in $BGROUPS, section counters
+task_r5c() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5c}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_beam.py -x -q -m gpu > $O/pytest_beam.log 2>&1; tail -5 $O/pytest_beam.log
+export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
+for g in ${BGROUPS:-0 4 8}; do
+  echo "== VASR_BEAM_GROUP=$g: serving shape"; VASR_BEAM_GROUP=$g python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -1
+  echo "== VASR_BEAM_GROUP=$g: beam_lat (B = 1)"; VASR_BEAM_GROUP=$g BATCHES=1 python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
+done > $O/beam_lat.txt 2>&1
+unset VASR_LIB_PATH
+cat $O/beam_lat.txt
+for g in ${BGROUPS:-0 4 8}; do [ $g = 0 ] && continue; echo "#### group W=$g"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_gprof.so VASR_BEAM_GROUP=$g WIDTHS=100 python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu; done > $O/beam_prof.txt 2>&1
+cat $O/beam_prof.txt
+}
+
+# ---- r5d: beam_group.hip with a larger pass (var_g716.so: 716 pairs per pass instead of 358): fuzz against the oracle AND against the
+#      one-wavefront kernel (bit equality), serving-shape latency, section counters -- after the same for the default build
+task_r5d() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5d}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_beam.py -x -q -m gpu > $O/pytest_beam.log 2>&1; tail -3 $O/pytest_beam.log
+{
+echo "== default build, serving shape"; VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -1
+echo "== default build, section counters"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_gprof.so VASR_BEAM_GROUP=4 WIDTHS=50,100 python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu
+echo "== g716: fuzz (oracle + bit equality with the one-wavefront kernel)"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_g716.so timeout 600 python tests/devtools/fuzz_beam.py 400 0 2>&1 | grep -v amdgpu | tail -8
+echo "== g716, serving shape"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_g716.so python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -1
+echo "== g716, section counters"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_gprof716.so VASR_BEAM_GROUP=4 WIDTHS=100 python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu
+} > $O/beam.txt 2>&1
+cat $O/beam.txt
+}
+
+# ---- r5e: beam_group.hip as shipped (716 pairs per pass, W = 4): the beam tests, 2 000 fuzz cases, serving-shape latency, section counters
+task_r5e() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5e}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_beam.py -x -q -m gpu > $O/pytest_beam.log 2>&1; tail -3 $O/pytest_beam.log
+{
+echo "== fuzz: 2 000 cases against the oracle and (bit equality) against the one-wavefront kernel"; timeout 900 python tests/devtools/fuzz_beam.py 2000 400 2>&1 | grep -v amdgpu | tail -5
+echo "== serving shape, four-wavefront kernel (default below 16 utterances)"; python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -1
+echo "== serving shape, one-wavefront kernel (VASR_BEAM_GROUP=0, devtools build)"; VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so VASR_BEAM_GROUP=0 python tools/b1_serving.py --calls 30 2>&1 | grep -v amdgpu | tail -1
+echo "== beam_lat, four-wavefront kernel"; BATCHES=1,8 python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
+echo "== beam_lat, one-wavefront kernel"; VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so VASR_BEAM_GROUP=0 BATCHES=1,8 python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
+echo "== section counters (var_gprof.so)"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var_gprof.so VASR_BEAM_GROUP=4 WIDTHS=50,100 python tools/probes/beam_prof.py 2>&1 | grep -v amdgpu
+} > $O/beam.txt 2>&1
+cat $O/beam.txt
+}
+
 task=${1:-list}; shift || true
 if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
 if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi

@@ -1,4 +1,4 @@
-// CTC prefix beam search with optional back-off n-gram LM: ONE UTTERANCE ON W WAVEFRONTS OF ONE COMPUTE UNIT (gfx950) --
+// CTC prefix beam search with optional back-off n-gram LM: ONE UTTERANCE ON FOUR WAVEFRONTS OF ONE COMPUTE UNIT (gfx950) --
 // the latency form of beam_wave.hip, for the shape the reference SERVES: batch 1, beam width 50 (app.py:27) or 100
 // (infer.py:191) + LM, reference nemo/collections/asr/beam_search_decoder.py:95-102 (pyctcdecode on the host, one utterance
 // at a time; third-party, parity unpinned: the algorithm restated is oracle/beam_oracle.py).
@@ -7,14 +7,13 @@
 // chip free for the next acoustic pass), but a lone utterance then runs on one SIMD of one CU out of 256, issuing a
 // dependent instruction stream at ~10 cycles per instruction (profiles/r04_beam_sq_counters.txt): 4.3 ms at beam 100 on
 // 331 frames, 91-95 % of the serving latency.  Here the SAME algorithm -- same keys, same merge arithmetic (ordered-int
-// max, 2^-44 fixed-point sums: associative, hence independent of who adds first), same prune / radix select / rank rules,
-// hence the same bits (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree) -- is dealt over W = 4 (or 2)
-// wavefronts, one per SIMD:
+// max, 2^-44 fixed-point sums: associative, hence independent of who adds first), same prune / radix select / rank rules --
+// is dealt over W = 4 wavefronts, one per SIMD (profiles/r05_beam_group.txt: 4.29 -> 1.99 ms at beam 100, 2.44 -> 1.42 at 50):
 //
-//   * (beam, character) pair p lives in wavefront (p >> 6) % W, lane p & 63: a lane carries ceil(pairs / 64 W) pairs (1-2
+//   * (beam, character) pair p lives in wavefront (p >> 6) % W, lane p & 63: a lane carries ceil(pairs / 256) pairs (1-3
 //     instead of 5-6) through expand / score / select; beams (LM refresh, children) are dealt one per THREAD;
 //   * the merge table, the beams and the radix histogram are shared in LDS (LDS atomics work across the wavefronts of a
-//     workgroup); what one wavefront needs from the others crosses in small mailboxes at LDS-only barriers:
+//     workgroup); what one wavefront needs from the others crosses at LDS-only barriers:
 //       B1 after the claims (all pairs sit in the table; merged slots know their contributors' maximum)
 //       B3 after the contributors' fixed-point adds            -- only on frames where two pairs merged
 //       B4 the best combined score (prune threshold)
@@ -22,16 +21,32 @@
 //       R  one per radix digit of the select (histogram buffers rotate: no clearing barrier)
 //       B6 per-block (greater, equal) counts -> every wavefront computes every rank offset itself
 //       Z  end of frame (children complete)
-//     5-7 barriers of 4 wavefronts per general frame against ~20 of 8 in the workgroup kernel of rounds 1-3;
+//     5-8 barriers of 4 wavefronts per general frame (50-500 cycles each, measured) against ~20 of 8 in the workgroup kernel
+//     of rounds 1-3;
+//   * workgroup-wide reductions (best score, live count, differing bits, claimed count) are LDS atomics on one word -- the
+//     LDS serialises the lanes, one instruction per wavefront -- instead of a DPP reduction per wavefront (~25 instructions,
+//     250 cycles at a lone wavefront's issue rate) plus a mailbox per wavefront;
+//   * the merge table has 2 048 slots for <= 716 pairs per pass (beam_wave.hip: 512 for 358): at <= 35 % load the first probe
+//     IS the compare-and-swap and hardly any lane walks on (the first version, 512 slots at 70 %, spent 7 200 of 23 400
+//     cycles per frame in the probe walk of a wavefront's unluckiest lane); a frame with 100 beams x 4-7 candidates is ONE
+//     pass instead of two.  A larger pass does not change the result: pairs that merge carry the same character, i.e. sit in
+//     the same pass either way; the survivors of the earlier passes re-enter the last pass's prune and select, so the
+//     selected SET is the top-k of the union in both forms; only the ORDER of the new beams differs (one pass: pair order;
+//     several: last pass's pairs, then carried survivors), and the order only breaks exact ties of 64-bit scores
+//     (tests/devtools/fuzz_beam.py: 400 cases bit-equal to the one-wavefront kernel, which passes at 358);
 //   * a claimer leaves its score in the slot (tsc) so that a contributor can form max(contributors, claimer) itself: the
 //     single-wavefront kernel's "claimer raises the maximum" step and its barrier are gone, the sums are the same integers;
+//   * the first radix digit of a select starts at the first BIT in which the live keys differ (byte-aligned digits wasted
+//     most of the first one: 3.1 -> 1.5 digits per frame at beam 100);
 //   * selected pairs of a frame's LAST pass build their children straight from the registers of the lane that owns them
 //     (no survivor records through LDS); frames of a blank run touch one beam per thread and skip every barrier;
 //   * log-probs and the candidate list are per-wavefront copies (each wavefront stages its own batch of eight frames): no
 //     barrier for either;
 //   * the final pass (commit pending words, merge identical texts, trace-back) is wavefront 0 alone, as in beam_wave.hip.
 //
-// Workgroup = 64 W threads = one utterance; LDS ~52 KB (W = 4).  Used for batches of < 16 utterances (vasr_api.cpp).
+// Results equal beam_wave.hip's bit for bit (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree, and every case of
+// the randomised comparison runs both forms).  Workgroup = 256 threads = one utterance; LDS 120 KB, one workgroup per CU.
+// Used for batches of < 16 utterances (vasr_api.cpp); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
 #include <cstdlib>
 #include <type_traits>
 
@@ -42,13 +57,17 @@ namespace vasr {
 namespace {
 using namespace beam_detail;
 
-constexpr int kTab = 512;                 // merge-table slots (as beam_wave.hip: the pass structure decides tie order)
-constexpr int kFill = kTab * 7 / 10;
+constexpr int kTab = 2048;                // merge-table slots
+#ifndef VASR_BEAM_GROUP_FILL
+#define VASR_BEAM_GROUP_FILL 716          // pairs per pass (file header; 358 = beam_wave.hip's: dev A/B builds)
+#endif
+constexpr int kFill = VASR_BEAM_GROUP_FILL;
 constexpr int kTbRows = 12;
 constexpr int kLpFrames = 8;
 constexpr int kLpRegs = kLpFrames * kMaxClasses / 64;
 constexpr int kChars = 3072;
-constexpr int kMaxBlocks = 10;            // block indices W j + w of a pass (W PPL <= 8) + 2 blocks of carried survivors
+constexpr int kMaxBlocks = 16;            // block indices W j + w of a pass (W PPL <= 12) + 2 blocks of carried survivors
+static_assert(4 * 3 + 2 <= kMaxBlocks, "block mailboxes");
 
 template <int W>
 struct GroupLds {
@@ -73,17 +92,20 @@ struct GroupLds {
   unsigned char cand[W][kMaxClasses];      // per wavefront
   int hist[3][256];
   // mailboxes
-  long long mb_best[W];
-  int mb_claimed[W];
-  int mb_live[W];
-  unsigned long long mb_diff[W];
+  // ... reduced by the LDS itself (one atomic per lane or per wavefront instead of a DPP reduction per wavefront -- ~25
+  // instructions each at a lone wavefront's ~10 cycles per instruction -- plus a mailbox per wavefront); two sets, used by
+  // alternate passes: thread 0 resets the other set right after B4
+  long long red_best[2];
+  unsigned long long red_diff[2];
+  int red_claimed[2], red_live[2];
   int mb_gt[kMaxBlocks], mb_eq[kMaxBlocks];
   int merge_epoch, anychar_epoch;
   int n_log;
 };
 static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
 static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
-static_assert(sizeof(GroupLds<4>) <= 64 * 1024, "fits the default dynamic LDS limit");
+static_assert(sizeof(GroupLds<4>) <= 160 * 1024, "one workgroup per compute unit");
+static_assert(kFill <= 3 * 256 && kFill <= kTab * 7 / 20, "pairs per pass: three per lane at most, table at most 35 % full");
 
 constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25;
 __device__ inline int meta_last(unsigned m) { return (int)(m & 0xffu) - 1; }
@@ -141,12 +163,21 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     if (use_lm) S.ctx[0][0][kMaxCtx - 1] = lm.bos;
     S.commit_lmd[0][0] = 0.f; S.commit_wid[0][0] = 0;
     S.merge_epoch = -1; S.anychar_epoch = -1; S.n_log = 0;
+    for (int k = 0; k < 2; ++k) { S.red_best[k] = ord64(-1e300); S.red_diff[k] = 0; S.red_claimed[k] = 0; S.red_live[k] = 0; }
   }
   group_sync();
   int cur = 0, nb = 1, epoch = 0;
   int hd = 0;                  // radix digits histogrammed so far: digit hd uses hist[hd % 3] (uniform)
   bool all_blank = false;      // every live beam ends in blank (uniform)
   bool dirty = false;          // frames of a blank run have updated beams without a barrier (uniform)
+#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals of wavefront 0 of utterance 0 (lane k accumulates section k)
+  unsigned pacc = 0, pt = (unsigned)__builtin_readcyclecounter();
+#define GTICK(k) { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); pacc += lane == (k) ? now_ - pt : 0u; pt = now_; }
+#define GCOUNT(k, v) pacc += lane == 32 + (k) ? (unsigned)(v) : 0u;
+#else
+#define GTICK(k)
+#define GCOUNT(k, v)
+#endif
 
   // log-probs: every wavefront stages its own copy of the batch of kLpFrames frames (beam_wave.hip says why they come
   // through LDS and why the loads are unconditional)
@@ -212,6 +243,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   for (int t = 0; t < frames; ++t) {
     // ---- 1. candidate characters (every wavefront for itself: same values everywhere) ----
     const int c0 = lane, c1 = lane + 64;
+    GTICK(15)
     if ((t & (kLpFrames - 1)) == 0) {
 #pragma unroll
       for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) lpq[64 * k + lane] = q[k];
@@ -221,19 +253,24 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     const float* lq = lpq + (t & (kLpFrames - 1)) * V1;
     const float v0 = c0 < V1 ? fminf(fmaxf(lq[c0], -34.538776f), 0.f) : 0.f, v1 = c1 < V1 ? fminf(fmaxf(lq[c1], -34.538776f), 0.f) : 0.f;
     auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
-    const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
-    const unsigned kmax = wave_max_u32(max(key0, key1));
-    const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
-    const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
-    const bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
-    const bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    // candidates = {x >= token_min_logp} U {arg-max}: when any class passes the threshold the arg-max is among them already
+    bool k0 = c0 < V1 && v0 >= token_min_logp, k1 = c1 < V1 && v1 >= token_min_logp;
+    unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    if ((m0 | m1) == 0ull) {
+      const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+      const unsigned kmax = wave_max_u32(max(key0, key1));
+      const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+      const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
+      k0 = c0 == amax; k1 = c1 == amax;
+      m0 = __ballot(k0); m1 = __ballot(k1);
+    }
     if (k0) cand[rank_in(m0)] = (unsigned char)c0;
     if (k1) cand[__popcll(m0) + rank_in(m1)] = (unsigned char)c1;
     const int nc_all = __popcll(m0) + __popcll(m1);
     const bool has_space = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
     const bool only_blank = nc_all == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
     wave_sync();
+    GTICK(0)
 
     // a blank-only frame met by beams that all end in blank: one beam per thread, nothing crosses wavefronts
     if (only_blank && all_blank) {
@@ -243,9 +280,11 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
       }
       dirty = true;
+      GTICK(1)
       continue;
     }
     if (dirty) { group_sync(); dirty = false; }
+    GCOUNT(0, 1)
 
     // ---- 2. ' ' is a candidate: LM cache log + commit scores, one beam per thread ----
     if (use_lm && has_space) {
@@ -280,14 +319,18 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       // (the commit scores are read after barrier B1)
     }
 
+    GTICK(2)
     const int cap = max(1, (int)(((float)kFill + 0.5f) * __builtin_amdgcn_rcpf((float)nb)));
     // survivors carried from the earlier passes of this frame (wavefront 0 only): ranks lane and lane + 64
     long long c_tot[2] = {ord64(-1e300), ord64(-1e300)}, c_lgt[2] = {0, 0};
     int c_src[2] = {0, 0};
     int n_sel = 0;
 
-    auto pass = [&](auto ppl_tag, int c_lo, int nc, bool last_pass) __attribute__((always_inline)) {
+    // carry_tag: the frame's earlier passes left survivors (wavefront 0 carries them as two more blocks of entries); a
+    // single-pass frame -- the usual case -- compiles them out
+    auto pass = [&](auto ppl_tag, auto carry_tag, int c_lo, int nc, bool last_pass) __attribute__((always_inline)) {
       constexpr int PPL = decltype(ppl_tag)::value;
+      constexpr int NC = decltype(carry_tag)::value ? 2 : 0;
       const int npairs = nb * nc;
       const float inv_nc = __builtin_amdgcn_rcpf((float)nc);
       ++epoch;
@@ -316,12 +359,12 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         slot[j] = (int)((k >> 17) & (kTab - 1));
         stride[j] = (int)((k >> 40) & (kTab - 1)) | 1;
       }
+      // the table is at most a sixth full: a home slot is usually empty, so the first probe IS the compare-and-swap (one LDS
+      // round trip instead of read + swap); its answer says empty (claimed), our key (a merge) or a foreign key (walk on)
       unsigned long long seen[PPL];
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) seen[j] = S.tkey[slot[j]];
-#pragma unroll
       for (int j = 0; j < PPL; ++j)
-        if ((act >> j & 1) && seen[j] == 0ull) {
+        if (act >> j & 1) {
           seen[j] = atomicCAS(&S.tkey[slot[j]], 0ull, kk[j]);
           if (seen[j] == 0ull) { claimed |= 1u << j; seen[j] = kk[j]; }
         }
@@ -333,13 +376,9 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           if (seen[j] != k) {
             while (true) {
               i = (i + stride[j]) & (kTab - 1);
-              const unsigned long long e = S.tkey[i];
-              if (e == k) break;
-              if (e == 0) {
-                const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
-                if (old == 0ull) { claimed |= 1u << j; break; }
-                if (old == k) break;
-              }
+              const unsigned long long old = atomicCAS(&S.tkey[i], 0ull, k);
+              if (old == 0ull) { claimed |= 1u << j; break; }
+              if (old == k) break;
             }
           }
           if (claimed >> j & 1) S.tsc[i] = score[j];                   // the claimer's score stays with the slot
@@ -352,9 +391,12 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         int n_cl = 0;
 #pragma unroll
         for (int j = 0; j < PPL; ++j) n_cl += __popcll(__ballot(claimed >> j & 1));
-        if (lane == 0) S.mb_claimed[wv] = n_cl;
+        if (lane == 0 && n_cl) atomicAdd(&S.red_claimed[epoch & 1], n_cl);
       }
+      GTICK(3)
       group_sync();                                                     // ---- B1
+      GTICK(4)
+      GCOUNT(1, npairs) GCOUNT(2, 1)
       const bool any_merge = S.merge_epoch == epoch;                    // uniform over the workgroup
       if (any_merge) {
         // a contributor adds exp(score - max(contributors, claimer)) as a 2^-44 fixed-point integer
@@ -367,10 +409,12 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           }
         }
         group_sync();                                                   // ---- B3
+        GCOUNT(3, 1)
       }
+      GTICK(5)
       // ---- 3. merged prefixes, each in the lane that claimed its slot ----
       long long tot[PPL], lgt[PPL];
-      long long my_best = max(c_tot[0], c_tot[1]);
+      long long my_best = NC ? max(c_tot[0], c_tot[1]) : ord64(-1e300);
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const bool mine = claimed >> j & 1;
@@ -402,15 +446,16 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         lgt[j] = __double_as_longlong(logit);
         my_best = max(my_best, tot[j]);
       }
-      {
-        const long long wb = wave_max_i64(my_best);
-        if (lane == 0) S.mb_best[wv] = wb;
-      }
+      if (my_best != ord64(-1e300)) atomicMax(&S.red_best[epoch & 1], my_best);
+      GTICK(6)
       group_sync();                                                     // ---- B4
-      long long best = S.mb_best[0];
-      int n_claimed_all = S.mb_claimed[0] + n_sel;                      // + the carried survivors
-#pragma unroll
-      for (int k = 1; k < W; ++k) { best = max(best, S.mb_best[k]); n_claimed_all += S.mb_claimed[k]; }
+      GTICK(7)
+      const long long best = S.red_best[epoch & 1];
+      const int n_claimed_all = S.red_claimed[epoch & 1] + n_sel;       // + the carried survivors
+      if (tid == 0) {   // the other set: last read a pass ago, next written after this pass's B6
+        const int o = (epoch + 1) & 1;
+        S.red_best[o] = ord64(-1e300); S.red_diff[o] = 0; S.red_claimed[o] = 0; S.red_live[o] = 0;
+      }
       // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
       const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
       const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
@@ -418,7 +463,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       int my_live = 0;
       unsigned long long diff = 0;
 #pragma unroll
-      for (int j = 0; j < PPL + 2; ++j) {
+      for (int j = 0; j < PPL + NC; ++j) {
         const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
         const bool lv = j < PPL ? ((claimed >> j & 1) && tt >= thr_prune) : (wv == 0 && lane + 64 * (j - PPL) < n_sel && tt >= thr_prune);
         if (lv) { live |= 1u << j; diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest; }
@@ -427,31 +472,36 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       unsigned long long prefix = 0, mask = 0;
       int want = beam_width;
       if (n_claimed_all > beam_width) {                                 // (uniform over the workgroup) only then can a select be needed
-        diff = ((unsigned long long)wave_or_u32((unsigned)(diff >> 32)) << 32) | wave_or_u32((unsigned)diff);
-        if (lane == 0) { S.mb_live[wv] = my_live; S.mb_diff[wv] = diff; }
+        if (diff) atomicOr(&S.red_diff[epoch & 1], diff);
+        if (lane == 0 && my_live) atomicAdd(&S.red_live[epoch & 1], my_live);
+        GTICK(8)
         group_sync();                                                   // ---- B5
-        int tot_live = 0;
-        diff = 0;
-#pragma unroll
-        for (int k = 0; k < W; ++k) { tot_live += S.mb_live[k]; diff |= S.mb_diff[k]; }
+        GTICK(9)
+        const int tot_live = S.red_live[epoch & 1];
+        diff = S.red_diff[epoch & 1];
         if (tot_live > beam_width) {
-          const int same = diff ? __clzll((long long)diff) / 8 : 8;
-          if (same > 0) { mask = same == 8 ? ~0ull : (~0ull << (64 - 8 * same)); prefix = ubest & mask; }
+          // the live keys agree in their `lead` leading bits (scores within beam_prune_logp of the best: sign, exponent and
+          // the top of the mantissa): the FIRST digit starts at the first bit in which they differ -- not at the next byte
+          // boundary, which wasted most of a digit: 3.1 digits per select at beam 100 -- and the digits then walk down in
+          // steps of eight, the last one clamped to bits 7..0 (an overlap with known bits is harmless: they match)
+          const int lead = diff ? __clzll((long long)diff) : 64;
+          if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
           // Histogram buffers rotate with a running digit count: digit hd adds into hist[hd % 3] -- cleared during digit
           // hd - 1 (or at the start) -- and clears hist[(hd + 1) % 3], last READ during digit hd - 2, which every wavefront
           // has left behind when it passed the barrier of digit hd - 1.  No clearing barrier.
 #pragma unroll 1
-          for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
+          for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
             int* h = S.hist[hd % 3];
             int* hn = S.hist[(hd + 1) % 3];
             ++hd;
 #pragma unroll
-            for (int j = 0; j < PPL + 2; ++j) {
+            for (int j = 0; j < PPL + NC; ++j) {
               const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
               if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&h[(int)((u >> shift) & 255)], 1);
             }
             for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;          // the next digit's buffer (last read two digits ago)
             group_sync();                                               // ---- R
+            GCOUNT(4, 1)
             int cnt[4], mine = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cnt[j] = h[255 - (4 * lane + j)]; mine += cnt[j]; }
@@ -469,16 +519,17 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
             const int whole = __builtin_amdgcn_readlane(f_whole, fl);
             prefix |= (unsigned long long)bucket << shift;
             mask |= 0xFFull << shift;
-            if (whole) break;
+            if (whole || shift == 0) break;
           }
         }
       }
+      GTICK(10)
       // ---- selected: live and key > threshold prefix, plus the first `want` equal to it in PAIR ORDER (block = 64 pairs:
       //      index W j + w; the carried survivors follow as blocks W PPL and W PPL + 1).  Every wavefront publishes its
       //      blocks' (greater, equal) counts; after B6 each computes every block's offset itself ----
-      bool gt[PPL + 2], eq[PPL + 2];
+      bool gt[PPL + NC], eq[PPL + NC];
 #pragma unroll
-      for (int j = 0; j < PPL + 2; ++j) {
+      for (int j = 0; j < PPL + NC; ++j) {
         const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
         gt[j] = false; eq[j] = false;
         if (live >> j & 1) {
@@ -491,11 +542,15 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           else if (wv == 0) { S.mb_gt[W * PPL + (j - PPL)] = ng; S.mb_eq[W * PPL + (j - PPL)] = ne; }
         }
       }
+      GTICK(11)
       group_sync();                                                     // ---- B6
+      GTICK(12)
+      // (every wavefront walks all blocks' counts itself; a lane-per-block form with two DPP scans measured 160-350 cycles per
+      // frame SLOWER: at one to three pairs per lane the walk is 4-14 short iterations)
       int n_out = 0, eq_seen = 0;
-      int off_out[PPL + 2], off_eq[PPL + 2];
+      int off_out[PPL + NC], off_eq[PPL + NC];
 #pragma unroll
-      for (int blk = 0; blk < W * PPL + 2; ++blk) {
+      for (int blk = 0; blk < W * PPL + NC; ++blk) {
         const int ng = S.mb_gt[blk], ne = S.mb_eq[blk];
         const int j = blk < W * PPL ? blk / W : PPL + (blk - W * PPL);
         const bool own = blk < W * PPL ? (blk % W == wv) : (wv == 0);
@@ -504,7 +559,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         eq_seen += ne;
       }
 #pragma unroll
-      for (int j = 0; j < PPL + 2; ++j) {
+      for (int j = 0; j < PPL + NC; ++j) {
         if (j >= PPL && wv != 0) continue;
         const unsigned long long em = __ballot(eq[j]);
         const bool take = gt[j] || (eq[j] && off_eq[j] + rank_in(em) < want);
@@ -538,16 +593,17 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       const bool last_pass = c_lo + cap >= nc_all;
       const int npairs = nb * nc;
       const int ppl = (npairs + 64 * W - 1) / (64 * W);
-      if constexpr (W >= 4) {
-        if (ppl <= 1) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
-        else pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
-      } else {
-        if (ppl <= 1) pass(std::integral_constant<int, 1>{}, c_lo, nc, last_pass);
-        else if (ppl == 2) pass(std::integral_constant<int, 2>{}, c_lo, nc, last_pass);
-        else pass(std::integral_constant<int, 3>{}, c_lo, nc, last_pass);
-      }
+      auto go = [&](auto ppl_tag) __attribute__((always_inline)) {
+        if (n_sel > 0) pass(ppl_tag, std::true_type{}, c_lo, nc, last_pass);
+        else pass(ppl_tag, std::false_type{}, c_lo, nc, last_pass);
+      };
+      if (ppl <= 1) go(std::integral_constant<int, 1>{});
+      else if (ppl == 2) go(std::integral_constant<int, 2>{});
+      else go(std::integral_constant<int, 3>{});
     }
+    GTICK(13)
     group_sync();                                                       // ---- Z: the new beams are complete
+    GTICK(14)
     all_blank = S.anychar_epoch != t;
     nb = n_sel;
     cur ^= 1;
@@ -555,6 +611,20 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   // every wavefront's back-pointer and log stores have reached L2 before wavefront 0 reads them back
   __syncthreads();
   if (wv != 0) return;
+#ifdef VASR_BEAM_PROF
+  S.hist[0][lane] = (int)pacc;
+  wave_sync();
+  if (lane == 0 && b == 0 && frames > 0) {
+    const int* P = S.hist[0];
+    const int gf = max(P[32], 1);
+    printf("group prof W=%d (cycles/frame over %d frames, wavefront 0): top %d candidates %d blank-exit %d LM %d expand %d B1wait %d merge %d "
+           "score %d B4wait %d live %d B5wait %d radix %d flags %d B6wait %d offsets+build %d Zwait %d | general frames %d pairs/gf %d "
+           "passes %d merge passes %d radix digits %d beams %d\n", W, frames, P[15] / frames, P[0] / frames, P[1] / frames, P[2] / frames,
+           P[3] / frames, P[4] / frames, P[5] / frames, P[6] / frames, P[7] / frames, P[8] / frames, P[9] / frames, P[10] / frames,
+           P[11] / frames, P[12] / frames, P[13] / frames, P[14] / frames, P[32], P[33] / gf, P[34], P[35], P[36], nb);
+  }
+  const unsigned pt_tail = (unsigned)__builtin_readcyclecounter();
+#endif
   const int n_log = S.n_log;
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best (as beam_wave.hip) ----
@@ -709,12 +779,18 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     out_len[b] = n;
     out_score[b] = (float)bs;
   }
+#ifdef VASR_BEAM_PROF
+  if (lane == 0 && b == 0) printf("group prof tail (final pass + trace-back): %u cycles\n", (unsigned)__builtin_readcyclecounter() - pt_tail);
+#endif
 }
 
 template <int W>
 int launch_group(const float* logp, int batch, int frames, int V1, int space_id, int beam_width, float token_min_logp,
                  float beam_prune_logp, const LmView& v, int use_lm, unsigned int* bp, unsigned long long* eoslog,
                  int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st, const int32_t* row_frames) {
+  static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in): the table alone is 72 KB
+  const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(beam_group_kernel<W>), (int)sizeof(GroupLds<W>), lds_opted);
+  if (attr != hipSuccess) return (int)attr;
   hipLaunchKernelGGL(beam_group_kernel<W>, dim3(batch), dim3(64 * W), sizeof(GroupLds<W>), st, logp, batch, frames, row_frames,
                      V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog, out_ids, out_len,
                      out_score);
@@ -726,9 +802,9 @@ int launch_group(const float* logp, int batch, int frames, int V1, int space_id,
 // wavefronts an utterance of a batch gets: 4 below 16 utterances (a lone utterance, a small serving batch: latency), 1 from
 // there on (beam_wave.hip: four utterances per compute unit, the chip left to the next acoustic pass)
 int beam_group_width(int batch) {
-  static const int force = dev_env("VASR_BEAM_GROUP") ? atoi(dev_env("VASR_BEAM_GROUP")) : -1;   // 0 | 1: never, 2, 4 (dev: A/B runs)
+  static const int force = dev_env("VASR_BEAM_GROUP") ? atoi(dev_env("VASR_BEAM_GROUP")) : -1;   // 0 | 1: never, 4: always (dev: A/B runs)
   if (force == 0 || force == 1) return 1;
-  if (force == 2 || force == 4) return force;
+  if (force == 4) return 4;
   return batch < 16 ? 4 : 1;
 }
 
@@ -749,8 +825,6 @@ int launch_beam_search_group(const float* logp, int batch, int frames, int V1, i
     v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
     v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
   }
-  if (W == 2) return launch_group<2>(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp,
-                                     eoslog, out_ids, out_len, out_score, st, row_frames);
   return launch_group<4>(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog,
                          out_ids, out_len, out_score, st, row_frames);
 }
