@@ -517,6 +517,26 @@ find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.cs
 cd $R; tail -3 $O/pytest.log; cat $O/smoke.log | tail -2; ls $O
 }
 
+# ---- final_r05: round-5 record: full GPU suite, smoke, kernel stats + PMC traffic of the bench, the default line (every config, latency,
+#      sol, box normalisers), configs 2 / 4 / 5 on their own, serving-shape latencies + their per-kernel table
+task_final_r05() {
+set -u
+TAG=${1:-r05}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; rm -f $R/gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+cp $R/gpurun_out/parity_errors.jsonl $O/parity_errors.jsonl 2>/dev/null
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+bash tools/profile_round.sh $TAG > $O/profile.log 2>&1
+for c in 2 4 5; do timeout 300 python bench.py --config $c --steps $([ $c = 5 ] && echo 5 || echo 20) --warmup 3 --no-other-gemm --no-cpu-baseline > $O/bench_c$c.json 2> $O/bench_c$c.err; done
+python tools/b1_serving.py > $O/b1_vi12x1.json 2> /dev/null
+python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_15x5.json 2> /dev/null
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b1 -- python $R/tools/b1_serving.py --calls 30 > /dev/null 2> $O/stats_b1.err
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*.db' -delete
+cd $R; tail -3 $O/pytest.log; cat $O/smoke.log | tail -2; ls $O
+}
+
 # ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them
 task_probes() {
 cd $R/tools/probes

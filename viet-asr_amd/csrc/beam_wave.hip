@@ -5,7 +5,7 @@
 // (infer.py:191) is the shape the reference SERVES.  pyctcdecode / kenlm are third-party and absent (parity unpinned);
 // the algorithm restated here is oracle/beam_oracle.py (file header there).
 //
-// Rounds 1-3 ran one 512-thread workgroup per utterance (beam.hip, kept in the devtools build): every frame crossed
+// Rounds 1-3 ran one 512-thread workgroup per utterance (beam.hip, retired in round 5): every frame crossed
 // ~20 workgroup barriers and every one of its eight wavefronts executed the whole ~5 000-instruction frame program --
 // 13 us per general frame although a frame of a pruned search has 30-150 (beam, character) pairs, less than one per
 // thread: the time was instruction issue and barrier latency, replicated eight times, not work.  This kernel gives an
@@ -14,7 +14,7 @@
 // frame really has (claimed table slots go on a list: nothing sweeps or clears the whole table), the log-probs of the
 // next frames are prefetched four deep, the LM score of a pending word is computed once per (text, word) lineage and
 // inherited, and the final trace-back walks the back-pointer rows through LDS in batches instead of one dependent HBM
-// round trip per frame.  An utterance needs 34 KB of LDS and 1 of the 16 wavefront slots a compute unit has, so four
+// round trip per frame.  An utterance needs 37.6 KB (38 528 bytes) of LDS (sizeof(WaveLds), pinned below) and 1 of the 16 wavefront slots a compute unit has, so four
 // utterances share a CU (one workgroup of `upw` independent wavefronts): a batch of 64 occupies 16 compute units instead
 // of 64 while the acoustic pass of the next batch runs on the rest.
 //
@@ -79,6 +79,7 @@ struct WaveLds {
   int hist[256];
 };
 static_assert(sizeof(WaveLds) * 4 <= 160 * 1024, "four utterances per compute unit");
+static_assert(sizeof(WaveLds) == 38528, "a new field changes the LDS per utterance: check that four still fit a compute unit, then update this number");
 static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
 static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
 
@@ -232,13 +233,18 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     const float* lq = S.lpq + (t & (kLpFrames - 1)) * V1;
     const float v0 = c0 < V1 ? fminf(fmaxf(lq[c0], -34.538776f), 0.f) : 0.f, v1 = c1 < V1 ? fminf(fmaxf(lq[c1], -34.538776f), 0.f) : 0.f;
     auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
-    const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
-    const unsigned kmax = wave_max_u32(max(key0, key1));
-    const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
-    const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
-    const bool k0 = c0 < V1 && (v0 >= token_min_logp || c0 == amax);
-    const bool k1 = c1 < V1 && (v1 >= token_min_logp || c1 == amax);
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    // candidates = {x >= token_min_logp} U {arg-max}: when any class passes the threshold the arg-max is among them already
+    // (round 5: the reduction for the arg-max is ~25 instructions of every frame's serial part)
+    bool k0 = c0 < V1 && v0 >= token_min_logp, k1 = c1 < V1 && v1 >= token_min_logp;
+    unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    if ((m0 | m1) == 0ull) {
+      const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+      const unsigned kmax = wave_max_u32(max(key0, key1));
+      const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+      const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
+      k0 = c0 == amax; k1 = c1 == amax;
+      m0 = __ballot(k0); m1 = __ballot(k1);
+    }
     if (k0) S.cand[rank_in(m0)] = (unsigned char)c0;
     if (k1) S.cand[__popcll(m0) + rank_in(m1)] = (unsigned char)c1;
     const int nc_all = __popcll(m0) + __popcll(m1);
@@ -477,11 +483,14 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         WCOUNT(6, 1)
         diff = ((unsigned long long)wave_or_u32((unsigned)(diff >> 32)) << 32) | wave_or_u32((unsigned)diff);
         // scores of live beams lie within beam_prune_logp of the best: their keys share the sign, the exponent and
-        // usually the top mantissa bits -- the leading digits all keys have in common cost no pass
-        const int same = diff ? __clzll((long long)diff) / 8 : 8;
-        if (same > 0) { mask = same == 8 ? ~0ull : (~0ull << (64 - 8 * same)); prefix = ubest & mask; }
+        // usually the top mantissa bits -- the leading BITS all keys have in common cost no pass: the first digit starts at
+        // the first bit in which they differ (round 5; byte-aligned digits wasted most of the first: 3.1 -> 2.4 digits per
+        // select at beam 100), the digits then walk down in steps of eight, the last clamped to bits 7..0 (an overlap with
+        // known bits is harmless: they match)
+        const int lead = diff ? __clzll((long long)diff) : 64;
+        if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
 #pragma unroll 1
-        for (int shift = 56 - 8 * same; shift >= 0; shift -= 8) {
+        for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
           WCOUNT(4, 1)
           for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
           wave_sync();
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
           const int whole = __builtin_amdgcn_readlane(f_whole, fl);
           prefix |= (unsigned long long)bucket << shift;
           mask |= 0xFFull << shift;
-          if (whole) break;       // the whole bucket is taken: no need to refine further
+          if (whole || shift == 0) break;       // the whole bucket is taken: no need to refine further
         }
       }
       WTICK(6)
