@@ -8,7 +8,7 @@
 // dependent instruction stream at ~10 cycles per instruction (profiles/r04_beam_sq_counters.txt): 4.3 ms at beam 100 on
 // 331 frames, 91-95 % of the serving latency.  Here the SAME algorithm -- same keys, same merge arithmetic (ordered-int
 // max, 2^-44 fixed-point sums: associative, hence independent of who adds first), same prune / radix select / rank rules --
-// is dealt over W = 4 wavefronts, one per SIMD (profiles/r05_beam_group.txt: 4.29 -> 1.99 ms at beam 100, 2.44 -> 1.42 at 50):
+// is dealt over W = 4 wavefronts, one per SIMD (profiles/r05_beam_group.txt: 4.30 -> 1.95 ms at beam 100, 2.45 -> 1.39 at 50):
 //
 //   * (beam, character) pair p lives in wavefront (p >> 6) % W, lane p & 63: a lane carries ceil(pairs / 256) pairs (1-3
 //     instead of 5-6) through expand / score / select; beams (LM refresh, children) are dealt one per THREAD;
@@ -40,12 +40,13 @@
 //     most of the first one: 3.1 -> 1.5 digits per frame at beam 100);
 //   * selected pairs of a frame's LAST pass build their children straight from the registers of the lane that owns them
 //     (no survivor records through LDS); frames of a blank run touch one beam per thread and skip every barrier;
-//   * log-probs and the candidate list are per-wavefront copies (each wavefront stages its own batch of eight frames): no
-//     barrier for either;
+//   * candidate characters depend on the frame alone: the four wavefronts list them for 32 frames at a time in parallel
+//     (eight frames each, records in LDS, two barriers per 32 frames) instead of repeating every frame's list in the serial
+//     loop;
 //   * the final pass (commit pending words, merge identical texts, trace-back) is wavefront 0 alone, as in beam_wave.hip.
 //
 // Results equal beam_wave.hip's bit for bit (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree, and every case of
-// the randomised comparison runs both forms).  Workgroup = 256 threads = one utterance; LDS 120 KB, one workgroup per CU.
+// the randomised comparison runs both forms).  Workgroup = 256 threads = one utterance; LDS ~136 KB, one workgroup per CU.
 // Used for batches of < 16 utterances (vasr_api.cpp); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
 #include <cstdlib>
 #include <type_traits>
@@ -88,8 +89,13 @@ struct GroupLds {
   int sel_src[kMaxBeams];
   double fin[kMaxBeams];
   unsigned long long cmix[kMaxClasses];
-  float lpq[W][kLpFrames * kMaxClasses];   // per wavefront
-  unsigned char cand[W][kMaxClasses];      // per wavefront
+  float lpq[W][kLpFrames * kMaxClasses];   // per wavefront: the log-probs of the eight frames whose candidates it lists
+  // candidate records of a chunk of 8 W frames, written by the pre-pass (wavefront w lists frames 8 w .. 8 w + 7 of the chunk):
+  // class ids and min(log-prob, 0) of the candidates in class order; header {count, has_space | only_blank << 1, bits of
+  // min(log-prob of blank, 0), 0}
+  unsigned char rc_cand[8 * W][kMaxClasses];
+  float rc_val[8 * W][kMaxClasses];
+  alignas(16) int rc_hdr[8 * W][4];
   int hist[3][256];
   // mailboxes
   // ... reduced by the LDS itself (one atomic per lane or per wavefront instead of a DPP reduction per wavefront -- ~25
@@ -179,8 +185,11 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
 #define GCOUNT(k, v)
 #endif
 
-  // log-probs: every wavefront stages its own copy of the batch of kLpFrames frames (beam_wave.hip says why they come
-  // through LDS and why the loads are unconditional)
+  // Candidate characters are a function of the frame alone, not of the beams: the four wavefronts list them for 32 frames
+  // at a time IN PARALLEL (eight frames each) instead of each repeating every frame's list in the serial loop -- 1 250 of a
+  // frame's 11 300 cycles at beam 50 were "loop top + candidates".  A wavefront stages the log-probs of ITS eight frames
+  // (requested one chunk ahead, unconditional clamped loads: beam_wave.hip says why) and writes the records to LDS.
+  constexpr int kChunk = 8 * W;
   float q[kLpRegs];
   const int lp_batch = kLpFrames * V1;
   auto lp_request = [&](int t0) __attribute__((always_inline)) {
@@ -190,9 +199,8 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < kLpRegs; ++k) q[k] = src[min(64 * k + lane, n - 1)];
   };
-  lp_request(0);
+  lp_request(kLpFrames * wv);
   float* lpq = S.lpq[wv];
-  unsigned char* cand = S.cand[wv];
 
   // One new beam at rank r from pair (parent bi, character c) with merged logit bits lgt
   auto build_child = [&](int t, int r, int src, long long lgt, bool has_space) __attribute__((always_inline)) {
@@ -241,40 +249,60 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   };
 
   for (int t = 0; t < frames; ++t) {
-    // ---- 1. candidate characters (every wavefront for itself: same values everywhere) ----
-    const int c0 = lane, c1 = lane + 64;
+    // ---- 1. candidate characters: from the chunk's records (pre-pass at every chunk boundary) ----
     GTICK(15)
-    if ((t & (kLpFrames - 1)) == 0) {
+    if ((t & (kChunk - 1)) == 0) {
+      group_sync();                        // the previous chunk's records (and frame t - 1's beams) are done with
+      dirty = false;
 #pragma unroll
       for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) lpq[64 * k + lane] = q[k];
-      lp_request(t + kLpFrames);
+      lp_request(t + kChunk + kLpFrames * wv);
       wave_sync();
+      const int c0 = lane, c1 = lane + 64;
+#pragma unroll 1
+      for (int f = 0; f < kLpFrames; ++f) {
+        const int tt = t + kLpFrames * wv + f;
+        if (tt >= frames) break;
+        const int fr = tt & (kChunk - 1);
+        const float* lq = lpq + f * V1;
+        const float x0 = c0 < V1 ? lq[c0] : 0.f, x1 = c1 < V1 ? lq[c1] : 0.f;
+        // pyctcdecode works on log(clip(p, 1e-15, 1)) = clip(x, log 1e-15, 0); for a class that can be a candidate that is min(x, 0)
+        const float v0 = fminf(fmaxf(x0, -34.538776f), 0.f), v1 = fminf(fmaxf(x1, -34.538776f), 0.f);
+        auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
+        // candidates = {x >= token_min_logp} U {arg-max}: when any class passes the threshold the arg-max is among them already
+        bool k0 = c0 < V1 && v0 >= token_min_logp, k1 = c1 < V1 && v1 >= token_min_logp;
+        unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        if ((m0 | m1) == 0ull) {
+          const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
+          const unsigned kmax = wave_max_u32(max(key0, key1));
+          const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
+          const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
+          k0 = c0 == amax; k1 = c1 == amax;
+          m0 = __ballot(k0); m1 = __ballot(k1);
+        }
+        if (k0) { const int r = rank_in(m0); S.rc_cand[fr][r] = (unsigned char)c0; S.rc_val[fr][r] = fminf(x0, 0.f); }
+        if (k1) { const int r = __popcll(m0) + rank_in(m1); S.rc_cand[fr][r] = (unsigned char)c1; S.rc_val[fr][r] = fminf(x1, 0.f); }
+        const int n_c = __popcll(m0) + __popcll(m1);
+        const bool sp = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
+        const bool ob = n_c == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
+        if (lane == 0) {
+          S.rc_hdr[fr][0] = n_c; S.rc_hdr[fr][1] = (sp ? 1 : 0) | (ob ? 2 : 0);
+          S.rc_hdr[fr][2] = __float_as_int(fminf(lq[V], 0.f));
+        }
+      }
+      group_sync();
     }
-    const float* lq = lpq + (t & (kLpFrames - 1)) * V1;
-    const float v0 = c0 < V1 ? fminf(fmaxf(lq[c0], -34.538776f), 0.f) : 0.f, v1 = c1 < V1 ? fminf(fmaxf(lq[c1], -34.538776f), 0.f) : 0.f;
-    auto okey = [](float v) { const unsigned q = __float_as_uint(v); return (q & 0x80000000u) ? ~q : (q | 0x80000000u); };
-    // candidates = {x >= token_min_logp} U {arg-max}: when any class passes the threshold the arg-max is among them already
-    bool k0 = c0 < V1 && v0 >= token_min_logp, k1 = c1 < V1 && v1 >= token_min_logp;
-    unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-    if ((m0 | m1) == 0ull) {
-      const unsigned key0 = c0 < V1 ? okey(v0) : 0u, key1 = c1 < V1 ? okey(v1) : 0u;
-      const unsigned kmax = wave_max_u32(max(key0, key1));
-      const unsigned long long a0 = __ballot(c0 < V1 && key0 == kmax), a1 = __ballot(c1 < V1 && key1 == kmax);
-      const int amax = a0 ? __ffsll((long long)a0) - 1 : 64 + __ffsll((long long)a1) - 1;   // first maximum
-      k0 = c0 == amax; k1 = c1 == amax;
-      m0 = __ballot(k0); m1 = __ballot(k1);
-    }
-    if (k0) cand[rank_in(m0)] = (unsigned char)c0;
-    if (k1) cand[__popcll(m0) + rank_in(m1)] = (unsigned char)c1;
-    const int nc_all = __popcll(m0) + __popcll(m1);
-    const bool has_space = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
-    const bool only_blank = nc_all == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
-    wave_sync();
+    const int fr = t & (kChunk - 1);
+    const unsigned char* cand = S.rc_cand[fr];
+    const float* cval = S.rc_val[fr];
+    const int4 hdr = *reinterpret_cast<const int4*>(&S.rc_hdr[fr][0]);
+    const int nc_all = __builtin_amdgcn_readfirstlane(hdr.x);
+    const bool has_space = __builtin_amdgcn_readfirstlane(hdr.y) & 1, only_blank = __builtin_amdgcn_readfirstlane(hdr.y) & 2;
     GTICK(0)
 
     // a blank-only frame met by beams that all end in blank: one beam per thread, nothing crosses wavefronts
     if (only_blank && all_blank) {
-      const double add = (double)fminf(lq[V], 0.f);
+      const double add = (double)__int_as_float(__builtin_amdgcn_readfirstlane(hdr.z));
       for (int i = tid; i < nb; i += 64 * W) {
         S.logit[cur][i] += add;
         bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
@@ -345,11 +373,12 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         if (p < npairs) act |= 1u << j;
         const int pp = min(p, npairs - 1);
         const int bi = (int)(((float)pp + 0.5f) * inv_nc);
-        const int c = cand[c_lo + pp - bi * nc];
+        const int ci = c_lo + pp - bi * nc;
+        const int c = cand[ci];
         const unsigned m = S.meta[cur][bi];
         const int last = meta_last(m);
         unsigned long long key = S.key[cur][bi];
-        score[j] = S.logit[cur][bi] + (double)fminf(lq[c], 0.f);
+        score[j] = S.logit[cur][bi] + (double)cval[ci];
         src[j] = (bi << 8) | c;
         const bool grows = !(c == V || c == last) && !(c == space_id && meta_wlen(m) == 0);
         const unsigned long long kx = hmix(key, (unsigned long long)c);
