@@ -648,6 +648,21 @@ echo "== section counters (var_gprof.so)"; VASR_LIB_PATH=$R/viet-asr_amd/lib/var
 cat $O/beam.txt
 }
 
+# ---- r5f: front-end iteration: the front-end / golden / edge-case tests, the front-end fuzz, then the default bench line's class times
+task_r5f() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5f}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round3.py -x -q -m gpu -k "golden or stage or edge or stft or front or independent or batch_size" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 600 python tests/devtools/fuzz_frontend.py 200 2>&1 | grep -v amdgpu | tail -3
+for i in 1 2; do python bench.py --no-cpu-baseline --no-other-gemm --no-side-configs 2>/dev/null | python -c "
+import sys, json
+j = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('step %.3f ms  other %s  box %s' % (j['ms_per_step'], j['other_ms_per_step'], j['box']))"; done
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-gemm --no-side-configs > /dev/null 2> $O/stats.err
+f=$(find $O/stats -name '*kernel_stats.csv' | head -1); grep -E "stft|normalize" $f | cut -c1-160
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+}
+
 task=${1:-list}; shift || true
 if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
 if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi
