@@ -135,7 +135,8 @@ def test_config4_quartznet15x5_beam128_lm_b64(gpu, tmp_path):
       (b) CTC-like log-probs of the same shape spelling words of the LM's vocabulary (synth.ctc_like_log_probs), where
           beams branch, merge and are re-ranked by the LM at word boundaries: the LM must change at least one
           transcript, and scores must agree with the oracle.
-    Every row: determinism, label range, normalised spacing, finite score."""
+    Every row: determinism, label range, normalised spacing, finite score, and (round 5) the same bits from the
+    four-wavefront kernel as from the one-wavefront kernel."""
     from viet_asr_amd import synth
     from viet_asr_amd.beam import BeamSearchDecoder
     from oracle import beam_oracle as BO
@@ -164,6 +165,16 @@ def test_config4_quartznet15x5_beam128_lm_b64(gpu, tmp_path):
             assert (ids[b, : n[b]] >= 0).all() and (ids[b, : n[b]] < 28).all()
             assert "  " not in t and t == t.strip(), (tag, b, t[:60])
         _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag)
+        # round 5: ALL 64 rows cross-checked between the two independent kernel forms -- the batch went through beam_wave.hip
+        # (one wavefront per utterance), slices of 8 rows go through beam_group.hip (four wavefronts per utterance, twice the
+        # pairs per pass): hypotheses, lengths and scores must be the same bits (the Python oracle covers the rows above)
+        for b0 in range(0, 64, 8):
+            ids_g, n_g, score_g = dec.decode_ids(logp[b0:b0 + 8].contiguous(), 128)
+            assert np.array_equal(n_g.cpu().numpy(), n[b0:b0 + 8]), (tag, b0)
+            assert np.array_equal(score_g.cpu().numpy(), score[b0:b0 + 8]), (tag, b0)
+            ig = ids_g.cpu().numpy()
+            for r_ in range(8):
+                assert np.array_equal(ig[r_, : n[b0 + r_]], ids[b0 + r_, : n[b0 + r_]]), (tag, b0 + r_)
         if tag == "ctc-like":
             plain = nolm.decode_batch(logp, 128)
             changed = sum(a != b for a, b in zip(plain, texts))
