@@ -534,7 +534,11 @@ python tools/b1_serving.py --model quartznet15x5 --seconds 10 --no-beam > $O/b1_
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b1 -- python $R/tools/b1_serving.py --calls 30 > /dev/null 2> $O/stats_b1.err
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*.db' -delete
-cd $R; tail -3 $O/pytest.log; cat $O/smoke.log | tail -2; ls $O
+cd $R
+# the tile a CTC head folded into the 512 -> 1024 GEMM would need (1024 x 64 on 8 wavefronts: spills), against the shipped rule, kernel-only
+{ echo "== 512 -> 1024, tile rule"; VASR_BENCH_KEEP_AMAX=1 python tools/bench_pw.py 512 1024 2>&1 | grep -v amdgpu
+  echo "== 512 -> 1024, 1024 x 64 tile (VASR_PW3_TILE=9)"; VASR_BENCH_KEEP_AMAX=1 VASR_PW3_TILE=9 python tools/bench_pw.py 512 1024 2>&1 | grep -v amdgpu; } > $O/head_fold_tile.txt 2>&1
+tail -3 $O/pytest.log; cat $O/smoke.log | tail -2; cat $O/head_fold_tile.txt; ls $O
 }
 
 # ---- probes: build the HIP probes from their sources (the binaries are not tracked) and run them

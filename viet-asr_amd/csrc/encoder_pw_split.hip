@@ -727,7 +727,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[9] = {0, 512, 256, 128, 64, 256, 256, 32, 512};
+  const int rows[10] = {0, 512, 256, 128, 64, 256, 256, 32, 512, 1024};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
@@ -751,7 +751,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     const int64_t n1 = blocks(512, 128), rounds = (n1 + cus - 1) / cus;
     if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
-  if (force >= 1 && force <= 8 && a.M % rows[force] == 0) tile = force;
+  if (force >= 1 && force <= 9 && a.M % rows[force] == 0) tile = force;
   // Small batches (the 64 x 32 tile's territory: <= 5 utterances of 10 s at 512 channels): the whole K range in ONE trip to
   // memory instead of K / 64 dependent chunk steps -- encoder_pw_lat.hip, same bits.  VASR_PW_LAT=0 keeps the chunked kernel,
   // =2 extends the latency kernel to the 128 x 64 tile's batches (dev: A/B runs).
@@ -772,6 +772,9 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     // slower than one 512 x 128 workgroup: 57.5 vs 54.6 us on a 512-channel layer; one wavefront per SIMD and workgroup does
     // not cover its own waits, and every workgroup converts the whole activation tile again)
     case 8: return launch_t<8, 2, 2>(a, arith, st, amax_n);   // 512 x 64 (dev: half-filled chips, configs[1])
+#ifdef VASR_DEVTOOLS
+    case 9: return launch_t<8, 4, 2>(a, arith, st, amax_n);   // 1024 x 64 (dev, round 5: the tile a CTC head folded into the last GEMM would need)
+#endif
     case 7: return launch_t<1, 1, 1>(a, arith, st, amax_n);   // 32 x 32 on one wavefront (dev: batch-1 experiment)
     case 3: return launch_t<4, 1, 2>(a, arith, st, amax_n);
     default: return launch_t<2, 1, 1>(a, arith, st, amax_n);
