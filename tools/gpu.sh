@@ -36,63 +36,6 @@ PY
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
 }
 
-# ---- beamcmp: 
-task_beamcmp() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-for f in $R/viet-asr_amd/lib/libvasr_hip_dev.so $R/viet-asr_amd/lib/var_t512s1024.so; do
-  export VASR_LIB_PATH=$f; echo "== $(basename $f)"; python tests/devtools/bench_beam.py 2>&1 | grep -v amdgpu
-done
-}
-
-# ---- beamgroup: 
-task_beamgroup() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
-MODE=base python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
-export VASR_LIB_PATH=$R/viet-asr_amd/lib/var_t512s1024.so
-for m in base group group_nomask half; do MODE=$m python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1; done
-MODE=half NCU=32 python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
-MODE=group NCU=128 python tools/probes/beam_group.py 2>&1 | grep -v amdgpu | tail -1
-}
-
-# ---- beampack: 
-task_beampack() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-for f in dev $R/viet-asr_amd/lib/var_*.so; do
-  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
-  echo "== $(basename $f)"; python tools/probes/beam_pack.py 2>&1 | grep -v amdgpu | tail -5
-done
-}
-
-# ---- beamprof: 
-task_beamprof() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-export VASR_LIB_PATH=$R/viet-asr_amd/lib/var_prof.so
-python tools/probes/beam_slots.py 2>&1 | grep -v amdgpu | grep "beam prof" | awk 'NR==61||NR==93||NR==96||NR==77||NR==29'
-}
-
-# ---- beamslots: 
-task_beamslots() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so
-for s in 512 1024 2048 auto; do
-  [ $s = auto ] && unset VASR_BEAM_SLOTS || export VASR_BEAM_SLOTS=$s
-  python tools/probes/beam_slots.py 2>&1 | grep -v amdgpu | tail -1
-done
-unset VASR_BEAM_SLOTS VASR_LIB_PATH
-timeout 900 python -m pytest tests/test_beam.py -m gpu -q -p no:cacheprovider -x 2>&1 | tail -2
-}
-
-# ---- beamvar: 
-task_beamvar() {
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-for f in dev $R/viet-asr_amd/lib/var_*.so; do
-  [ $f = dev ] && export VASR_LIB_PATH=$R/viet-asr_amd/lib/libvasr_hip_dev.so || export VASR_LIB_PATH=$f
-  echo "== $(basename $f)"; python tests/devtools/bench_beam.py 2>&1 | grep -v amdgpu | grep "128"
-  timeout 300 python tests/devtools/fuzz_beam.py 150 0 2>&1 | tail -1
-done
-}
-
 # ---- c5prof: 
 task_c5prof() {
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-c5prof}; mkdir -p $O
@@ -362,7 +305,7 @@ find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
 cd $R; tail -5 $O/pytest.log; cat $O/b1_vi.json $O/b1_15x5.json $O/b8_15x5.json
 }
 
-# ---- beamlat: beam-search latency of the default dev library and every var_*.so (tools/probes/beam_lat.py), table sizes from $SLOTS
+# ---- beamlat: beam-search latency of the default dev library and every var_*.so (tools/probes/beam_lat.py)
 task_beamlat() {
 cd $R
 for f in dev $R/viet-asr_amd/lib/var_*.so; do
@@ -370,10 +313,7 @@ for f in dev $R/viet-asr_amd/lib/var_*.so; do
   case $f in
     *prof*|*p.so) echo "== $(basename $f) (section cycle counters, one launch per case)"
         ONCE=1 BATCHES=1 WIDTHS=${PROF_WIDTHS:-50,100} python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu | grep -E "prof|/B1/" ;;
-    *) for s in ${SLOTS:-auto}; do
-         [ $s = auto ] && unset VASR_BEAM_SLOTS || export VASR_BEAM_SLOTS=$s
-         echo "== $(basename $f) slots $s"; python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu
-       done; unset VASR_BEAM_SLOTS ;;
+    *) echo "== $(basename $f)"; python tools/probes/beam_lat.py 2>&1 | grep -v amdgpu ;;
   esac
 done
 unset VASR_LIB_PATH
