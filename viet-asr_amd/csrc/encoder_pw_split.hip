@@ -773,6 +773,7 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     // not cover its own waits, and every workgroup converts the whole activation tile again)
     case 8: return launch_t<8, 2, 2>(a, arith, st, amax_n);   // 512 x 64 (dev: half-filled chips, configs[1])
 #ifdef VASR_DEVTOOLS
+    // (128 x 32 tiles for the CTC head -- four workgroups per CU -- measured 39.9 us against 35.4 for the 128 x 64 tile: not kept)
     case 9: return launch_t<8, 4, 2>(a, arith, st, amax_n);   // 1024 x 64 (dev, round 5: the tile a CTC head folded into the last GEMM would need)
 #endif
     case 7: return launch_t<1, 1, 1>(a, arith, st, amax_n);   // 32 x 32 on one wavefront (dev: batch-1 experiment)
