@@ -8,7 +8,7 @@
 // dependent instruction stream at ~10 cycles per instruction (profiles/r04_beam_sq_counters.txt): 4.3 ms at beam 100 on
 // 331 frames, 91-95 % of the serving latency.  Here the SAME algorithm -- same keys, same merge arithmetic (ordered-int
 // max, 2^-44 fixed-point sums: associative, hence independent of who adds first), same prune / radix select / rank rules --
-// is dealt over W = 4 wavefronts, one per SIMD (profiles/r05_beam_group.txt: 4.30 -> 1.95 ms at beam 100, 2.45 -> 1.39 at 50):
+// is dealt over W = 4 wavefronts, one per SIMD (profiles/r05_beam_group.txt: 4.30 -> 1.83 ms at beam 100, 2.45 -> 1.28 at 50):
 //
 //   * (beam, character) pair p lives in wavefront (p >> 6) % W, lane p & 63: a lane carries ceil(pairs / 256) pairs (1-3
 //     instead of 5-6) through expand / score / select; beams (LM refresh, children) are dealt one per THREAD;
@@ -17,11 +17,10 @@
 //       B1 after the claims (all pairs sit in the table; merged slots know their contributors' maximum)
 //       B3 after the contributors' fixed-point adds            -- only on frames where two pairs merged
 //       B4 the best combined score (prune threshold)
-//       B5 live entries + differing key bits                   -- only when more entries than beam_width were claimed
 //       R  one per radix digit of the select (histogram buffers rotate: no clearing barrier)
 //       B6 per-block (greater, equal) counts -> every wavefront computes every rank offset itself
 //       Z  end of frame (children complete)
-//     5-8 barriers of 4 wavefronts per general frame (50-500 cycles each, measured) against ~20 of 8 in the workgroup kernel
+//     4-7 barriers of 4 wavefronts per general frame (50-500 cycles each, measured) against ~20 of 8 in the workgroup kernel
 //     of rounds 1-3;
 //   * workgroup-wide reductions (best score, live count, differing bits, claimed count) are LDS atomics on one word -- the
 //     LDS serialises the lanes, one instruction per wavefront -- instead of a DPP reduction per wavefront (~25 instructions,
@@ -36,8 +35,9 @@
 //     (tests/devtools/fuzz_beam.py: 400 cases bit-equal to the one-wavefront kernel, which passes at 358);
 //   * a claimer leaves its score in the slot (tsc) so that a contributor can form max(contributors, claimer) itself: the
 //     single-wavefront kernel's "claimer raises the maximum" step and its barrier are gone, the sums are the same integers;
-//   * the first radix digit of a select starts at the first BIT in which the live keys differ (byte-aligned digits wasted
-//     most of the first one: 3.1 -> 1.5 digits per frame at beam 100);
+//   * the first radix digit of a select starts at the first BIT in which the best score and the prune threshold differ
+//     (byte-aligned digits wasted most of the first one: 3.1 -> 1.5 digits per frame at beam 100), and its histogram's total is
+//     the live count: no separate count / barrier;
 //   * selected pairs of a frame's LAST pass build their children straight from the registers of the lane that owns them
 //     (no survivor records through LDS); frames of a blank run touch one beam per thread and skip every barrier;
 //   * candidate characters depend on the frame alone: the four wavefronts list them for 32 frames at a time in parallel
@@ -96,14 +96,13 @@ struct GroupLds {
   unsigned char rc_cand[8 * W][kMaxClasses];
   float rc_val[8 * W][kMaxClasses];
   alignas(16) int rc_hdr[8 * W][4];
-  int hist[3][256];
+  alignas(16) int hist[3][256];             // radix histograms, bins in DESCENDING digit order (bin 255 - digit)
   // mailboxes
   // ... reduced by the LDS itself (one atomic per lane or per wavefront instead of a DPP reduction per wavefront -- ~25
   // instructions each at a lone wavefront's ~10 cycles per instruction -- plus a mailbox per wavefront); two sets, used by
   // alternate passes: thread 0 resets the other set right after B4
   long long red_best[2];
-  unsigned long long red_diff[2];
-  int red_claimed[2], red_live[2];
+  int red_claimed[2];
   int mb_gt[kMaxBlocks], mb_eq[kMaxBlocks];
   int merge_epoch, anychar_epoch;
   int n_log;
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     if (use_lm) S.ctx[0][0][kMaxCtx - 1] = lm.bos;
     S.commit_lmd[0][0] = 0.f; S.commit_wid[0][0] = 0;
     S.merge_epoch = -1; S.anychar_epoch = -1; S.n_log = 0;
-    for (int k = 0; k < 2; ++k) { S.red_best[k] = ord64(-1e300); S.red_diff[k] = 0; S.red_claimed[k] = 0; S.red_live[k] = 0; }
+    for (int k = 0; k < 2; ++k) { S.red_best[k] = ord64(-1e300); S.red_claimed[k] = 0; }
   }
   group_sync();
   int cur = 0, nb = 1, epoch = 0;
@@ -483,73 +482,75 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       const int n_claimed_all = S.red_claimed[epoch & 1] + n_sel;       // + the carried survivors
       if (tid == 0) {   // the other set: last read a pass ago, next written after this pass's B6
         const int o = (epoch + 1) & 1;
-        S.red_best[o] = ord64(-1e300); S.red_diff[o] = 0; S.red_claimed[o] = 0; S.red_live[o] = 0;
+        S.red_best[o] = ord64(-1e300); S.red_claimed[o] = 0;
       }
       // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
       const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
       const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
       unsigned live = 0;
-      int my_live = 0;
-      unsigned long long diff = 0;
 #pragma unroll
       for (int j = 0; j < PPL + NC; ++j) {
         const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
         const bool lv = j < PPL ? ((claimed >> j & 1) && tt >= thr_prune) : (wv == 0 && lane + 64 * (j - PPL) < n_sel && tt >= thr_prune);
-        if (lv) { live |= 1u << j; diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest; }
-        my_live += __popcll(__ballot(lv));
+        if (lv) live |= 1u << j;
       }
       unsigned long long prefix = 0, mask = 0;
       int want = beam_width;
       if (n_claimed_all > beam_width) {                                 // (uniform over the workgroup) only then can a select be needed
-        if (diff) atomicOr(&S.red_diff[epoch & 1], diff);
-        if (lane == 0 && my_live) atomicAdd(&S.red_live[epoch & 1], my_live);
-        GTICK(8)
-        group_sync();                                                   // ---- B5
-        GTICK(9)
-        const int tot_live = S.red_live[epoch & 1];
-        diff = S.red_diff[epoch & 1];
-        if (tot_live > beam_width) {
-          // the live keys agree in their `lead` leading bits (scores within beam_prune_logp of the best: sign, exponent and
-          // the top of the mantissa): the FIRST digit starts at the first bit in which they differ -- not at the next byte
-          // boundary, which wasted most of a digit: 3.1 digits per select at beam 100 -- and the digits then walk down in
-          // steps of eight, the last one clamped to bits 7..0 (an overlap with known bits is harmless: they match)
-          const int lead = diff ? __clzll((long long)diff) : 64;
-          if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
-          // Histogram buffers rotate with a running digit count: digit hd adds into hist[hd % 3] -- cleared during digit
-          // hd - 1 (or at the start) -- and clears hist[(hd + 1) % 3], last READ during digit hd - 2, which every wavefront
-          // has left behind when it passed the barrier of digit hd - 1.  No clearing barrier.
+        // Every live key lies between the prune threshold and the best score, so the leading bits those two have in common
+        // (sign, exponent, the top of the mantissa) are common to all of them: the first digit starts at the first bit in
+        // which they differ -- known to every wavefront from `best` alone.  (An earlier version counted the live entries and
+        // OR-ed their differing bits over the workgroup first: one more barrier and two atomics per select frame, for a
+        // first digit that started at most a bit or two lower.)  The first histogram's total IS the live count: if it does
+        // not exceed beam_width nothing is selected away.  Digits then walk down in steps of eight, the last one clamped to
+        // bits 7..0 (an overlap with known bits is harmless: they match).
+        const unsigned long long ulo = (unsigned long long)thr_prune ^ 0x8000000000000000ull;
+        const unsigned long long d0 = ubest ^ ulo;
+        const int lead = d0 ? __clzll((long long)d0) : 64;
+        if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
+        bool first = true;
+        // Histogram buffers rotate with a running digit count: digit hd adds into hist[hd % 3] -- cleared during digit
+        // hd - 1 (or at the start) -- and clears hist[(hd + 1) % 3], last READ during digit hd - 2, which every wavefront
+        // has left behind when it passed the barrier of digit hd - 1.  No clearing barrier.
 #pragma unroll 1
-          for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
-            int* h = S.hist[hd % 3];
-            int* hn = S.hist[(hd + 1) % 3];
-            ++hd;
+        for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
+          int* h = S.hist[hd % 3];
+          int* hn = S.hist[(hd + 1) % 3];
+          ++hd;
 #pragma unroll
-            for (int j = 0; j < PPL + NC; ++j) {
-              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
-              if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&h[(int)((u >> shift) & 255)], 1);
-            }
-            for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;          // the next digit's buffer (last read two digits ago)
-            group_sync();                                               // ---- R
-            GCOUNT(4, 1)
-            int cnt[4], mine = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { cnt[j] = h[255 - (4 * lane + j)]; mine += cnt[j]; }
-            int above = wave_scan_incl(mine) - mine;
-            int f_bucket = -1, f_want = 0, f_whole = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
-              above += cnt[j];
-            }
-            const unsigned long long fm = __ballot(f_bucket >= 0);
-            const int fl = __ffsll((long long)fm) - 1;
-            const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
-            want = __builtin_amdgcn_readlane(f_want, fl);
-            const int whole = __builtin_amdgcn_readlane(f_whole, fl);
-            prefix |= (unsigned long long)bucket << shift;
-            mask |= 0xFFull << shift;
-            if (whole || shift == 0) break;
+          for (int j = 0; j < PPL + NC; ++j) {
+            const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+            if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&h[255 - (int)((u >> shift) & 255)], 1);
           }
+          for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;          // the next digit's buffer (last read two digits ago)
+          GTICK(8)
+          group_sync();                                               // ---- R
+          GTICK(9)
+          GCOUNT(4, 1)
+          // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
+          const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
+          const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+          const int mine = (c4.x + c4.y) + (c4.z + c4.w);
+          const int incl = wave_scan_incl(mine);
+          if (first) {
+            first = false;
+            if (__builtin_amdgcn_readlane(incl, 63) <= want) { mask = 0; prefix = 0; break; }   // no more live entries than beams
+          }
+          int above = incl - mine;
+          int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+            above += cnt[j];
+          }
+          const unsigned long long fm = __ballot(f_bucket >= 0);
+          const int fl = __ffsll((long long)fm) - 1;
+          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+          want = __builtin_amdgcn_readlane(f_want, fl);
+          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
+          prefix |= (unsigned long long)bucket << shift;
+          mask |= 0xFFull << shift;
+          if (whole || shift == 0) break;
         }
       }
       GTICK(10)
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     const int* P = S.hist[0];
     const int gf = max(P[32], 1);
     printf("group prof W=%d (cycles/frame over %d frames, wavefront 0): top %d candidates %d blank-exit %d LM %d expand %d B1wait %d merge %d "
-           "score %d B4wait %d live %d B5wait %d radix %d flags %d B6wait %d offsets+build %d Zwait %d | general frames %d pairs/gf %d "
+           "score %d B4wait %d live+hist %d Rwait %d radix-search %d flags %d B6wait %d offsets+build %d Zwait %d | general frames %d pairs/gf %d "
            "passes %d merge passes %d radix digits %d beams %d\n", W, frames, P[15] / frames, P[0] / frames, P[1] / frames, P[2] / frames,
            P[3] / frames, P[4] / frames, P[5] / frames, P[6] / frames, P[7] / frames, P[8] / frames, P[9] / frames, P[10] / frames,
            P[11] / frames, P[12] / frames, P[13] / frames, P[14] / frames, P[32], P[33] / gf, P[34], P[35], P[36], nb);

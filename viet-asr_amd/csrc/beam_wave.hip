@@ -469,25 +469,25 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
       unsigned live = 0;                // bit j: entry j survives the prune; bits PPL, PPL + 1: the carried survivors
       int tot_live = 0;
-      unsigned long long diff = 0;      // OR of (key ^ best key) over the live keys: where they first differ
 #pragma unroll
       for (int j = 0; j < PPL + 2; ++j) {
         const long long tt = j < PPL ? tot[j] : c_tot[j - PPL];
         const bool lv = j < PPL ? ((claimed >> j & 1) && tt >= thr_prune) : (lane + 64 * (j - PPL) < n_sel && tt >= thr_prune);
-        if (lv) { live |= 1u << j; diff |= ((unsigned long long)tt ^ 0x8000000000000000ull) ^ ubest; }
+        if (lv) live |= 1u << j;
         tot_live += __popcll(__ballot(lv));
       }
       unsigned long long prefix = 0, mask = 0;
       int want = beam_width;
       if (tot_live > beam_width) {
         WCOUNT(6, 1)
-        diff = ((unsigned long long)wave_or_u32((unsigned)(diff >> 32)) << 32) | wave_or_u32((unsigned)diff);
-        // scores of live beams lie within beam_prune_logp of the best: their keys share the sign, the exponent and
-        // usually the top mantissa bits -- the leading BITS all keys have in common cost no pass: the first digit starts at
-        // the first bit in which they differ (round 5; byte-aligned digits wasted most of the first: 3.1 -> 2.4 digits per
-        // select at beam 100), the digits then walk down in steps of eight, the last clamped to bits 7..0 (an overlap with
-        // known bits is harmless: they match)
-        const int lead = diff ? __clzll((long long)diff) : 64;
+        // every live key lies between the prune threshold and the best score: the leading BITS those two have in common
+        // (sign, exponent, the top of the mantissa) are common to all of them and cost no pass -- the first digit starts at the
+        // first bit in which they differ (round 5: byte-aligned digits wasted most of the first one, 3.1 -> 2.4 digits per select
+        // at beam 100, and OR-ing the live keys' differing bits over the wavefront was two reductions for at most a bit or
+        // two more), the digits then walk down in steps of eight, the last clamped to bits 7..0 (an overlap with known bits
+        // is harmless: they match)
+        const unsigned long long d0 = ubest ^ ((unsigned long long)thr_prune ^ 0x8000000000000000ull);
+        const int lead = d0 ? __clzll((long long)d0) : 64;
         if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
 #pragma unroll 1
         for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
