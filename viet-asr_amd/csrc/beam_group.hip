@@ -454,7 +454,11 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           const bool stay = (c == V || c == last);
           const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
           const float commit = S.commit_lmd[cur][bi];
-          lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new) + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
+          // partial_penalty(unk_offset, wlen_new), its division only when some lane's pending word is longer than six
+          // characters (as a select the compiler runs the ~12-instruction division in every frame)
+          float pen = wlen_new > 0 ? lm.unk_offset : 0.f;
+          if (__ballot(wlen_new > 6) != 0ull) pen = wlen_new > 6 ? pen * (float)wlen_new / 6.0f : pen;
+          lmt = S.lm_text[cur][bi] + pen + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
         }
         double logit = score[j];
         if (mine) {
