@@ -15,12 +15,11 @@
 //   * the merge table, the beams and the radix histogram are shared in LDS (LDS atomics work across the wavefronts of a
 //     workgroup); what one wavefront needs from the others crosses at LDS-only barriers:
 //       B1 after the claims (all pairs sit in the table; merged slots know their contributors' maximum)
-//       B3 after the contributors' fixed-point adds            -- only on frames where two pairs merged
 //       B4 the best combined score (prune threshold)
 //       R  one per radix digit of the select (histogram buffers rotate: no clearing barrier)
 //       B6 per-block (greater, equal) counts -> every wavefront computes every rank offset itself
 //       Z  end of frame (children complete)
-//     4-7 barriers of 4 wavefronts per general frame (50-500 cycles each, measured) against ~20 of 8 in the workgroup kernel
+//     4-6 barriers of 4 wavefronts per general frame (50-500 cycles each, measured) against ~20 of 8 in the workgroup kernel
 //     of rounds 1-3;
 //   * workgroup-wide reductions (best score, live count, differing bits, claimed count) are LDS atomics on one word -- the
 //     LDS serialises the lanes, one instruction per wavefront -- instead of a DPP reduction per wavefront (~25 instructions,
@@ -33,8 +32,11 @@
 //     selected SET is the top-k of the union in both forms; only the ORDER of the new beams differs (one pass: pair order;
 //     several: last pass's pairs, then carried survivors), and the order only breaks exact ties of 64-bit scores
 //     (tests/devtools/fuzz_beam.py: 400 cases bit-equal to the one-wavefront kernel, which passes at 358);
-//   * a claimer leaves its score in the slot (tsc) so that a contributor can form max(contributors, claimer) itself: the
-//     single-wavefront kernel's "claimer raises the maximum" step and its barrier are gone, the sums are the same integers;
+//   * a pair that finds its key already claimed (a contributor) leaves its SCORE in the slot -- a prefix (text, last
+//     character) is reached by at most four pairs: from the two beams that share its text (ending in blank / in its last
+//     character) and from the two that share the text one character shorter --, and the claimer forms the log-sum-exp of all
+//     of them after B1: maximum, then the terms as 2^-44 fixed-point integers, the same integers the one-wavefront kernel
+//     adds atomically; its "raise the maximum", "add the terms" phases, their barrier and the 64-bit LDS atomics are gone;
 //   * the first radix digit of a select starts at the first BIT in which the best score and the prune threshold differ
 //     (byte-aligned digits wasted most of the first one: 3.1 -> 1.5 digits per frame at beam 100), and its histogram's total is
 //     the live count: no separate count / barrier;
@@ -81,10 +83,8 @@ struct GroupLds {
   float commit_lmd[2][kMaxBeams];
   int commit_wid[2][kMaxBeams];
   unsigned long long tkey[kTab];
-  long long tmx[kTab];                     // ordered bits of the CONTRIBUTORS' maximum (-1e300: none)
-  unsigned long long tsum[kTab];
-  double tsc[kTab];                        // the claimer's score
-  int tsrc[kTab];
+  double tcs[kTab][3];                     // scores of the pairs that found their key already claimed (contributors: at most 3,
+  int tcnt[kTab];                          //   header) and their count; the claimer merges them and resets the count
   long long sel_lgt[kMaxBeams], sel_tot[kMaxBeams];
   int sel_src[kMaxBeams];
   double fin[kMaxBeams];
@@ -104,10 +104,10 @@ struct GroupLds {
   long long red_best[2];
   int red_claimed[2];
   int mb_gt[kMaxBlocks], mb_eq[kMaxBlocks];
-  int merge_epoch, anychar_epoch;
+  int merge_epoch, anychar_epoch, overflow;
   int n_log;
 };
-static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
+static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab), "trace-back batches alias tkey");
 static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
 static_assert(sizeof(GroupLds<4>) <= 160 * 1024, "one workgroup per compute unit");
 static_assert(kFill <= 3 * 256 && kFill <= kTab * 7 / 20, "pairs per pass: three per lane at most, table at most 35 % full");
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
   unsigned long long* eoslog = eoslog_all + (int64_t)b * frames_ld * kMaxBeams;
 
-  for (int i = tid; i < kTab; i += 64 * W) { S.tkey[i] = 0; S.tmx[i] = ord64(-1e300); S.tsum[i] = 0; }
+  for (int i = tid; i < kTab; i += 64 * W) { S.tkey[i] = 0; S.tcnt[i] = 0; }
   for (int c = tid; c < kMaxClasses; c += 64 * W) S.cmix[c] = hmix(hmix(kFnvOffset, (unsigned long long)(c + 7)), 0x9e3779b9ull);
   for (int i = tid; i < 3 * 256; i += 64 * W) (&S.hist[0][0])[i] = 0;
   if (tid == 0) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     for (int i = 0; i < kMaxCtx; ++i) S.ctx[0][0][i] = -1;
     if (use_lm) S.ctx[0][0][kMaxCtx - 1] = lm.bos;
     S.commit_lmd[0][0] = 0.f; S.commit_wid[0][0] = 0;
-    S.merge_epoch = -1; S.anychar_epoch = -1; S.n_log = 0;
+    S.merge_epoch = -1; S.anychar_epoch = -1; S.n_log = 0; S.overflow = 0;
     for (int k = 0; k < 2; ++k) { S.red_best[k] = ord64(-1e300); S.red_claimed[k] = 0; }
   }
   group_sync();
@@ -409,8 +409,11 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
               if (old == k) break;
             }
           }
-          if (claimed >> j & 1) S.tsc[i] = score[j];                   // the claimer's score stays with the slot
-          else atomicMax(&S.tmx[i], ord64(score[j]));                  // a contributor: the contributors' maximum
+          if (!(claimed >> j & 1)) {                                   // a contributor: its score goes into the slot's next cell
+            const int n = atomicAdd(&S.tcnt[i], 1);
+            if (n < 3) S.tcs[i][n] = score[j];
+            else S.overflow = 1;                                       // (cannot happen -- a prefix has at most four pairs: file header -- and is reported: id_len = -1)
+          }
           slot[j] = i;
         }
       }
@@ -426,19 +429,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       GTICK(4)
       GCOUNT(1, npairs) GCOUNT(2, 1)
       const bool any_merge = S.merge_epoch == epoch;                    // uniform over the workgroup
-      if (any_merge) {
-        // a contributor adds exp(score - max(contributors, claimer)) as a 2^-44 fixed-point integer
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-          if ((act & ~claimed) >> j & 1) {
-            const long long mx = max(S.tmx[slot[j]], ord64(S.tsc[slot[j]]));
-            const float e = __builtin_amdgcn_exp2f((float)((score[j] - unord64(mx)) * 1.4426950408889634));
-            atomicAdd(&S.tsum[slot[j]], (unsigned long long)((double)e * kFix));
-          }
-        }
-        group_sync();                                                   // ---- B3
-        GCOUNT(3, 1)
-      }
       GTICK(5)
       // ---- 3. merged prefixes, each in the lane that claimed its slot ----
       long long tot[PPL], lgt[PPL];
@@ -464,12 +454,23 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         if (mine) {
           S.tkey[i] = 0;
           if (any_merge) {
-            const long long mo = S.tmx[i];
-            if (mo != ord64(-1e300)) {
-              const double m = unord64(max(mo, ord64(score[j])));
-              const float e = __builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634));
-              const unsigned long long s8 = S.tsum[i] + (unsigned long long)((double)e * kFix);
-              S.tmx[i] = ord64(-1e300); S.tsum[i] = 0;
+            const int n = S.tcnt[i];
+            if (n > 0) {
+              // log-sum-exp of the claimer and its n contributors: the maximum m first, then every term exp(s - m) through the
+              // hardware 2^x on a float (1 ulp) as a 2^-44 fixed-point integer -- integer sums are associative, so the result
+              // does not depend on who arrived first (and equals the one-wavefront kernel's max / atomic-add form bit for bit)
+              S.tcnt[i] = 0;
+              // (a second or third contributor is rare: their cells are read and their terms formed only when some lane has one)
+              const bool any2 = __ballot(n >= 2) != 0ull, any3 = __ballot(n >= 3) != 0ull;
+              const double s0 = S.tcs[i][0];
+              const double s1 = any2 ? S.tcs[i][1] : s0, s2 = any3 ? S.tcs[i][2] : s0;
+              double m = fmax(score[j], s0);
+              if (any2) m = n >= 2 ? fmax(m, s1) : m;
+              if (any3) m = n >= 3 ? fmax(m, s2) : m;
+              unsigned long long s8 = (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634)) * kFix);
+              s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s0 - m) * 1.4426950408889634)) * kFix);
+              if (any2 && n >= 2) s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s1 - m) * 1.4426950408889634)) * kFix);
+              if (any3 && n >= 3) s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s2 - m) * 1.4426950408889634)) * kFix);
               logit = m + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
             }
           }
@@ -685,19 +686,19 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         }
       }
     }
-    for (int i = lane; i < kTab; i += 64) S.tsrc[i] = 0;
+    for (int i = lane; i < kTab; i += 64) S.tcnt[i] = 0;
     wave_sync();
     for (int q2 = lane; q2 < n_log; q2 += 64) {
       const unsigned long long k = __hip_atomic_load(&eoslog[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int i = (int)((k >> 17) & (kTab - 1));; i = (i + 1) & (kTab - 1)) {
         const unsigned long long e = S.tkey[i];
-        if (e == k) { S.tsrc[i] = 1; break; }
+        if (e == k) { S.tcnt[i] = 1; break; }
         if (e == 0) break;
       }
     }
     wave_sync();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) if (myslot[j] >= 0) in_cache[j] = S.tsrc[myslot[j]];
+    for (int j = 0; j < 2; ++j) if (myslot[j] >= 0) in_cache[j] = S.tcnt[myslot[j]];
     wave_sync();
   }
   double* fin = S.fin;
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     }
   }
   if (lane == 0) {
-    out_len[b] = n;
+    out_len[b] = S.overflow ? -1 : n;
     out_score[b] = (float)bs;
   }
 #ifdef VASR_BEAM_PROF
