@@ -223,7 +223,9 @@ VASR_API int vasr_set_busy_cus(vasr_handle* h, int cus);
 /* BeamSearchDecoderWithLM.forward (beam_search_decoder.py:95-102 -> pyctcdecode, third-party: parity unpinned,
  * algorithm restated in oracle/beam_oracle.py).  Unlike the reference any batch size is accepted.
  *   d_logp [B][T'][V+1] f32 log-probabilities, blank = V (last class); space_id = index of ' ' in the labels
- *   -> d_ids [B][T'] i32 label ids of the best hypothesis (words separated by space_id), d_id_len [B] i32,
+ *   -> d_ids [B][T'] i32 label ids of the best hypothesis (words separated by space_id), d_id_len [B] i32 (-1: the
+ *      four-wavefront kernel's merge cells overflowed -- a prefix is reached by at most four pairs, so this cannot happen; it is
+ *      reported instead of a wrong answer),
  *      d_score [B] f32 combined (acoustic + LM) natural-log score of that hypothesis.
  * beam_width <= 128, V+1 <= 128.  token_min_logp / beam_prune_logp: pyctcdecode defaults are -5 / -10. */
 typedef struct vasr_lm vasr_lm;

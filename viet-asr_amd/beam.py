@@ -247,4 +247,6 @@ class BeamSearchDecoder:
     def decode_batch(self, log_probs, beam_width, frames=None):
         ids, n, _ = self.decode_ids(log_probs, beam_width, frames)
         ids, n = ids.cpu().numpy(), n.cpu().numpy()
+        if (n < 0).any():      # vasr.h: id_len = -1 reports a merge-cell overflow of the four-wavefront kernel (provably impossible)
+            raise _lib.VasrError("beam search reported an internal overflow (id_len = -1) for rows %s" % np.nonzero(n < 0)[0].tolist())
         return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]
