@@ -124,6 +124,28 @@ def test_lm_tables_spread_their_keys_and_probe_chains_stay_short():
             assert i == w
 
 
+def test_fixed_point_term_integer_form():
+    """csrc/beam_group.hip fix44: the 2^-44 fixed-point term of a prefix merge, (u64)((double)e * 2^44) for a float e in
+    [0, 1], as integer arithmetic on the float's bits (mantissa shifted by E - 106).  Exhaustive agreement over every float
+    in [0, 1] was checked once on the host in C; this replays both forms in numpy on 4e6 random floats, the powers of two,
+    their neighbours, 0 and 1."""
+    r = np.random.default_rng(0)
+    bits = np.concatenate([r.integers(0x00800000, 0x3f800001, 4_000_000, dtype=np.uint32),
+                           np.array([0, 0x3f800000, 0x3f7fffff, 0x00800000], dtype=np.uint32),
+                           (np.arange(1, 128, dtype=np.uint32) << 23), (np.arange(1, 128, dtype=np.uint32) << 23) - 1,
+                           (np.arange(1, 127, dtype=np.uint32) << 23) + 1]).astype(np.uint32)
+    bits = bits[(bits <= 0x3f800000) & (((bits >> 23) & 0xff) > 0) | (bits == 0)]
+    e = bits.view(np.float32)
+    ref = np.floor(e.astype(np.float64) * 2.0 ** 44).astype(np.uint64)
+    E = ((bits >> 23) & 0xff).astype(np.int64)
+    m = ((bits & 0x7fffff) | 0x800000).astype(np.uint64)
+    sh = E - 106
+    left = m << np.clip(sh, 0, 63).astype(np.uint64)
+    right = m >> np.clip(-sh, 0, 63).astype(np.uint64)
+    got = np.where(E == 0, 0, np.where(sh >= 0, left, right)).astype(np.uint64)
+    assert np.array_equal(got, ref)
+
+
 def test_reciprocal_forms_of_the_wave_kernels_integer_divisions():
     """csrc/beam_wave.hip divides by a wave-uniform small integer through the hardware reciprocal (1 ulp): pair index ->
     (beam, candidate) as (int)((p + 0.5f) * rcp(nc)) and candidates per pass as (int)((kFill + 0.5f) * rcp(nb)).  Replayed

@@ -132,6 +132,18 @@ __device__ inline void group_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// (unsigned long long)((double)e * 2^44) for a float e in [0, 1] -- the 2^-44 fixed-point term of a merge -- in integer
+// arithmetic: e = m * 2^(E - 150), so the product is m shifted by E - 106, truncated.  The double form is ~15 instructions of
+// conversion per term on this ISA (there is no f64 -> u64 instruction).  Identical for EVERY float in [0, 1]: checked
+// exhaustively on the host (1 056 964 610 values; tests/test_beam.py::test_fixed_point_term_integer_form samples it).
+__device__ inline unsigned long long fix44(float e) {
+  const unsigned b = __float_as_uint(e);
+  const int E = (int)((b >> 23) & 0xffu);
+  const unsigned long long m = (unsigned long long)((b & 0x7fffffu) | 0x800000u);
+  const int sh = E - 106;
+  return E == 0 ? 0ull : (sh >= 0 ? m << sh : (sh > -64 ? m >> -sh : 0ull));
+}
+
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ inline int rank_in(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -467,10 +479,10 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
               double m = fmax(score[j], s0);
               if (any2) m = n >= 2 ? fmax(m, s1) : m;
               if (any3) m = n >= 3 ? fmax(m, s2) : m;
-              unsigned long long s8 = (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634)) * kFix);
-              s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s0 - m) * 1.4426950408889634)) * kFix);
-              if (any2 && n >= 2) s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s1 - m) * 1.4426950408889634)) * kFix);
-              if (any3 && n >= 3) s8 += (unsigned long long)((double)__builtin_amdgcn_exp2f((float)((s2 - m) * 1.4426950408889634)) * kFix);
+              unsigned long long s8 = fix44(__builtin_amdgcn_exp2f((float)((score[j] - m) * 1.4426950408889634)));
+              s8 += fix44(__builtin_amdgcn_exp2f((float)((s0 - m) * 1.4426950408889634)));
+              if (any2 && n >= 2) s8 += fix44(__builtin_amdgcn_exp2f((float)((s1 - m) * 1.4426950408889634)));
+              if (any3 && n >= 3) s8 += fix44(__builtin_amdgcn_exp2f((float)((s2 - m) * 1.4426950408889634)));
               logit = m + (s8 == (unsigned long long)kFix ? 0.0 : log_ge1((double)s8 * (1.0 / kFix)));
             }
           }
