@@ -849,6 +849,19 @@ def main():
             out["roofline"]["measured_sustained_peak"] = norm["measured_mfma_tflops"]
             out["roofline"]["frac_of_measured"] = round(cr["exec_tflops"] / norm["measured_mfma_tflops"], 4)
             out["roofline"]["gemm_family"]["frac_of_measured"] = round(cr["fam_exec_tflops"] / norm["measured_mfma_tflops"], 4)
+            if norm.get("measured_copy_gbs_cache_resident") and prof["pointwise"]["bytes"]:
+                # A GEMM launch is two serial phases on every CU at once -- a main loop the matrix pipe bounds (at the rate the
+                # box's power limit allows) and a store-only epilogue the memory system bounds -- so its floor on THIS box is
+                # executed flops / measured MFMA rate + stored bytes / measured streaming rate (cache-resident: a layer's output
+                # stays in the Infinity Cache for its consumer at these sizes).  Unlike frac_of_measured, whose MFMA-only
+                # denominator follows the box's clock twice as closely as the kernel does, this fraction reproduces across
+                # boxes (five boxes of round 5: 0.733-0.745).
+                st_bytes = prof["pointwise"]["bytes"] / a.steps
+                t_mfma = cr["pw_flops"] * cr["terms"] / (norm["measured_mfma_tflops"] * 1e12) * 1e3
+                t_store = st_bytes / (norm["measured_copy_gbs_cache_resident"] * 1e9) * 1e3
+                out["roofline"]["serial_floor"] = {"mfma_ms": round(t_mfma, 3), "store_ms": round(t_store, 3), "stored_bytes_per_step": st_bytes,
+                                                   "frac": round((t_mfma + t_store) / cr["pw_ms"], 4),
+                                                   "note": "(flops / box MFMA rate + stored bytes / box streaming rate) / measured GEMM time"}
         if norm.get("measured_copy_gbs"):
             out["depthwise"]["measured_copy_gbs"] = norm["measured_copy_gbs"]
             out["depthwise"]["measured_copy_gbs_cache_resident"] = norm["measured_copy_gbs_cache_resident"]

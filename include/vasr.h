@@ -278,7 +278,8 @@ VASR_API int vasr_algorithmic_work(const vasr_handle* h, int batch, int64_t samp
  *   [0] front end (seq_len + STFT/mel + CMVN)  [1] depthwise convs  [2] pointwise GEMMs
  *   [3] CTC head (decoder GEMM + log-softmax/argmax + collapse)  [4] fused depthwise + pointwise sub-blocks
  * flops / bytes (optional, may be NULL): the algorithmic work of the launches of each class that actually ran --
- * 2 M N K of every GEMM (class 2 and 4), HBM bytes read + written by every depthwise (1) and fused (4) layer. */
+ * 2 M N K of every GEMM (class 2 and 4), HBM bytes read + written by every depthwise (1) and fused (4) layer, bytes STORED by
+ * every plain GEMM (2: its store-only epilogue is the part of its time the matrix pipe does not bound). */
 VASR_API int vasr_profile_begin(vasr_handle* h);
 VASR_API int vasr_profile_end(vasr_handle* h, double ms[5], int64_t launches[5], double flops[5], double bytes[5]);
 /* Row pitch of the library's padded activation buffers: frames rounded up to the 128-frame tile. */

@@ -595,7 +595,8 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       a.ldx = cur_ld; a.ldy = cur_ld; a.ldr = 0; a.frames = (int)cur_T; a.store_cols = (int)cur_ld;
       a.m_store = B.res.m_pad; a.relu = 0;
       a.amax_x = blk_amax;
-      ProfScope ps(h, kProfPointwise, st, 2.0 * B.res.cin * B.res.cout * (double)cur_T * batch);
+      ProfScope ps(h, kProfPointwise, st, 2.0 * B.res.cin * B.res.cout * (double)cur_T * batch,
+                   4.0 * B.res.m_pad * (double)cur_ld * batch);   // bytes of class 2 = what the GEMM STORES (its epilogue's share of the time)
       if (run_pointwise(h, a, B.res, st) < 0) return VASR_ERR_HIP;
     }
     int flip = 0;
@@ -715,7 +716,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       }
       int published;
       {
-        ProfScope ps(h, kProfPointwise, st, 2.0 * W.cin * W.cout * (double)g_T * batch);
+        ProfScope ps(h, kProfPointwise, st, 2.0 * W.cin * W.cout * (double)g_T * batch, 4.0 * W.m_pad * (double)dst_ld * batch);
         published = run_pointwise(h, a, W, st);
       }
       if (published < 0) return VASR_ERR_HIP;
