@@ -31,6 +31,9 @@ abc = os.path.join(tmp, "abc.arpa")
 BO.write_arpa(abc, 3, ng)
 
 
+STATS = {"cases": 0, "near_tie_excuses": 0}
+
+
 def small_alphabet(Tn, V1, seed, k):
     r = np.random.RandomState(seed)
     z = r.randn(Tn, V1) * k
@@ -68,6 +71,9 @@ def run_case(case):
     ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm)
     close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
     ok_text = text == ref[0][0] or (close and text == ref[1][0])
+    if ok_text and text != ref[0][0]:
+        STATS["near_tie_excuses"] += 1           # the device returned the oracle's runner-up, < 1e-3 behind its best
+    STATS["cases"] += 1
     ok_score = (not ok_text) or text != ref[0][0] or abs(float(score[0]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50)
     if ok_text and ok_score:
         return None
@@ -85,4 +91,4 @@ if __name__ == "__main__":
         if msg:
             bad += 1
             print("MISMATCH", msg, flush=True)
-    print(f"{N} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+    print(f"{N} cases, {bad} mismatches, {STATS['near_tie_excuses']} decided by the near-tie allowance, {time.time() - t0:.0f} s")

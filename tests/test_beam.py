@@ -310,6 +310,9 @@ def test_device_beam_search_randomised_cases(gpu):
     import fuzz_beam
     bad = [m for m in (fuzz_beam.run_case(c) for c in range(400)) if m]
     assert not bad, bad
+    from test_gpu_parity import _record
+    _record("beam_fuzz", **fuzz_beam.STATS)      # how many of the cases the < 1e-3 near-tie allowance decided
+    assert fuzz_beam.STATS["near_tie_excuses"] == 0     # measured (round 5): none of 2 400 cases; the allowance stays for other hosts' numpy
 
 
 @pytest.mark.gpu
