@@ -117,6 +117,7 @@ def test_config2_quartznet12x1_vi_b32_10s_full_size(gpu):
 
 def _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag):
     from oracle import beam_oracle as BO
+    excused, worst = 0, 0.0
     for b in rows:
         ref = BO.decode_beams(np.exp(logp[b].double().cpu().numpy()), labels, 128, lm=olm)
         # near-ties between the two best hypotheses may legitimately resolve differently (fp rounding), as in test_beam.py
@@ -124,6 +125,11 @@ def _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag):
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (tag, b, texts[b][:80], ref[0][0][:80])
         if texts[b] == ref[0][0]:
             assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (tag, b, float(score[b]), ref[0][2])
+            worst = max(worst, abs(float(score[b]) - ref[0][2]))
+        else:
+            excused += 1
+    from test_gpu_parity import _record
+    _record("config4_beam_rows", tag=tag, rows=len(list(rows)), decided_by_the_near_tie_allowance=excused, worst_score_err=worst)
 
 
 def test_config4_quartznet15x5_beam128_lm_b64(gpu, tmp_path):
