@@ -607,6 +607,13 @@ f=$(find $O/stats -name '*kernel_stats.csv' | head -1); grep -E "stft|normalize"
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
 }
 
+# ---- r5soak: the two beam-search kernels against each other and against themselves (run-to-run), seeds the tests do not use
+task_r5soak() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5soak}; mkdir -p $O; cd $R
+timeout 400 python tools/soak_beam.py ${2:-2000} ${3:-500000} 4 ${4:-170} 2> $O/soak.err | tee $O/soak.json
+grep -v amdgpu $O/soak.err | tail -5
+}
+
 task=${1:-list}; shift || true
 if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
 if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi
