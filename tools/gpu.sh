@@ -614,6 +614,18 @@ timeout 400 python tools/soak_beam.py ${2:-2000} ${3:-500000} 4 ${4:-170} 2> $O/
 grep -v amdgpu $O/soak.err | tail -5
 }
 
+# ---- r5g: tie-break by key in both beam kernels: the beam tests, the soak, serving-shape latency, configs[3]
+task_r5g() {
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r5g}; mkdir -p $O; cd $R
+timeout 600 python -m pytest tests/test_beam.py -x -q -m gpu -p no:cacheprovider > $O/pytest_beam.log 2>&1; tail -3 $O/pytest_beam.log
+timeout 300 python tools/soak_beam.py 2000 500000 4 170 2> $O/soak.err | tee $O/soak.json
+python tools/b1_serving.py 2> /dev/null | tee $O/b1_vi12x1.json
+timeout 200 python bench.py --config 4 --steps 20 --warmup 3 --no-other-gemm --no-cpu-baseline 2> /dev/null | python -c "
+import sys, json
+j = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('config 4: %.3f ms/step, beam %s' % (j['ms_per_step'], j.get('beam')))"
+}
+
 task=${1:-list}; shift || true
 if [ "$task" = list ]; then grep -E "^# ---- " "$0" | sed "s/^# ---- //"; exit 0; fi
 if ! declare -F "task_$task" > /dev/null; then echo "unknown task $task (try: list)" >&2; exit 2; fi

@@ -38,13 +38,7 @@ def posteriors(kind, rows, frames, labels, words, seed, r):
     return (z - np.log(np.exp(z).sum(-1, keepdims=True))).astype(np.float32)
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 500_000
-    repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-    max_seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 1e9
-    dev = torch.device("cuda:0")
-    tmp = tempfile.mkdtemp(prefix="vasr_soak_")
+def make_vocabs(tmp):
     vocabs = {}
     for name, labels in (("en29", list(" abcdefghijklmnopqrstuvwxyz'")), ("vi91", configs.builtin("quartznet12x1_vi")["labels"]),
                          ("wide128", [" "] + [chr(0x100 + i) for i in range(126)])):
@@ -52,56 +46,68 @@ def main():
         synth.synthetic_arpa(arpa, labels, seed=11)
         words = sorted(w[0] for w in read_arpa(arpa)[1] if len(w) == 1 and not w[0].startswith("<"))
         vocabs[name] = (labels, arpa, words)
-    decs = {}
-    bad, launches, overflow = [], 0, 0
+    return vocabs
+
+
+def run_case(seed, vocabs, decs, repeats, dev, stats):
+    """None when every form and every repeat of case `seed` gave the same bits, else a description of the first difference."""
+    r = np.random.RandomState(seed)
+    name = ["en29", "vi91", "wide128"][r.randint(3)]
+    labels, arpa, words = vocabs[name]
+    use_lm = bool(r.randint(2))
+    alpha, beta = float(r.choice([0.3, 0.5, 1.2])), float(r.choice([0.0, 1.5, 2.5]))
+    key = (name, use_lm, alpha, beta)
+    if key not in decs:
+        decs[key] = BeamSearchDecoder(labels, lm_path=arpa if use_lm else None, alpha=alpha, beta=beta)
+    dec = decs[key]
+    frames = int(r.choice([20, 77, 140, 331, 501, 1200]))
+    width = int(r.choice([8, 20, 50, 100, 128]))
+    kind = int(r.randint(3))
+    if kind == 2:
+        frames = min(frames, 140)          # flat posteriors: every class a candidate on every frame, exact ties of scores
+    rows = 16
+    lp = torch.from_numpy(posteriors(kind, rows, frames, labels, words, seed, r)).to(dev)
+    ragged = torch.from_numpy(r.randint(1, frames + 1, size=rows).astype(np.int32)) if r.randint(2) else None
+    ref = [t.cpu() for t in dec.decode_ids(lp, width, frames=ragged)]            # 16 rows: beam_wave.hip
+    stats["searches"] += 1
+    stats["overflow_rows"] += int((ref[1] < 0).sum())
+    for lo, hi in ((0, 1), (1, 4), (1, 16)):                                     # 1, 3, 15 rows: beam_group.hip
+        sub = lp[lo:hi].contiguous()
+        fr = ragged[lo:hi] if ragged is not None else None
+        for rep in range(repeats):
+            ids, n, score = [t.cpu() for t in dec.decode_ids(sub, width, frames=fr)]
+            stats["searches"] += 1
+            stats["overflow_rows"] += int((n < 0).sum())
+            for j in range(len(n)):
+                k = int(n[j])
+                if (k != int(ref[1][lo + j]) or not torch.equal(ids[j, :k], ref[0][lo + j, :k])
+                        or float(score[j]).hex() != float(ref[2][lo + j]).hex()):
+                    return {"case": seed, "vocab": name, "lm": use_lm, "frames": frames, "width": width, "kind": kind,
+                            "batch_rows": [lo, hi], "row": lo + j, "repeat": rep, "ragged": ragged is not None,
+                            "lengths": [k, int(ref[1][lo + j])], "scores": [float(score[j]), float(ref[2][lo + j])]}
+    return None
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 500_000
+    repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    max_seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 1e9
+    dev = torch.device("cuda:0")
+    vocabs = make_vocabs(tempfile.mkdtemp(prefix="vasr_soak_"))
+    decs, bad, stats = {}, [], {"searches": 0, "overflow_rows": 0}
     t_start = time.time()
     done = 0
     for case in range(n_cases):
         if time.time() - t_start > max_seconds:
             break
         done += 1
-        r = np.random.RandomState(seed0 + case)
-        name = ["en29", "vi91", "wide128"][r.randint(3)]
-        labels, arpa, words = vocabs[name]
-        use_lm = bool(r.randint(2))
-        alpha, beta = float(r.choice([0.3, 0.5, 1.2])), float(r.choice([0.0, 1.5, 2.5]))
-        key = (name, use_lm, alpha, beta)
-        if key not in decs:
-            decs[key] = BeamSearchDecoder(labels, lm_path=arpa if use_lm else None, alpha=alpha, beta=beta)
-        dec = decs[key]
-        frames = int(r.choice([20, 77, 140, 331, 501, 1200]))
-        width = int(r.choice([8, 20, 50, 100, 128]))
-        kind = int(r.randint(3))
-        if kind == 2:
-            frames = min(frames, 140)          # flat posteriors: every class a candidate on every frame
-        rows = 16
-        lp = torch.from_numpy(posteriors(kind, rows, frames, labels, words, seed0 + case, r)).to(dev)
-        ragged = torch.from_numpy(r.randint(1, frames + 1, size=rows).astype(np.int32)) if r.randint(2) else None
-        ref = [t.cpu() for t in dec.decode_ids(lp, width, frames=ragged)]            # 16 rows: beam_wave.hip
-        launches += 1
-        overflow += int((ref[1] < 0).sum())
-
-        def same(ids, n, score, lo):
-            for j in range(len(n)):
-                k = int(n[j])
-                if k != int(ref[1][lo + j]) or not torch.equal(ids[j, :k], ref[0][lo + j, :k]):
-                    return False
-            return torch.equal(score.view(torch.int32), ref[2][lo:lo + len(n)].view(torch.int32))
-
-        for lo, hi in ((0, 1), (1, 4), (1, 16)):                                     # 1, 3, 15 rows: beam_group.hip
-            sub = lp[lo:hi].contiguous()
-            fr = ragged[lo:hi] if ragged is not None else None
-            for rep in range(repeats):
-                ids, n, score = [t.cpu() for t in dec.decode_ids(sub, width, frames=fr)]
-                launches += 1
-                overflow += int((n < 0).sum())
-                if not same(ids, n, score, lo):
-                    bad.append({"case": seed0 + case, "vocab": name, "lm": use_lm, "frames": frames, "width": width, "kind": kind,
-                                "rows": [lo, hi], "repeat": rep, "ragged": ragged is not None})
-                    break
-    print(json.dumps({"cases": done, "seed0": seed0, "repeats": repeats, "searches": launches, "overflow_rows": overflow,
-                      "mismatches": len(bad), "first": bad[:5], "seconds": round(time.time() - t_start, 1)}))
-    return 1 if bad or overflow else 0
+        m = run_case(seed0 + case, vocabs, decs, repeats, dev, stats)
+        if m:
+            bad.append(m)
+    print(json.dumps({"cases": done, "seed0": seed0, "repeats": repeats, **stats, "mismatches": len(bad), "first": bad[:5],
+                      "seconds": round(time.time() - t_start, 1)}))
+    return 1 if bad or stats["overflow_rows"] else 0
 
 
 if __name__ == "__main__":

@@ -30,8 +30,10 @@
 //     pass instead of two.  A larger pass does not change the result: pairs that merge carry the same character, i.e. sit in
 //     the same pass either way; the survivors of the earlier passes re-enter the last pass's prune and select, so the
 //     selected SET is the top-k of the union in both forms; only the ORDER of the new beams differs (one pass: pair order;
-//     several: last pass's pairs, then carried survivors), and the order only breaks exact ties of 64-bit scores
-//     (tests/devtools/fuzz_beam.py: 400 cases bit-equal to the one-wavefront kernel, which passes at 358);
+//     several: last pass's pairs, then carried survivors; and the pair that claims a merged prefix is whoever came first).
+//     Order could only break exact ties of 64-bit scores -- which almost flat posteriors do produce (tools/soak_beam.py: 3
+//     cases of 2 000 differed between the kernels) -- so a tie at the cut and a tie of the final scores are decided by
+//     the entries' table KEYS in both kernels, not by position: the result does not depend on the order at all;
 //   * a pair that finds its key already claimed (a contributor) leaves its SCORE in the slot -- a prefix (text, last
 //     character) is reached by at most four pairs: from the two beams that share its text (ending in blank / in its last
 //     character) and from the two that share the text one character shorter --, and the claimer forms the log-sum-exp of all
@@ -47,8 +49,9 @@
 //     loop;
 //   * the final pass (commit pending words, merge identical texts, trace-back) is wavefront 0 alone, as in beam_wave.hip.
 //
-// Results equal beam_wave.hip's bit for bit (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree, and every case of
-// the randomised comparison runs both forms).  Workgroup = 256 threads = one utterance; LDS ~136 KB, one workgroup per CU.
+// Results equal beam_wave.hip's bit for bit (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree,
+// ::test_exact_score_ties_do_not_depend_on_the_kernel_form, every case of the randomised comparison runs both forms; soak:
+// profiles/r05_beam_soak.txt, 26 000 searches, 1 / 3 / 15 rows four times each against 16 rows).  Workgroup = 256 threads = one utterance; LDS ~136 KB, one workgroup per CU.
 // Used for batches of < 16 utterances (vasr_api.cpp); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
 #include <cstdlib>
 #include <type_traits>
@@ -365,6 +368,15 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     int c_src[2] = {0, 0};
     int n_sel = 0;
 
+    // table key of pair (beam bi, character c) = src -- (prefix text, last character), as the expand step forms it
+    auto pair_key = [&](int sr) __attribute__((always_inline)) -> unsigned long long {
+      const int bi = sr >> 8, c = sr & 255;
+      const unsigned m = S.meta[cur][bi];
+      const bool grows = !(c == V || c == meta_last(m)) && !(c == space_id && meta_wlen(m) == 0);
+      const unsigned long long key = S.key[cur][bi];
+      return ((grows ? hmix(key, (unsigned long long)c) : key) ^ S.cmix[c]) | 1ull;
+    };
+
     // carry_tag: the frame's earlier passes left survivors (wavefront 0 carries them as two more blocks of entries); a
     // single-pass frame -- the usual case -- compiles them out
     auto pass = [&](auto ppl_tag, auto carry_tag, int c_lo, int nc, bool last_pass) __attribute__((always_inline)) {
@@ -512,7 +524,32 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         if (lv) live |= 1u << j;
       }
       unsigned long long prefix = 0, mask = 0;
+      unsigned long long kprefix = 0, kmask = 0, tk[PPL + NC];          // (an exact tie at the cut, below)
+      bool tie = false;
       int want = beam_width;
+      // the bucket of histogram h (bins in descending digit order) that holds the want-th largest digit; `want` becomes the
+      // rank wanted inside it, `whole` says that the bucket is taken entirely, `total` is the histogram's sum
+      auto find_bucket = [&](const int* h, int& whole, int& total) __attribute__((always_inline)) -> int {
+        // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
+        const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
+        const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+        const int mine = (c4.x + c4.y) + (c4.z + c4.w);
+        const int incl = wave_scan_incl(mine);
+        total = __builtin_amdgcn_readlane(incl, 63);
+        int above = incl - mine;
+        int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+          above += cnt[j];
+        }
+        const unsigned long long fm = __ballot(f_bucket >= 0);
+        if (fm == 0ull) { whole = 1; return 0; }                        // (total <= want: the caller's first digit checks the total)
+        const int fl = __ffsll((long long)fm) - 1;
+        want = __builtin_amdgcn_readlane(f_want, fl);
+        whole = __builtin_amdgcn_readlane(f_whole, fl);
+        return __builtin_amdgcn_readlane(f_bucket, fl);
+      };
       if (n_claimed_all > beam_width) {                                 // (uniform over the workgroup) only then can a select be needed
         // Every live key lies between the prune threshold and the best score, so the leading bits those two have in common
         // (sign, exponent, the top of the mantissa) are common to all of them: the first digit starts at the first bit in
@@ -525,6 +562,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         const unsigned long long d0 = ubest ^ ulo;
         const int lead = d0 ? __clzll((long long)d0) : 64;
         if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
+        tie = lead == 64;                                               // (a prune threshold AT the best score: whatever is live is tied)
         bool first = true;
         // Histogram buffers rotate with a running digit count: digit hd adds into hist[hd % 3] -- cleared during digit
         // hd - 1 (or at the start) -- and clears hist[(hd + 1) % 3], last READ during digit hd - 2, which every wavefront
@@ -544,30 +582,43 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           group_sync();                                               // ---- R
           GTICK(9)
           GCOUNT(4, 1)
-          // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
-          const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
-          const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
-          const int mine = (c4.x + c4.y) + (c4.z + c4.w);
-          const int incl = wave_scan_incl(mine);
+          int whole, total;
+          const int want_in = want;
+          const int bucket = find_bucket(h, whole, total);
           if (first) {
             first = false;
-            if (__builtin_amdgcn_readlane(incl, 63) <= want) { mask = 0; prefix = 0; break; }   // no more live entries than beams
+            if (total <= want_in) { want = want_in; mask = 0; prefix = 0; break; }   // no more live entries than beams
           }
-          int above = incl - mine;
-          int f_bucket = -1, f_want = 0, f_whole = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
-            above += cnt[j];
-          }
-          const unsigned long long fm = __ballot(f_bucket >= 0);
-          const int fl = __ffsll((long long)fm) - 1;
-          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
-          want = __builtin_amdgcn_readlane(f_want, fl);
-          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
           prefix |= (unsigned long long)bucket << shift;
           mask |= 0xFFull << shift;
-          if (whole || shift == 0) break;
+          if (whole || shift == 0) { tie = !whole; break; }
+        }
+        // ---- an exact tie at the cut: more entries share all 64 bits of the cut score than fit.  The ORDER of the entries is
+        //      not the same in the two kernels (passes of 716 pairs here, 358 there; here the pair that claims a merged prefix
+        //      is whoever came first), so position must not decide who stays: the tied entries with the LARGEST table keys
+        //      do -- (prefix text, last character), unique per entry and the same in every schedule -- by the same digit search
+        //      over their keys (flat synthetic posteriors reach this: tools/soak_beam.py; one digit as a rule) ----
+        if (tie) {                                                      // (uniform)
+#pragma unroll
+          for (int j = 0; j < PPL + NC; ++j) tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+#pragma unroll 1
+          for (int shift = 56;; shift -= 8) {
+            int* h = S.hist[hd % 3];
+            int* hn = S.hist[(hd + 1) % 3];
+            ++hd;
+#pragma unroll
+            for (int j = 0; j < PPL + NC; ++j) {
+              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+              if ((live >> j & 1) && u == prefix && (tk[j] & kmask) == kprefix) atomicAdd(&h[255 - (int)((tk[j] >> shift) & 255)], 1);
+            }
+            for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;
+            group_sync();                                               // ---- R (tie)
+            int whole, total;
+            const int bucket = find_bucket(h, whole, total);
+            kprefix |= (unsigned long long)bucket << shift;
+            kmask |= 0xFFull << shift;
+            if (whole || shift == 0) break;
+          }
         }
       }
       GTICK(10)
@@ -581,7 +632,12 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         gt[j] = false; eq[j] = false;
         if (live >> j & 1) {
           const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
-          if (mask == 0 || u > prefix) gt[j] = true; else if (u == prefix) eq[j] = true;
+          if (mask == 0 || u > prefix) gt[j] = true;
+          else if (u == prefix) {
+            if (!tie) eq[j] = true;
+            else if ((tk[j] & kmask) > kprefix) gt[j] = true;
+            else if ((tk[j] & kmask) == kprefix) eq[j] = true;
+          }
         }
         const int ng = __popcll(__ballot(gt[j])), ne = __popcll(__ballot(eq[j]));
         if (lane == 0) {
@@ -739,7 +795,10 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     }
   }
   wave_sync();
+  // (exact ties -- of the last-frame scores inside a group, of the groups' merged scores -- go to the larger key, not to the
+  // earlier beam: the beams' order is not the same in the two kernels, see the select)
   double my_score = -1e300;
+  unsigned long long my_key = 0;
   int my_first = 0x7fffffff;
 #pragma unroll 1
   for (int i = lane; i < nb; i += 64) {
@@ -750,14 +809,18 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     double m = S.logit[cur][i];
     int rep = i;
     for (int j = i + 1; j < nb; ++j)
-      if (fkey[j] == k) { m = fmax(m, S.logit[cur][j]); if (frank[j] < frank[rep]) rep = j; }
+      if (fkey[j] == k) {
+        m = fmax(m, S.logit[cur][j]);
+        if (frank[j] < frank[rep] || (frank[j] == frank[rep] && S.key[cur][j] > S.key[cur][rep])) rep = j;
+      }
     double ssum = 0;
     for (int j = i; j < nb; ++j) if (fkey[j] == k) ssum += exp(S.logit[cur][j] - m);
     const double merged = (fin[rep] - S.logit[cur][rep]) + m + log(ssum);
-    if (merged > my_score) { my_score = merged; my_first = i; }
+    if (merged > my_score || (merged == my_score && k > my_key)) { my_score = merged; my_key = k; my_first = i; }
   }
   const long long sbest = wave_max_i64(ord64(my_score));
-  const unsigned long long wm = __ballot(ord64(my_score) == sbest);
+  const long long kbest = wave_max_i64(ord64(my_score) == sbest ? (long long)(my_key ^ 0x8000000000000000ull) : (long long)0x8000000000000000ull);
+  const unsigned long long wm = __ballot(ord64(my_score) == sbest && (long long)(my_key ^ 0x8000000000000000ull) == kbest);
   int bi_best = 0x7fffffff;
   for (unsigned long long q2 = wm; q2; q2 &= q2 - 1) bi_best = min(bi_best, __builtin_amdgcn_readlane(my_first, __ffsll((long long)q2) - 1));
   const double bs = unord64(sbest);

@@ -318,6 +318,15 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     bool any_char = false;
     WTICK(2)
 
+    // table key of pair (beam bi, character c) = src -- (prefix text, last character), as the expand step forms it
+    auto pair_key = [&](int sr) __attribute__((always_inline)) -> unsigned long long {
+      const int bi = sr >> 8, c = sr & 255;
+      const unsigned m = S.meta[cur][bi];
+      const bool grows = !(c == V || c == meta_last(m)) && !(c == space_id && meta_wlen(m) == 0);
+      const unsigned long long key = S.key[cur][bi];
+      return ((grows ? hmix(key, (unsigned long long)c) : key) ^ S.cmix[c]) | 1ull;
+    };
+
     // One pass = nc candidates x nb beams, PPL pairs per lane (pair p = 64 j + lane), everything between the table and the
     // new beams in REGISTERS: a pair's slot and score, a merged prefix's combined score and logit in the lane that claimed
     // its slot.  The claimed-slot list, the pair -> slot map and the survivor records of the first version of this kernel
@@ -477,7 +486,28 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         tot_live += __popcll(__ballot(lv));
       }
       unsigned long long prefix = 0, mask = 0;
+      unsigned long long kprefix = 0, kmask = 0, tk[PPL + 2];          // (an exact tie at the cut, below)
+      bool tie = false;
       int want = beam_width;
+      // the bucket of the histogram that holds the want-th largest digit, searched from the top: lane l owns bins 255 - 4l ...
+      // 252 - 4l; `want` becomes the rank wanted inside it, `whole` says that the bucket is taken entirely
+      auto find_bucket = [&](int& whole) __attribute__((always_inline)) -> int {
+        int cnt[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
+        int above = wave_scan_incl(mine) - mine;
+        int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+          above += cnt[j];
+        }
+        const unsigned long long fm = __ballot(f_bucket >= 0);
+        const int fl = __ffsll((long long)fm) - 1;           // exactly one lane finds it (more entries than wanted, want >= 1)
+        want = __builtin_amdgcn_readlane(f_want, fl);
+        whole = __builtin_amdgcn_readlane(f_whole, fl);
+        return __builtin_amdgcn_readlane(f_bucket, fl);
+      };
       if (tot_live > beam_width) {
         WCOUNT(6, 1)
         // every live key lies between the prune threshold and the best score: the leading BITS those two have in common
@@ -489,6 +519,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         const unsigned long long d0 = ubest ^ ((unsigned long long)thr_prune ^ 0x8000000000000000ull);
         const int lead = d0 ? __clzll((long long)d0) : 64;
         if (lead > 0) { mask = lead == 64 ? ~0ull : (~0ull << (64 - lead)); prefix = ubest & mask; }
+        tie = lead == 64;                       // (a prune threshold AT the best score: whatever is live is tied)
 #pragma unroll 1
         for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
           WCOUNT(4, 1)
@@ -500,25 +531,36 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
             if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
           }
           wave_sync();
-          // the bucket holding the want-th largest key, searched from the top: lane l owns bins 255 - 4l ... 252 - 4l
-          int cnt[4], mine = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
-          int above = wave_scan_incl(mine) - mine;
-          int f_bucket = -1, f_want = 0, f_whole = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
-            above += cnt[j];
-          }
-          const unsigned long long fm = __ballot(f_bucket >= 0);
-          const int fl = __ffsll((long long)fm) - 1;           // exactly one lane finds it (tot_live > want >= 1)
-          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
-          want = __builtin_amdgcn_readlane(f_want, fl);
-          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
+          int whole;
+          const int bucket = find_bucket(whole);
           prefix |= (unsigned long long)bucket << shift;
           mask |= 0xFFull << shift;
-          if (whole || shift == 0) break;       // the whole bucket is taken: no need to refine further
+          if (whole || shift == 0) { tie = !whole; break; }   // the whole bucket is taken: no need to refine further
+        }
+        // ---- an exact tie at the cut: more entries share all 64 bits of the cut score than fit.  The ORDER of the entries is
+        //      not the same here and in beam_group.hip (passes of 358 pairs here, 716 there; there the pair that claims a merged
+        //      prefix is whoever came first), so position must not decide who stays: the tied entries with the LARGEST table
+        //      keys do -- (prefix text, last character), unique per entry and the same in every schedule -- by the same digit
+        //      search over their keys (flat synthetic posteriors reach this: tools/soak_beam.py; one digit as a rule) ----
+        if (tie) {                              // (uniform)
+#pragma unroll
+          for (int j = 0; j < PPL + 2; ++j) tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+#pragma unroll 1
+          for (int shift = 56;; shift -= 8) {
+            for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < PPL + 2; ++j) {
+              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+              if ((live >> j & 1) && u == prefix && (tk[j] & kmask) == kprefix) atomicAdd(&S.hist[(int)((tk[j] >> shift) & 255)], 1);
+            }
+            wave_sync();
+            int whole;
+            const int bucket = find_bucket(whole);
+            kprefix |= (unsigned long long)bucket << shift;
+            kmask |= 0xFFull << shift;
+            if (whole || shift == 0) break;
+          }
         }
       }
       WTICK(6)
@@ -532,7 +574,12 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         bool gt = false, eq = false;
         if (live >> j & 1) {
           const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
-          if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
+          if (mask == 0 || u > prefix) gt = true;
+          else if (u == prefix) {
+            if (!tie) eq = true;
+            else if ((tk[j] & kmask) > kprefix) gt = true;
+            else if ((tk[j] & kmask) == kprefix) eq = true;
+          }
         }
         const unsigned long long em = __ballot(eq);
         const bool take = gt || (eq && eq_seen + rank_in(em) < want);
@@ -677,7 +724,10 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   // pyctcdecode's _merge_beams overwrites the group's entry with every further member it meets while walking its
   // score-sorted beam list, so the member with the LOWEST last-frame score provides the LM part.  Every lane takes the
   // groups whose first member it owns; the best group is the first maximum in beam order.
+  // (Exact ties -- of the last-frame scores inside a group, of the groups' merged scores -- go to the larger key, not to the
+  // earlier beam: the beams' order is not the same in the two kernels, see the select.)
   double my_score = -1e300;
+  unsigned long long my_key = 0;
   int my_first = 0x7fffffff;
 #pragma unroll 1
   for (int i = lane; i < nb; i += 64) {
@@ -688,14 +738,18 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     double m = S.logit[cur][i];
     int rep = i;
     for (int j = i + 1; j < nb; ++j)
-      if (fkey[j] == k) { m = fmax(m, S.logit[cur][j]); if (frank[j] < frank[rep]) rep = j; }
+      if (fkey[j] == k) {
+        m = fmax(m, S.logit[cur][j]);
+        if (frank[j] < frank[rep] || (frank[j] == frank[rep] && S.key[cur][j] > S.key[cur][rep])) rep = j;
+      }
     double ssum = 0;
     for (int j = i; j < nb; ++j) if (fkey[j] == k) ssum += exp(S.logit[cur][j] - m);
     const double merged = (fin[rep] - S.logit[cur][rep]) + m + log(ssum);
-    if (merged > my_score) { my_score = merged; my_first = i; }
+    if (merged > my_score || (merged == my_score && k > my_key)) { my_score = merged; my_key = k; my_first = i; }
   }
   const long long sbest = wave_max_i64(ord64(my_score));
-  const unsigned long long wm = __ballot(ord64(my_score) == sbest);
+  const long long kbest = wave_max_i64(ord64(my_score) == sbest ? (long long)(my_key ^ 0x8000000000000000ull) : (long long)0x8000000000000000ull);
+  const unsigned long long wm = __ballot(ord64(my_score) == sbest && (long long)(my_key ^ 0x8000000000000000ull) == kbest);
   // lowest beam index among the lanes that hold the maximum (a lane's own groups are already in beam order)
   int bi_best = 0x7fffffff;
   for (unsigned long long q = wm; q; q &= q - 1) bi_best = min(bi_best, __builtin_amdgcn_readlane(my_first, __ffsll((long long)q) - 1));
