@@ -524,32 +524,8 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         if (lv) live |= 1u << j;
       }
       unsigned long long prefix = 0, mask = 0;
-      unsigned long long kprefix = 0, kmask = 0, tk[PPL + NC];          // (an exact tie at the cut, below)
-      bool tie = false;
       int want = beam_width;
-      // the bucket of histogram h (bins in descending digit order) that holds the want-th largest digit; `want` becomes the
-      // rank wanted inside it, `whole` says that the bucket is taken entirely, `total` is the histogram's sum
-      auto find_bucket = [&](const int* h, int& whole, int& total) __attribute__((always_inline)) -> int {
-        // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
-        const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
-        const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
-        const int mine = (c4.x + c4.y) + (c4.z + c4.w);
-        const int incl = wave_scan_incl(mine);
-        total = __builtin_amdgcn_readlane(incl, 63);
-        int above = incl - mine;
-        int f_bucket = -1, f_want = 0, f_whole = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
-          above += cnt[j];
-        }
-        const unsigned long long fm = __ballot(f_bucket >= 0);
-        if (fm == 0ull) { whole = 1; return 0; }                        // (total <= want: the caller's first digit checks the total)
-        const int fl = __ffsll((long long)fm) - 1;
-        want = __builtin_amdgcn_readlane(f_want, fl);
-        whole = __builtin_amdgcn_readlane(f_whole, fl);
-        return __builtin_amdgcn_readlane(f_bucket, fl);
-      };
+      bool tie = false;                                                 // (uniform) the digits ran out on a bucket with more entries than wanted
       if (n_claimed_all > beam_width) {                                 // (uniform over the workgroup) only then can a select be needed
         // Every live key lies between the prune threshold and the best score, so the leading bits those two have in common
         // (sign, exponent, the top of the mantissa) are common to all of them: the first digit starts at the first bit in
@@ -582,43 +558,86 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           group_sync();                                               // ---- R
           GTICK(9)
           GCOUNT(4, 1)
-          int whole, total;
-          const int want_in = want;
-          const int bucket = find_bucket(h, whole, total);
+          // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
+          const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
+          const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+          const int mine = (c4.x + c4.y) + (c4.z + c4.w);
+          const int incl = wave_scan_incl(mine);
           if (first) {
             first = false;
-            if (total <= want_in) { want = want_in; mask = 0; prefix = 0; break; }   // no more live entries than beams
+            if (__builtin_amdgcn_readlane(incl, 63) <= want) { mask = 0; prefix = 0; break; }   // no more live entries than beams
           }
+          int above = incl - mine;
+          int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+            above += cnt[j];
+          }
+          const unsigned long long fm = __ballot(f_bucket >= 0);
+          const int fl = __ffsll((long long)fm) - 1;
+          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+          want = __builtin_amdgcn_readlane(f_want, fl);
+          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
           prefix |= (unsigned long long)bucket << shift;
           mask |= 0xFFull << shift;
           if (whole || shift == 0) { tie = !whole; break; }
         }
         // ---- an exact tie at the cut: more entries share all 64 bits of the cut score than fit.  The ORDER of the entries is
         //      not the same in the two kernels (passes of 716 pairs here, 358 there; here the pair that claims a merged prefix
-        //      is whoever came first), so position must not decide who stays: the tied entries with the LARGEST table keys
-        //      do -- (prefix text, last character), unique per entry and the same in every schedule -- by the same digit search
-        //      over their keys (flat synthetic posteriors reach this: tools/soak_beam.py; one digit as a rule) ----
-        if (tie) {                                                      // (uniform)
+        //      is whoever came first), so position must not decide who stays: the `want` tied entries with the LARGEST table
+        //      keys do -- (prefix text, last character), unique per entry and the same in every schedule.  The same digit
+        //      search over the keys of the tied entries (one digit as a rule); the others then leave the live set, and what
+        //      follows sees exactly `want` entries equal to the cut.  Out of line: flat synthetic posteriors reach this
+        //      (tools/soak_beam.py), a model's do not ----
+        if (tie) {
+          const int want_tied = want;
+          unsigned long long tk[PPL + NC], kprefix = 0, kmask = 0;
+          unsigned tied = 0;
 #pragma unroll
-          for (int j = 0; j < PPL + NC; ++j) tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+          for (int j = 0; j < PPL + NC; ++j) {
+            tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+            const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+            if ((live >> j & 1) && u == prefix) tied |= 1u << j;
+          }
+          bool fits = false;
 #pragma unroll 1
           for (int shift = 56;; shift -= 8) {
             int* h = S.hist[hd % 3];
             int* hn = S.hist[(hd + 1) % 3];
             ++hd;
 #pragma unroll
-            for (int j = 0; j < PPL + NC; ++j) {
-              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
-              if ((live >> j & 1) && u == prefix && (tk[j] & kmask) == kprefix) atomicAdd(&h[255 - (int)((tk[j] >> shift) & 255)], 1);
-            }
+            for (int j = 0; j < PPL + NC; ++j)
+              if ((tied >> j & 1) && (tk[j] & kmask) == kprefix) atomicAdd(&h[255 - (int)((tk[j] >> shift) & 255)], 1);
             for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;
             group_sync();                                               // ---- R (tie)
-            int whole, total;
-            const int bucket = find_bucket(h, whole, total);
+            const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
+            const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+            const int mine = (c4.x + c4.y) + (c4.z + c4.w);
+            const int incl = wave_scan_incl(mine);
+            if (shift == 56 && __builtin_amdgcn_readlane(incl, 63) <= want) { fits = true; break; }   // (lead == 64 only) all tied entries fit
+            int above = incl - mine;
+            int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+              above += cnt[j];
+            }
+            const unsigned long long fm = __ballot(f_bucket >= 0);
+            const int fl = __ffsll((long long)fm) - 1;
+            const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+            want = __builtin_amdgcn_readlane(f_want, fl);
+            const int whole = __builtin_amdgcn_readlane(f_whole, fl);
             kprefix |= (unsigned long long)bucket << shift;
             kmask |= 0xFFull << shift;
             if (whole || shift == 0) break;
           }
+          if (!fits) {
+#pragma unroll
+            for (int j = 0; j < PPL + NC; ++j)
+              if ((tied >> j & 1) && (tk[j] & kmask) < kprefix) live &= ~(1u << j);
+          }
+          want = want_tied;
         }
       }
       GTICK(10)
@@ -632,12 +651,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         gt[j] = false; eq[j] = false;
         if (live >> j & 1) {
           const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
-          if (mask == 0 || u > prefix) gt[j] = true;
-          else if (u == prefix) {
-            if (!tie) eq[j] = true;
-            else if ((tk[j] & kmask) > kprefix) gt[j] = true;
-            else if ((tk[j] & kmask) == kprefix) eq[j] = true;
-          }
+          if (mask == 0 || u > prefix) gt[j] = true; else if (u == prefix) eq[j] = true;
         }
         const int ng = __popcll(__ballot(gt[j])), ne = __popcll(__ballot(eq[j]));
         if (lane == 0) {

@@ -486,28 +486,8 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         tot_live += __popcll(__ballot(lv));
       }
       unsigned long long prefix = 0, mask = 0;
-      unsigned long long kprefix = 0, kmask = 0, tk[PPL + 2];          // (an exact tie at the cut, below)
-      bool tie = false;
       int want = beam_width;
-      // the bucket of the histogram that holds the want-th largest digit, searched from the top: lane l owns bins 255 - 4l ...
-      // 252 - 4l; `want` becomes the rank wanted inside it, `whole` says that the bucket is taken entirely
-      auto find_bucket = [&](int& whole) __attribute__((always_inline)) -> int {
-        int cnt[4], mine = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
-        int above = wave_scan_incl(mine) - mine;
-        int f_bucket = -1, f_want = 0, f_whole = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
-          above += cnt[j];
-        }
-        const unsigned long long fm = __ballot(f_bucket >= 0);
-        const int fl = __ffsll((long long)fm) - 1;           // exactly one lane finds it (more entries than wanted, want >= 1)
-        want = __builtin_amdgcn_readlane(f_want, fl);
-        whole = __builtin_amdgcn_readlane(f_whole, fl);
-        return __builtin_amdgcn_readlane(f_bucket, fl);
-      };
+      bool tie = false;                 // (uniform) the digits ran out on a bucket with more entries than wanted
       if (tot_live > beam_width) {
         WCOUNT(6, 1)
         // every live key lies between the prune threshold and the best score: the leading BITS those two have in common
@@ -531,36 +511,74 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
             if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&S.hist[(int)((u >> shift) & 255)], 1);
           }
           wave_sync();
-          int whole;
-          const int bucket = find_bucket(whole);
+          // the bucket holding the want-th largest key, searched from the top: lane l owns bins 255 - 4l ... 252 - 4l
+          int cnt[4], mine = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
+          int above = wave_scan_incl(mine) - mine;
+          int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+            above += cnt[j];
+          }
+          const unsigned long long fm = __ballot(f_bucket >= 0);
+          const int fl = __ffsll((long long)fm) - 1;           // exactly one lane finds it (tot_live > want >= 1)
+          const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+          want = __builtin_amdgcn_readlane(f_want, fl);
+          const int whole = __builtin_amdgcn_readlane(f_whole, fl);
           prefix |= (unsigned long long)bucket << shift;
           mask |= 0xFFull << shift;
           if (whole || shift == 0) { tie = !whole; break; }   // the whole bucket is taken: no need to refine further
         }
         // ---- an exact tie at the cut: more entries share all 64 bits of the cut score than fit.  The ORDER of the entries is
         //      not the same here and in beam_group.hip (passes of 358 pairs here, 716 there; there the pair that claims a merged
-        //      prefix is whoever came first), so position must not decide who stays: the tied entries with the LARGEST table
-        //      keys do -- (prefix text, last character), unique per entry and the same in every schedule -- by the same digit
-        //      search over their keys (flat synthetic posteriors reach this: tools/soak_beam.py; one digit as a rule) ----
-        if (tie) {                              // (uniform)
+        //      prefix is whoever came first), so position must not decide who stays: the `want` tied entries with the LARGEST
+        //      table keys do -- (prefix text, last character), unique per entry and the same in every schedule.  The same digit
+        //      search over the keys of the tied entries (one digit as a rule); the others then leave the live set, and what
+        //      follows sees exactly `want` entries equal to the cut.  Out of line: flat synthetic posteriors reach this
+        //      (tools/soak_beam.py), a model's do not ----
+        if (tie) {
+          const int want_tied = want;
+          unsigned long long tk[PPL + 2], kprefix = 0, kmask = 0;
+          unsigned tied = 0;
 #pragma unroll
-          for (int j = 0; j < PPL + 2; ++j) tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+          for (int j = 0; j < PPL + 2; ++j) {
+            tk[j] = pair_key(j < PPL ? src[j] : c_src[j - PPL]);
+            const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
+            if ((live >> j & 1) && u == prefix) tied |= 1u << j;
+          }
 #pragma unroll 1
           for (int shift = 56;; shift -= 8) {
             for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
             wave_sync();
 #pragma unroll
-            for (int j = 0; j < PPL + 2; ++j) {
-              const unsigned long long u = (unsigned long long)(j < PPL ? tot[j] : c_tot[j - PPL]) ^ 0x8000000000000000ull;
-              if ((live >> j & 1) && u == prefix && (tk[j] & kmask) == kprefix) atomicAdd(&S.hist[(int)((tk[j] >> shift) & 255)], 1);
-            }
+            for (int j = 0; j < PPL + 2; ++j)
+              if ((tied >> j & 1) && (tk[j] & kmask) == kprefix) atomicAdd(&S.hist[(int)((tk[j] >> shift) & 255)], 1);
             wave_sync();
-            int whole;
-            const int bucket = find_bucket(whole);
+            int cnt[4], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cnt[j] = S.hist[255 - (4 * lane + j)]; mine += cnt[j]; }
+            int above = wave_scan_incl(mine) - mine;
+            int f_bucket = -1, f_want = 0, f_whole = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (above < want && want <= above + cnt[j]) { f_bucket = 255 - (4 * lane + j); f_want = want - above; f_whole = cnt[j] == want - above; }
+              above += cnt[j];
+            }
+            const unsigned long long fm = __ballot(f_bucket >= 0);
+            const int fl = __ffsll((long long)fm) - 1;         // exactly one lane finds it (more tied entries than wanted, want >= 1)
+            const int bucket = __builtin_amdgcn_readlane(f_bucket, fl);
+            want = __builtin_amdgcn_readlane(f_want, fl);
+            const int whole = __builtin_amdgcn_readlane(f_whole, fl);
             kprefix |= (unsigned long long)bucket << shift;
             kmask |= 0xFFull << shift;
             if (whole || shift == 0) break;
           }
+#pragma unroll
+          for (int j = 0; j < PPL + 2; ++j)
+            if ((tied >> j & 1) && (tk[j] & kmask) < kprefix) live &= ~(1u << j);
+          want = want_tied;
         }
       }
       WTICK(6)
@@ -574,12 +592,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         bool gt = false, eq = false;
         if (live >> j & 1) {
           const unsigned long long u = ((unsigned long long)tt ^ 0x8000000000000000ull) & mask;
-          if (mask == 0 || u > prefix) gt = true;
-          else if (u == prefix) {
-            if (!tie) eq = true;
-            else if ((tk[j] & kmask) > kprefix) gt = true;
-            else if ((tk[j] & kmask) == kprefix) eq = true;
-          }
+          if (mask == 0 || u > prefix) gt = true; else if (u == prefix) eq = true;
         }
         const unsigned long long em = __ballot(eq);
         const bool take = gt || (eq && eq_seen + rank_in(em) < want);
