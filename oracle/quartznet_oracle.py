@@ -24,7 +24,6 @@ reference tree and NOT installed here, so they are *parity unpinned*:
     parts/features.py:155-166; configs/quartznet15x5.yaml:26 selects it) --
     ``torch_stft_magnitude`` below restates its published transform.
 """
-import math
 
 import numpy as np
 import torch

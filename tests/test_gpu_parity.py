@@ -630,7 +630,6 @@ def test_depthwise_on_the_matrix_pipe_matches_fp64_convolution(gpu, K, dil, C, B
     wavefront; the last one is then computed twice), several 512-frame tiles, a last tile of one 256-frame group,
     ragged lengths (input mask, output zeroed past the length), dilation 2; error bounded like the packed-FMA kernel's
     (2e-6 of the largest output), which is run beside it where it exists (dilation 1); published maxima exact."""
-    import ctypes as C_
     from viet_asr_amd import _lib
     L = _lib.dev_lib()      # include/vasr_devtools.h lives in the devtools build
     ld = int(L.vasr_padded_frames(T))

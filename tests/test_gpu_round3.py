@@ -9,7 +9,6 @@
     the CTC head's operand scale now comes from the row's own frames);
   * beam search: the LM score cache's effect on the final </s> pass, which round 2's kernel did not model.
 """
-import math
 import os
 
 import numpy as np
