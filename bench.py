@@ -143,7 +143,7 @@ def cpu_baseline(model, seed, decoder, lm_path, budget_s=25.0, batch=64, clip_se
     if decoder == "beam":
         from oracle import beam_oracle as BO
         b, seconds = 1, 2.0       # the restated pyctcdecode loop is pure Python: one 2 s utterance is ~10 s of CPU
-        lm = BO.LanguageModel(BO.NgramLM.from_arpa(lm_path), alpha=0.5, beta=1.5) if lm_path else None
+        lm = BO.LanguageModel(BO.NgramLM.from_arpa(lm_path), alpha=0.5, beta=1.5, unigrams=BO.unigrams_for_path(lm_path)) if lm_path else None
     else:
         # 4 clips: the batch at which the CPU path is FASTEST per audio-second (measured on the GPU box's 16 cores: 292x real
         # time at 4 x 10 s, 77x at the workload's own 64 x 10 s, whose 67 MB activations per layer fall out of the caches) --
@@ -232,7 +232,9 @@ def beam_decoder_for(cfg, no_lm, seed=3):
         lm = dec._get_lm()
         info = None
         if lm is not None:
-            info = {"order": lm.order, "ngrams": lm.n_ngrams, "words": lm.n_words, "table_load": round(lm.table_load, 3)}
+            info = {"order": lm.order, "ngrams": lm.n_ngrams, "words": lm.n_words, "table_load": round(lm.table_load, 3),
+                    # pyctcdecode's behaviour for a path ending in .arpa: unigram set + character trie (viet-asr_amd/beam.py)
+                    "unigrams": "arpa" if lm.unigram_set is not None else "none", "trie_nodes": getattr(lm, "n_trie_nodes", 0)}
         _LM[key] = (dec, lm_path, info)
     return _LM[key]
 

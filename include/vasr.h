@@ -34,8 +34,9 @@ extern "C" {
 /* Binary interface number of this header; vasr_abi_version() returns the one the library was built from.  Bumped whenever
  * a signature or struct layout changes (4: vasr_profile_end reports five kernel classes with flops / bytes per class --
  * a caller built against the four-class form would be written past its arrays; 5: vasr_lm_create takes 16-byte table
- * entries with power-of-two capacities). */
-#define VASR_ABI_VERSION 5
+ * entries with power-of-two capacities; 6: vasr_lm_create takes the character trie of pyctcdecode's unigram set, the
+ * vocabulary entries carry a set-membership flag, vasr_resample_f32 emits ceil(len * ratio) samples). */
+#define VASR_ABI_VERSION 6
 
 typedef struct vasr_handle vasr_handle;
 typedef void* vasr_stream; /* hipStream_t */
@@ -189,8 +190,11 @@ VASR_API int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, va
 /* Band-limited sample-rate conversion of a zero-padded batch (interpolated windowed-sinc, the scheme of resampy's
  * kaiser_best that librosa.load uses by default; third-party => parity unpinned).  d_table = [nwin][2] floats
  * (window value, delta to the next entry) with num_table entries per zero crossing, built on the host
- * (viet-asr_amd/audio.py::sinc_table); ratio = sr_out / sr_in; d_len_out[b] = int(d_len_in[b] * ratio);
- * rows of d_out are zero past that length.  ld_out >= max output length. */
+ * (viet-asr_amd/audio.py::sinc_table); ratio = sr_out / sr_in.  Lengths as librosa.load -> librosa.resample(fix=True)
+ * produces them: resampy computes int(d_len_in[b] * ratio) samples, librosa pads (with zeros) to
+ * d_len_out[b] = ceil(d_len_in[b] * ratio), both products in double (11 025 -> 16 000 Hz: 5 000 samples give 7 256
+ * computed samples and a length of 7 257; the reference's 8 -> 16 kHz: 2 n either way).  Rows of d_out are
+ * zero from int(d_len_in[b] * ratio) on.  ld_out >= ceil(ld_in * ratio).  (ABI 6; ABI 5 reported int(len * ratio).) */
 VASR_API int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* d_len_in, int batch, const float* d_table,
                       int nwin, int num_table, double ratio, float* d_out, int64_t ld_out, int64_t* d_len_out,
                       vasr_stream stream);
@@ -249,15 +253,25 @@ VASR_API int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row
 /* Back-off n-gram model as two open-addressing hash tables of 16-BYTE entries (one load returns key and value), both with
  * power-of-two capacity 2^lg >= 16, linear probing from the home slot ((uint32)(key ^ key >> 32) * 0x9E3779B1) >> (32 - lg),
  * key 0 = empty slot, stored keys have bit 0 set:
- *   h_vocab [vcap] {uint64 key, int32 word id, int32 0}: key = the word's label ids folded with vasr_beam_hash_step from
- *           vasr_beam_hash_init(), first character first;
+ *   h_vocab [vcap] {uint64 key, int32 word id, uint32 flags}: key = the word's label ids folded with vasr_beam_hash_step from
+ *           vasr_beam_hash_init(), first character first; flags bit 0 = the word is in pyctcdecode's unigram set (below);
  *   h_ngram [ncap] {uint64 key, float log10 p, float log10 back-off}: the key of (w_1 .. w_n) folds the word ids from the
  *           LAST word backwards, hash_step(... hash_step(hash_step(init, w_n), w_{n-1}) ..., w_1) -- the keys of every suffix
  *           of a history then come out of one chain, and the kernel requests the whole back-off walk in one trip to memory.
- * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel.  (ABI 5; ABI 4 took four
- * parallel arrays with odd capacities and `key % cap`.) */
-VASR_API int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, int order, int bos_id, int eos_id,
-                   int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out);
+ *   h_trie  [trie_buckets] buckets of TWO uint64 keys (16 bytes), trie_buckets a power of two >= 16, or NULL.
+ *           pyctcdecode's build_ctcdecoder(labels, kenlm_model_path, alpha, beta) -- the reference's call,
+ *           beam_search_decoder.py:82-87 -- behaves in one of two ways depending on the path's SUFFIX: for "*.arpa" it reads
+ *           the file's unigrams (1-gram lines with a back-off field), keeps those the model knows (unigram_set) and builds a
+ *           character trie of them: a partial word that is a prefix of a set member carries NO out-of-vocabulary penalty,
+ *           and a committed word outside the set gets the unk offset even if the model knows it.  For any other suffix (the
+ *           reference's own `3-gram-lm.binary`) there is no set: every partial word is penalised.
+ *           h_trie = the trie's nodes: key = (label ids of a non-empty PREFIX of a set member folded like a word's) | 1, in its
+ *           home bucket ((uint32)(key ^ key >> 32) * 0x9E3779B1) >> (32 - lg buckets) or the next one with a free cell (0);
+ *           NULL = the no-unigram behaviour (also what an EMPTY unigram set amounts to).
+ * Host arrays are copied to the device.  alpha/beta/unk_offset as in pyctcdecode's LanguageModel.  (ABI 6; ABI 5 had no
+ * trie; ABI 4 took four parallel arrays with odd capacities and `key % cap`.) */
+VASR_API int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, const void* h_trie, int trie_buckets,
+                   int order, int bos_id, int eos_id, int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out);
 VASR_API void vasr_lm_destroy(vasr_lm* lm);
 VASR_API uint64_t vasr_beam_hash_init(void);
 VASR_API uint64_t vasr_beam_hash_step(uint64_t h, uint64_t v);

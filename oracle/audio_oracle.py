@@ -2,7 +2,15 @@
 
 *** PARITY UNPINNED *** The reference resamples with ``librosa.load(sr=16000)`` (infer.py:200) whose default
 ``res_type='kaiser_best'`` is the third-party package resampy (absent here).  This restates resampy's published
-``resample_f`` loop (interpolated windowed sinc) in numpy, float64 accumulation.
+``resample_f`` loop (interpolated windowed sinc) in numpy and librosa's length rule around it:
+
+    librosa.resample(y, orig_sr, target_sr, fix=True):  ratio = float(target_sr) / orig_sr
+        n_samples = int(np.ceil(y.shape[-1] * ratio));  y_hat = resampy.resample(...)   # int(n * ratio) samples
+        y_hat = util.fix_length(y_hat, n_samples)                                        # zero-padded to ceil(n * ratio)
+
+Two known differences from the packages, both inside the 2e-6 bound the device is held to: resampy accumulates in the
+INPUT dtype (float32 for librosa.load's output) where this loop accumulates in float64, and its table is float64 where
+the device's is float32.
 """
 import numpy as np
 
@@ -18,7 +26,8 @@ def sinc_window(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.7
 def resample(x, sr_orig, sr_new, **kw):
     x = np.asarray(x, dtype=np.float64)
     ratio = float(sr_new) / sr_orig
-    n_out = int(x.shape[0] * ratio)
+    n_out = int(x.shape[0] * ratio)                 # resampy: shape[axis] = int(shape[axis] * sample_ratio)
+    n_fixed = int(np.ceil(x.shape[0] * ratio))      # librosa.resample(fix=True)
     interp_win, num_table = sinc_window(**kw)
     if ratio < 1:
         interp_win = interp_win * ratio
@@ -27,7 +36,7 @@ def resample(x, sr_orig, sr_new, **kw):
     scale = min(1.0, ratio)
     index_step = int(scale * num_table)
     nwin, n_orig = interp_win.shape[0], x.shape[0]
-    y = np.zeros(n_out)
+    y = np.zeros(n_fixed)
     for t in range(n_out):
         time_register = t / ratio
         n = int(time_register)

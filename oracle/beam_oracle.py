@@ -10,10 +10,26 @@ on the reference's call site:
     nemo/collections/asr/beam_search_decoder.py:82-87   build_ctcdecoder(vocab, kenlm_model_path, alpha, beta)
     nemo/collections/asr/beam_search_decoder.py:95-102  probs = exp(log_probs[0]); decoder.decode(probs, beam_width)
 
-so: no unigram list (=> no character trie: every partial word is "OOV"), no hotwords, default
-``beam_prune_logp=-10``, ``token_min_logp=-5``, ``unk_score_offset=-10``, ``prune_history=False``; the blank is the
-LAST class (pyctcdecode appends "" to the labels).  Scores are natural-log; LM scores are
-``alpha * log10_score * ln(10) + beta`` per scored word.
+so: no hotwords, default ``beam_prune_logp=-10``, ``token_min_logp=-5``, ``unk_score_offset=-10``,
+``prune_history=False``; the blank is the LAST class (pyctcdecode appends "" to the labels).  Scores are natural-log; LM
+scores are ``alpha * log10_score * ln(10) + beta`` per scored word.
+
+TWO behaviours hide behind that one call, chosen by the SUFFIX of ``kenlm_model_path`` ("either .arpa or .bin file",
+beam_search_decoder.py:84) -- ``build_ctcdecoder`` as published:
+
+    unigrams is None and path.endswith(".arpa")  ->  unigrams = load_unigram_set_from_arpa(path)
+    otherwise (the reference's own ``3-gram-lm.binary``, infer.py:184)  ->  unigrams stay None (a warning)
+
+* ``unigrams=None``  ("binary" semantics): no character trie, EVERY partial word is "OOV" (``is_oov = 1.0``); a committed word
+  gets the unk offset iff it is not in the n-gram model's vocabulary.
+* unigrams given  ("arpa" semantics): ``unigram_set = {t in unigrams if t in kenlm_model}``, ``char_trie =
+  CharTrie.fromkeys(unigram_set)``; a partial word is OOV iff ``char_trie.has_node(partial) == 0`` -- i.e. iff it is NOT a prefix
+  of (or equal to) a word of the set; a committed word gets the unk offset iff ``word not in unigram_set or word not in
+  kenlm_model``.  ``load_unigram_set_from_arpa`` keeps the 1-gram lines that split into exactly THREE tab-separated fields
+  (probability, word, back-off): a unigram printed without a back-off weight (KenLM prints ``</s>`` and, in a unigram-only
+  model, every word that way) is in the model but NOT in the set.
+``LanguageModel(unigrams=...)`` / ``load_unigram_set_from_arpa`` / ``unigrams_for_path`` below restate exactly that; the
+prefix set ``_prefixes`` stands in for ``pygtrie.CharTrie.has_node``.
 
 The n-gram model is a plain back-off model read from ARPA text (``NgramLM``): KenLM's ``BaseScore(state, word)``
 on a full (order-1)-word history, which is what KenLM computes (its state minimisation does not change scores).
@@ -62,8 +78,8 @@ class NgramLM:
                 ngrams[words] = (prob, bo)
         return cls(order, ngrams)
 
-    def __contains__(self, word):
-        return word in self.vocab
+    def __contains__(self, word):       # kenlm.Model.__contains__: vocabulary index != 0, and index 0 is <unk>
+        return word in self.vocab and word != "<unk>"
 
     def begin_state(self):
         return ("<s>",)
@@ -87,24 +103,65 @@ class NgramLM:
         return score, new_state
 
 
-class LanguageModel:
-    """pyctcdecode.language_model.LanguageModel with unigrams=None (as build_ctcdecoder is called by the reference)."""
+def load_unigram_set_from_arpa(arpa_path):
+    """pyctcdecode.language_model.load_unigram_set_from_arpa as published: the words of the ``\\1-grams:`` section whose line
+    splits into exactly three TAB-separated fields; raises when none is found."""
+    unigrams = set()
+    with open(arpa_path, encoding="utf-8") as f:
+        start_1_gram = False
+        for line in f:
+            line = line.strip()
+            if line == "\\1-grams:":
+                start_1_gram = True
+            elif line == "\\2-grams:":
+                break
+            if start_1_gram and len(line) > 0:
+                parts = line.split("\t")
+                if len(parts) == 3:
+                    unigrams.add(parts[1])
+    if len(unigrams) == 0:
+        raise ValueError("No unigrams found in arpa file. Something is wrong with the file.")
+    return unigrams
 
-    def __init__(self, lm, alpha=0.5, beta=1.5, unk_score_offset=DEFAULT_UNK_LOGP_OFFSET, score_boundary=True):
+
+def unigrams_for_path(kenlm_model_path):
+    """What build_ctcdecoder(labels, kenlm_model_path, alpha, beta) -- the reference's call, no ``unigrams`` argument --
+    ends up with: the ARPA's own unigram list for a path that ENDS in ".arpa", None for anything else."""
+    if kenlm_model_path is not None and kenlm_model_path.endswith(".arpa"):
+        return load_unigram_set_from_arpa(kenlm_model_path)
+    return None
+
+
+class LanguageModel:
+    """pyctcdecode.language_model.LanguageModel.  ``unigrams=None`` is what build_ctcdecoder leaves for a ``.binary`` path,
+    a collection of words what it loads for an ``.arpa`` path (file header)."""
+
+    def __init__(self, lm, alpha=0.5, beta=1.5, unk_score_offset=DEFAULT_UNK_LOGP_OFFSET, score_boundary=True,
+                 unigrams=None):
         self.lm, self.alpha, self.beta, self.unk_score_offset, self.score_boundary = lm, alpha, beta, unk_score_offset, score_boundary
+        if unigrams is None:
+            self._unigram_set, self._prefixes = set(), None
+        else:
+            self._unigram_set = {t for t in set(unigrams) if t in lm}
+            # CharTrie.fromkeys(unigram_set).has_node(s)  <=>  s is a prefix of (or equal to) a key
+            self._prefixes = {w[:i] for w in self._unigram_set for i in range(1, len(w) + 1)}
 
     def get_start_state(self):
         return self.lm.begin_state() if self.score_boundary else ()
 
     def score_partial_token(self, partial_token):
-        unk_score = self.unk_score_offset * 1.0          # no char trie => is_oov = 1.0
+        if self._prefixes is None:
+            is_oov = 1.0                                  # no char trie
+        else:
+            is_oov = int(partial_token not in self._prefixes)
+        unk_score = self.unk_score_offset * is_oov
         if len(partial_token) > AVG_TOKEN_LEN:
             unk_score = unk_score * len(partial_token) / AVG_TOKEN_LEN
         return unk_score
 
     def score(self, prev_state, word, is_last_word=False):
         lm_score, end_state = self.lm.base_score(prev_state, word)
-        if word not in self.lm:
+        if (len(self._unigram_set) > 0 and word not in self._unigram_set) or word not in self.lm:
             lm_score += self.unk_score_offset
         if is_last_word and self.score_boundary:
             lm_score += self.lm.base_score(end_state, "</s>")[0]
@@ -197,8 +254,9 @@ def decode(log_probs_row, labels, beam_width, lm=None, **kw):
     return decode_beams(np.exp(np.asarray(log_probs_row, dtype=np.float64)), labels, beam_width, lm=lm, **kw)[0][0]
 
 
-def write_arpa(path, order, ngrams):
-    """ngrams: {tuple(words): (log10 p, log10 backoff)} -> ARPA text (test helper)."""
+def write_arpa(path, order, ngrams, no_backoff=()):
+    """ngrams: {tuple(words): (log10 p, log10 backoff)} -> ARPA text (test helper).  Unigrams named in ``no_backoff`` are
+    printed without the back-off field, as KenLM prints ``</s>``: in the model, not in pyctcdecode's unigram set."""
     with open(path, "w", encoding="utf-8") as f:
         f.write("\\data\\\n")
         for n in range(1, order + 1):
@@ -207,5 +265,5 @@ def write_arpa(path, order, ngrams):
             f.write(f"\n\\{n}-grams:\n")
             for w, (p, bo) in sorted(ngrams.items()):
                 if len(w) == n:
-                    f.write(f"{p:.6f}\t{' '.join(w)}" + (f"\t{bo:.6f}" if n < order else "") + "\n")
+                    f.write(f"{p:.6f}\t{' '.join(w)}" + (f"\t{bo:.6f}" if n < order and not (n == 1 and w[0] in no_backoff) else "") + "\n")
         f.write("\n\\end\\\n")

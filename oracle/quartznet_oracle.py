@@ -33,15 +33,23 @@ CONSTANT = 1e-5  # parts/features.py:14
 
 
 # --------------------------------------------------------------------------- A4
-def slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=64, fmin=0.0, fmax=None):
-    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with htk=False, norm='slaney'.
+def slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=64, fmin=0.0, fmax=None, variant="librosa"):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with htk=False, norm='slaney', dtype=float32.
 
-    Call site: parts/features.py:199-205.  Published algorithm (librosa 0.7/0.8
-    ``filters.mel``): Slaney mel scale (linear below 1 kHz at 200/3 Hz per mel,
-    log above with step log(6.4)/27), n_mels+2 band edges, triangular weights
-    ``max(0, min(lower, upper))`` from the ramps, then area normalisation
-    ``2 / (f[i+2] - f[i])``.  float64 maths, float32 result [n_mels, 1+n_fft//2].
+    Call site: parts/features.py:199-205 (positional ``(sr, n_fft, ...)`` => librosa < 0.10).  Published algorithm (librosa
+    0.7/0.8 ``filters.mel``): Slaney mel scale (linear below 1 kHz at 200/3 Hz per mel, log above with step log(6.4)/27),
+    n_mels+2 band edges, FFT bin centres ``linspace(0, sr/2, 1+n_fft//2)``, triangular weights
+    ``max(0, min(lower, upper))`` from the ramps, then area normalisation ``2 / (f[i+2] - f[i])``.
+
+    variant="librosa" (default) follows the published ORDER OF ROUNDINGS: ``weights`` is allocated as float32, every
+    un-normalised triangle row is STORED into it (first rounding), then ``weights *= enorm[:, np.newaxis]`` multiplies the
+    float32 values by the float64 normalisers in float64 and rounds back into the float32 array (second rounding).
+    variant="f64" is rounds 1-5's restatement -- triangle and normalisation in float64, one rounding at the end: 140 of the
+    498 non-zero coefficients of the reference's (16000, 512, 64, 0, 8000) bank differ from "librosa" by 1 ulp.  Parity is
+    unpinned either way (librosa absent); tools/pin_third_party.py reports which variant a real librosa matches.
     """
+    if variant not in ("librosa", "f64"):
+        raise ValueError("variant: 'librosa' or 'f64'")
     if fmax is None:
         fmax = sr / 2.0
     f_sp = 200.0 / 3
@@ -65,13 +73,13 @@ def slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=64, fmin=0.0, fmax=None):
     mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
     fdiff = np.diff(mel_f)
     ramps = np.subtract.outer(mel_f, fftfreqs)
-    weights = np.zeros((n_mels, int(1 + n_fft // 2)), dtype=np.float64)
+    weights = np.zeros((n_mels, int(1 + n_fft // 2)), dtype=np.float32 if variant == "librosa" else np.float64)
     for i in range(n_mels):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0, np.minimum(lower, upper))
+        weights[i] = np.maximum(0, np.minimum(lower, upper))      # "librosa": float64 -> float32 here
     enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
-    weights *= enorm[:, np.newaxis]
+    weights *= enorm[:, np.newaxis]                               # "librosa": float32 * float64 in float64 -> float32
     return weights.astype(np.float32)
 
 

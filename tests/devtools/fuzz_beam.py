@@ -27,11 +27,15 @@ for _ in range(60):
 for w in words[:10]:
     ng[("<s>", w)] = (float(-0.5 - rng.random()), -0.1)
     ng[(w, "</s>")] = (float(-0.4 - rng.random()), 0.0)
+# a few words (and </s>) printed WITHOUT a back-off weight: in the model, outside pyctcdecode's unigram list and trie
+no_bo = ("</s>",) + tuple(words[3::9])
+for w in no_bo:
+    ng[(w,)] = (ng[(w,)][0], 0.0)
 abc = os.path.join(tmp, "abc.arpa")
-BO.write_arpa(abc, 3, ng)
+BO.write_arpa(abc, 3, ng, no_backoff=no_bo)
 
 
-STATS = {"cases": 0, "near_tie_excuses": 0}
+STATS = {"cases": 0, "near_tie_excuses": 0, "arpa_mode_cases": 0, "modes_differ": 0}
 
 
 def small_alphabet(Tn, V1, seed, k):
@@ -56,8 +60,21 @@ def run_case(case):
     else:
         lp = small_alphabet(Tn, 29, case, float(r.choice([0.5, 1.0, 2.0])))
     path = [None, toy, abc][lm_kind]
-    dec = BeamSearchDecoder(T.LABELS, lm_path=path, alpha=alpha, beta=beta)
     x = torch.from_numpy(lp[None]).cuda()
+    # with an LM: BOTH of pyctcdecode's behaviours -- "binary" (no unigram list) and "arpa" (unigram set + character trie)
+    texts = []
+    for mode in (("binary", "arpa") if path else ("none",)):
+        msg = _run_mode(case, kind, Tn, bw, lm_kind, alpha, beta, lp, x, path, mode, texts)
+        if msg:
+            return msg
+    if len(texts) == 2:
+        STATS["arpa_mode_cases"] += 1
+        STATS["modes_differ"] += int(texts[0] != texts[1])
+    return None
+
+
+def _run_mode(case, kind, Tn, bw, lm_kind, alpha, beta, lp, x, path, mode, texts):
+    dec = T.make_decoder(T.LABELS, path, mode, alpha, beta)
     ids, n, score = dec.decode_ids(x, bw)          # batch 1: the latency form, an utterance on four wavefronts (beam_group.hip)
     text = dec.decode_batch(x, bw)[0]
     # the same utterance as rows of a batch of 16: one wavefront per utterance (beam_wave.hip) -- must give the SAME BITS
@@ -65,9 +82,10 @@ def run_case(case):
     for row in (0, 15):
         k = int(n[0])
         if int(n16[row]) != k or not torch.equal(ids16[row, :k], ids[0, :k]) or float(score16[row]) != float(score[0]):
-            return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind}: the one-wavefront kernel (row {row} of 16) and the "
+            return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} {mode}: the one-wavefront kernel (row {row} of 16) and the "
                     f"four-wavefront kernel disagree: lengths {int(n16[row])} / {k}, scores {float(score16[row])!r} / {float(score[0])!r}")
-    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=alpha, beta=beta) if path else None
+    texts.append(text)
+    lm = T.oracle_lm(path, mode, alpha, beta)
     ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, bw, lm=lm)
     close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
     ok_text = text == ref[0][0] or (close and text == ref[1][0])
@@ -78,7 +96,7 @@ def run_case(case):
     if ok_text and ok_score:
         return None
     mine = [q for q in ref if q[0] == text]
-    return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} a {alpha} b {beta}: device {text[-30:]!r} {float(score[0]):.4f} | "
+    return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} {mode} a {alpha} b {beta}: device {text[-30:]!r} {float(score[0]):.4f} | "
             f"oracle {ref[0][0][-30:]!r} {ref[0][2]:.4f} | oracle's score of the device text {[round(float(q[2]), 4) for q in mine][:1]}")
 
 

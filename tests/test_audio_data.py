@@ -57,6 +57,21 @@ def test_sinc_table_matches_oracle():
     assert np.abs(tab[:, 0] - win).max() < 1e-7 and abs(tab[0, 0] - 0.9475937167399596) < 1e-7
 
 
+def test_resampler_oracle_length_rule_is_librosas():
+    """librosa.load(sr=16000) -> librosa.resample(fix=True): resampy computes int(n * ratio) samples, librosa pads them with
+    zeros to ceil(n * ratio), both products in float64 (infer.py:200).  The reference's 8 -> 16 kHz case cannot tell the two
+    rules apart; 11 025 -> 16 000 Hz can: 5 000 samples -> 7 256 computed, 7 257 returned."""
+    from oracle import audio_oracle as AO
+    r = np.random.RandomState(4)
+    for sr_in, sr_out, n in ((8000, 16000, 333), (11025, 16000, 5000), (11025, 16000, 300), (16000, 8000, 301), (44100, 16000, 1000)):
+        x = r.randn(n).astype(np.float32)
+        y = AO.resample(x, sr_in, sr_out)
+        ratio = float(sr_out) / sr_in
+        assert len(y) == int(np.ceil(n * ratio))
+        assert not y[int(n * ratio):].any()                       # the padding fix_length adds
+    assert len(AO.resample(np.zeros(5000, dtype=np.float32), 11025, 16000)) == 7257 and int(5000 * (16000.0 / 11025)) == 7256
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr_in,sr_out", [(8000, 16000), (16000, 8000), (11025, 16000), (16000, 24000), (48000, 16000)])
 def test_device_resampler_matches_oracle(gpu, sr_in, sr_out):

@@ -21,8 +21,27 @@ def toy_lm(tmp_path):
           ("<s>", "ab"): (-0.4, -0.1), ("ab", "ba"): (-0.5, -0.2), ("ba", "</s>"): (-0.3, 0.0), ("ab", "cab"): (-0.7, 0.0),
           ("<s>", "ab", "ba"): (-0.2, 0.0), ("ab", "ba", "</s>"): (-0.1, 0.0)}
     path = os.path.join(tmp_path, "toy.arpa")
-    BO.write_arpa(path, 3, ng)
+    BO.write_arpa(path, 3, ng, no_backoff=("</s>",))        # as KenLM prints it: </s> is in the model, not in the unigram list
     return path, ng
+
+
+# The LM behaviours of pyctcdecode's build_ctcdecoder (oracle/beam_oracle.py header): "binary" = no unigram list (what the
+# reference got from 3-gram-lm.binary), "arpa" = unigram set + character trie read from the ARPA file (what it gets from a
+# path ending in .arpa -- the only kind of file this library reads).  Every device test with an LM runs both.
+LM_MODES = ["none", "binary", "arpa"]
+
+
+def make_decoder(labels, path, mode, alpha=0.7, beta=1.1):
+    from viet_asr_amd.beam import BeamSearchDecoder
+    return BeamSearchDecoder(labels, lm_path=path if mode != "none" else None, alpha=alpha, beta=beta,
+                             unigrams=None if mode == "binary" else "auto")
+
+
+def oracle_lm(path, mode, alpha=0.7, beta=1.1):
+    if mode == "none":
+        return None
+    return BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=alpha, beta=beta,
+                            unigrams=BO.unigrams_for_path(path) if mode == "arpa" else None)
 
 
 def random_posteriors(T, V1, seed, peaky=4.0):
@@ -88,6 +107,101 @@ def test_lm_changes_the_ranking(tmp_path):
     a = BO.decode_beams(np.exp(lp.astype(np.float64)), LABELS, 16)
     b = BO.decode_beams(np.exp(lp.astype(np.float64)), LABELS, 16, lm=lm)
     assert a[0][2] == a[0][1] and b[0][2] != b[0][1]              # combined score carries the LM term
+
+
+def mode_lm(tmp_path):
+    """A bigram model over {ab, ba, a}: "ab" and "a" carry a back-off weight (=> in pyctcdecode's unigram list for an .arpa
+    path), "ba" does not (=> in the model, outside the list)."""
+    ng = {("<s>",): (-99.0, -0.3), ("</s>",): (-1.0, 0.0), ("<unk>",): (-2.5, 0.0),
+          ("ab",): (-1.2, -0.2), ("ba",): (-1.2, 0.0), ("a",): (-1.5, -0.1),
+          ("<s>", "ab"): (-0.6, 0.0), ("<s>", "ba"): (-0.6, 0.0)}
+    path = os.path.join(tmp_path, "mode.arpa")
+    BO.write_arpa(path, 2, ng, no_backoff=("</s>", "ba"))
+    return path
+
+
+MODE_LABELS = [" ", "a", "b"]
+
+
+def mode_case_set_membership():
+    """"ba" is acoustically ahead of "ab" (0.55^2 vs 0.45^2); both are words of the model with the same probabilities."""
+    p = np.array([[0.0, 0.45, 0.55, 0.0], [0.0, 0.0, 0.0, 1.0], [0.0, 0.55, 0.45, 0.0]]) + 1e-9
+    return np.log(p / p.sum(1, keepdims=True)).astype(np.float32)
+
+
+def mode_case_partial_word_prune():
+    """Frame 0 prefers blank (0.61) to 'a' (0.38), frame 1 is 'b': the beam "a" needs to survive frame 0 for "ab" to exist."""
+    p = np.array([[0.005, 0.38, 0.005, 0.61], [0.0067, 0.0067, 0.98, 0.0066]])
+    return np.log(p / p.sum(1, keepdims=True)).astype(np.float32)
+
+
+def test_unigram_list_is_read_as_pyctcdecode_reads_it(tmp_path):
+    from viet_asr_amd import beam
+    path = mode_lm(str(tmp_path))
+    want = {"<s>", "<unk>", "ab", "a"}                       # three tab-separated fields; "ba" and "</s>" have two
+    assert BO.load_unigram_set_from_arpa(path) == want == beam.load_unigram_set_from_arpa(path)
+    assert BO.unigrams_for_path(path) == want and BO.unigrams_for_path(path[:-5] + ".binary") is None
+    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), unigrams=want)
+    assert lm._unigram_set == {"<s>", "ab", "a"}             # "t in kenlm_model": <unk> is vocabulary index 0
+    assert lm._prefixes == {"<", "<s", "<s>", "a", "ab"}
+    assert lm.score_partial_token("a") == 0.0 and lm.score_partial_token("b") == -10.0
+    assert lm.score_partial_token("abababab") == -10.0 * 8 / 6
+    none = BO.LanguageModel(BO.NgramLM.from_arpa(path))
+    assert none.score_partial_token("a") == -10.0
+    # a unigram-only ARPA prints no back-off at all: pyctcdecode finds no unigrams and raises
+    one = os.path.join(str(tmp_path), "one.arpa")
+    BO.write_arpa(one, 1, {("<s>",): (-99.0, 0.0), ("</s>",): (-1.0, 0.0), ("<unk>",): (-2.0, 0.0), ("a",): (-1.0, 0.0)})
+    for f in (BO.load_unigram_set_from_arpa, beam.load_unigram_set_from_arpa):
+        with pytest.raises(ValueError):
+            f(one)
+
+
+def test_the_two_lm_behaviours_rank_differently(tmp_path):
+    """pyctcdecode's build_ctcdecoder on an .arpa path (unigram set + character trie) against the same model as a .binary
+    (no unigram list), on inputs where the difference is provable by hand."""
+    path = mode_lm(str(tmp_path))
+    # (1) a committed word outside the unigram list gets the unk offset only in arpa mode: alpha * -10 * ln 10 = -11.5
+    lp = mode_case_set_membership()
+    got = {m: BO.decode_beams(np.exp(lp.astype(np.float64)), MODE_LABELS, 8, lm=oracle_lm(path, m, 0.5, 1.5)) for m in ("binary", "arpa")}
+    assert got["binary"][0][0] == "ba" and got["arpa"][0][0] == "ab"
+    wide = {m: BO.decode_beams(np.exp(lp.astype(np.float64)), MODE_LABELS, 8, lm=oracle_lm(path, m, 0.5, 1.5), beam_prune_logp=-50.0)
+            for m in ("binary", "arpa")}
+    s_ba = {m: [b[2] for b in wide[m] if b[0] == "ba"][0] for m in wide}
+    assert abs((s_ba["binary"] - s_ba["arpa"]) - 0.5 * 10.0 * math.log(10.0)) < 1e-9
+    # (2) a partial word that is a prefix of a known word carries no penalty in arpa mode; in binary mode its -10 meets
+    #     beam_prune_logp = -10 and the beam is gone before the word can be completed
+    lp = mode_case_partial_word_prune()
+    got = {m: BO.decode_beams(np.exp(lp.astype(np.float64)), MODE_LABELS, 8, lm=oracle_lm(path, m, 0.5, 1.5)) for m in ("binary", "arpa")}
+    assert got["binary"][0][0] == "b" and "ab" not in [b[0] for b in got["binary"]]
+    assert got["arpa"][0][0] == "ab"
+
+
+def test_trie_buckets_hold_every_node_where_the_kernel_looks(tmp_path):
+    """viet_asr_amd.beam._trie_buckets against csrc/beam_common.h trie_has_node: from the home bucket, bucket by bucket, until
+    the key or a bucket with a free cell."""
+    from viet_asr_amd import beam
+    r = np.random.RandomState(3)
+    for n in (0, 1, 7, 500, 40000):
+        keys = np.unique(r.randint(0, 2**63, size=n, dtype=np.int64).astype(np.uint64) | np.uint64(1))
+        cells = beam._trie_buckets(keys)
+        nb = len(cells)
+        assert nb >= 16 and nb & (nb - 1) == 0 and 2 * nb >= 4 * len(keys)
+        assert sorted(cells[cells != 0].tolist()) == sorted(keys.tolist())
+        def has(k):
+            i = int(beam._home(np.array([k], dtype=np.uint64), nb)[0])
+            for _ in range(nb):
+                if k in cells[i]:
+                    return True
+                if (cells[i] == 0).any():
+                    return False
+                i = (i + 1) & (nb - 1)
+            return False
+        for k in keys[:300]:
+            assert has(k)
+        for k in (r.randint(0, 2**63, size=100, dtype=np.int64).astype(np.uint64) | np.uint64(1)):
+            assert has(k) == (k in keys)
+        full = (cells != 0).all(1).mean() if nb else 0.0
+        assert full <= 0.12, full                              # a full bucket is what costs a lookup a second load
 
 
 # ------------------------------------------------------------------------------------------- device
@@ -163,17 +277,17 @@ def test_reciprocal_forms_of_the_wave_kernels_integer_divisions():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_lm", [False, True])
+@pytest.mark.parametrize("lm_mode", LM_MODES)
 @pytest.mark.parametrize("beam_width,V1,seed", [(8, 29, 1), (32, 29, 2), (128, 29, 3), (20, 91, 4)])
-def test_device_beam_search_matches_oracle(gpu, tmp_path, use_lm, beam_width, V1, seed):
+def test_device_beam_search_matches_oracle(gpu, tmp_path, lm_mode, beam_width, V1, seed):
     from viet_asr_amd.beam import BeamSearchDecoder
     labels = LABELS if V1 == 29 else [" "] + [chr(0x100 + i) for i in range(89)]
     path, _ = toy_lm(str(tmp_path))
     lp = np.stack([random_posteriors(40 + 7 * b, V1, seed * 10 + b)[:40] for b in range(3)])
-    dec = BeamSearchDecoder(labels, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    dec = make_decoder(labels, path, lm_mode)
     ids, n, score = dec.decode_ids(torch.from_numpy(lp).to(gpu), beam_width)
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), beam_width)
-    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
+    lm = oracle_lm(path, lm_mode)
     for b in range(3):
         ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), labels, beam_width, lm=lm)
         # near-ties between the two best hypotheses may legitimately resolve differently (fp rounding)
@@ -181,6 +295,30 @@ def test_device_beam_search_matches_oracle(gpu, tmp_path, use_lm, beam_width, V1
         assert texts[b] == ref[0][0] or (close and texts[b] == ref[1][0]), (texts[b], ref[:2])
         if texts[b] == ref[0][0]:
             assert abs(float(score[b]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50), (float(score[b]), ref[0][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 16])
+def test_device_beam_search_has_both_lm_behaviours(gpu, tmp_path, rows):
+    """The hand-checkable inputs of test_the_two_lm_behaviours_rank_differently on the device, in both kernel forms (1 row:
+    four wavefronts per utterance, 16 rows: one), and the default (`unigrams="auto"`) follows the path's suffix as
+    pyctcdecode's build_ctcdecoder does (beam_search_decoder.py:82-87: "either .arpa or .bin file")."""
+    import shutil
+    from viet_asr_amd.beam import BeamSearchDecoder
+    path = mode_lm(str(tmp_path))
+    other = os.path.join(str(tmp_path), "same_model.txt")       # ARPA text under a suffix pyctcdecode reads no unigrams from
+    shutil.copy(path, other)
+    for lp, want in ((mode_case_set_membership(), {"binary": "ba", "arpa": "ab"}),
+                     (mode_case_partial_word_prune(), {"binary": "b", "arpa": "ab"})):
+        x = torch.from_numpy(np.repeat(lp[None], rows, 0)).to(gpu)
+        for mode in ("binary", "arpa"):
+            dec = make_decoder(MODE_LABELS, path, mode, 0.5, 1.5)
+            texts = dec.decode_batch(x, 8)
+            ref = BO.decode_beams(np.exp(lp.astype(np.float64)), MODE_LABELS, 8, lm=oracle_lm(path, mode, 0.5, 1.5))
+            assert texts == [want[mode]] * rows == [ref[0][0]] * rows, (mode, texts, ref[:2])
+            assert abs(float(dec.decode_ids(x, 8)[2][0]) - ref[0][2]) < 2e-3
+        assert BeamSearchDecoder(MODE_LABELS, lm_path=path, alpha=0.5, beta=1.5).decode_batch(x, 8) == [want["arpa"]] * rows
+        assert BeamSearchDecoder(MODE_LABELS, lm_path=other, alpha=0.5, beta=1.5).decode_batch(x, 8) == [want["binary"]] * rows
 
 
 @pytest.mark.gpu
@@ -203,8 +341,8 @@ def test_beam_module_on_model_output(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_lm", [False, True])
-def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
+@pytest.mark.parametrize("lm_mode", LM_MODES)
+def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, lm_mode):
     """Flat posteriors over 150 frames: every class clears token_min_logp, 64 beams x 29 candidates = 1856 pairs do not
     fit the merge table (1434), so every frame takes two candidate passes with the first pass's survivors carried into
     the second selection; multi-digit radix select and heavy prefix merging are all on the path.  Compared with the
@@ -212,10 +350,10 @@ def test_device_beam_search_flat_posteriors_long(gpu, tmp_path, use_lm):
     from viet_asr_amd.beam import BeamSearchDecoder
     path, _ = toy_lm(str(tmp_path))
     lp = np.stack([random_posteriors(150, 29, 70 + b, peaky=1.0) for b in range(2)])
-    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    dec = make_decoder(LABELS, path, lm_mode)
     ids, n, score = dec.decode_ids(torch.from_numpy(lp).to(gpu), 64)
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), 64)
-    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
+    lm = oracle_lm(path, lm_mode)
     for b in range(2):
         ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, 64, lm=lm)
         close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
@@ -239,18 +377,18 @@ def ctc_like_posteriors(T, V1, seed, p_blank=0.7):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_lm", [False, True])
+@pytest.mark.parametrize("lm_mode", LM_MODES)
 @pytest.mark.parametrize("beam_width", [4, 32, 128])
-def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
+def test_device_beam_search_blank_runs(gpu, tmp_path, lm_mode, beam_width):
     """Blank-only frames on beams that all end in blank take an early exit in the kernel (scores shift, nothing else
     changes); the first frame of every run must still merge beams that differ in their last character only."""
     from viet_asr_amd.beam import BeamSearchDecoder
     path, _ = toy_lm(str(tmp_path))
     lp = np.stack([ctc_like_posteriors(120, 29, 300 + b, p_blank=(0.5, 0.7, 0.9, 1.0)[b]) for b in range(4)])
-    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    dec = make_decoder(LABELS, path, lm_mode)
     ids, n, score = dec.decode_ids(torch.from_numpy(lp).to(gpu), beam_width)
     texts = dec.decode_batch(torch.from_numpy(lp).to(gpu), beam_width)
-    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1) if use_lm else None
+    lm = oracle_lm(path, lm_mode)
     for b in range(4):
         ref = BO.decode_beams(np.exp(lp[b].astype(np.float64)), LABELS, beam_width, lm=lm)
         close = len(ref) > 1 and abs(ref[0][2] - ref[1][2]) < 1e-3
@@ -260,8 +398,8 @@ def test_device_beam_search_blank_runs(gpu, tmp_path, use_lm, beam_width):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_lm", [False, True])
-def test_device_beam_search_per_row_frame_counts(gpu, tmp_path, use_lm):
+@pytest.mark.parametrize("lm_mode", LM_MODES)
+def test_device_beam_search_per_row_frame_counts(gpu, tmp_path, lm_mode):
     """vasr_beam_search_rows_f32: a row searched over its own frame count inside a padded batch gives exactly what the
     truncated row gives alone (ids and score bit-identical; 0 frames -> empty hypothesis)."""
     from viet_asr_amd.beam import BeamSearchDecoder
@@ -269,7 +407,7 @@ def test_device_beam_search_per_row_frame_counts(gpu, tmp_path, use_lm):
     T = 90
     lp = np.stack([ctc_like_posteriors(T, 29, 500 + b, p_blank=0.6) for b in range(5)])
     frames = [T, 37, 1, 64, 0]
-    dec = BeamSearchDecoder(LABELS, lm_path=path if use_lm else None, alpha=0.7, beta=1.1)
+    dec = make_decoder(LABELS, path, lm_mode)
     x = torch.from_numpy(lp).to(gpu)
     ids, n, score = dec.decode_ids(x, 32, frames=frames)
     assert int(n[4]) == 0
@@ -372,8 +510,8 @@ for V1, labels in ((29, T.LABELS),):
     lp = np.stack([T.ctc_like_posteriors(160, V1, 900 + b, p_blank=0.55) for b in range(6)] +
                   [T.random_posteriors(160, V1, 950 + b, peaky=k) for b, k in enumerate((0.5, 2.0, 4.0))])
     x = torch.from_numpy(lp).cuda()
-    for lm in (None, path):
-        dec = BeamSearchDecoder(labels, lm_path=lm, alpha=0.7, beta=1.1)
+    for mode in T.LM_MODES:
+        dec = T.make_decoder(labels, path, mode)
         for w in (8, 50, 100, 128):
             ids, n, score = dec.decode_ids(x, w)
             out.append((ids.cpu().numpy(), n.cpu().numpy(), score.cpu().numpy()))
@@ -387,7 +525,7 @@ def test_wave_kernel_and_group_kernel_agree(gpu, tmp_path):
     compute unit: the serving latency; VASR_BEAM_GROUP pins the form in the devtools build): the same keys, merge arithmetic
     (ordered-int max, fixed-point sums), prune, radix select and rank rules on a different schedule and with twice the pairs
     per pass -- hypotheses, lengths and scores identical bit for bit on CTC-like, flat and peaked posteriors, widths 8 ... 128,
-    with and without the LM (flat posteriors at width 100-128 take several passes per frame and a radix select on most).
+    without an LM and with one in both of pyctcdecode's behaviours (flat posteriors at width 100-128 take several passes per frame and a radix select on most).
     Each form runs in its own process (the switch is read once)."""
     import subprocess, sys
     from conftest import ROOT
@@ -400,7 +538,7 @@ def test_wave_kernel_and_group_kernel_agree(gpu, tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(dst, allow_pickle=True))
-    assert len(res[0]) == len(res[1]) == 8
+    assert len(res[0]) == len(res[1]) == 12
     for other in (1,):
         for k, (a, b) in enumerate(zip(res[0], res[other])):
             n_a, n_b = np.frombuffer(a[1], np.int32), np.frombuffer(b[1], np.int32)

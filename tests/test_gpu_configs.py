@@ -157,38 +157,49 @@ def test_config4_quartznet15x5_beam128_lm_b64(gpu, tmp_path):
     assert len(ng) > 100000
     words = sorted(w[0] for w in ng if len(w) == 1 and not w[0].startswith("<"))
     logp_ctc = torch.from_numpy(synth.ctc_like_log_probs(64, 501, labels, words, seed=3)).to(gpu)
-    dec = BeamSearchDecoder(labels, lm_path=arpa, alpha=0.5, beta=1.5)
     nolm = BeamSearchDecoder(labels, lm_path=None)
-    olm = BO.LanguageModel(BO.NgramLM.from_arpa(arpa), alpha=0.5, beta=1.5)
-    # (round 5: EVERY row against the Python oracle -- 0.1 s per row -- where rounds 2-4 sampled five of the 128)
-    for tag, logp, rows in (("model", logp_model, range(64)), ("ctc-like", logp_ctc, range(64))):
-        ids, n, score = dec.decode_ids(logp, 128)
-        ids_b, n_b, score_b = dec.decode_ids(logp, 128)
-        assert torch.equal(n, n_b) and torch.equal(score, score_b) and _prefix_equal(ids, ids_b, n), tag   # deterministic
-        ids, n, score = ids.cpu().numpy(), n.cpu().numpy(), score.cpu().numpy()
-        assert np.isfinite(score).all()
-        texts = ["".join(labels[c] for c in ids[b, : n[b]]) for b in range(64)]
-        for b, t in enumerate(texts):
-            assert (ids[b, : n[b]] >= 0).all() and (ids[b, : n[b]] < 28).all()
-            assert "  " not in t and t == t.strip(), (tag, b, t[:60])
-        _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag)
-        # round 5: ALL 64 rows cross-checked between the two independent kernel forms -- the batch went through beam_wave.hip
-        # (one wavefront per utterance), slices of 8 rows go through beam_group.hip (four wavefronts per utterance, twice the
-        # pairs per pass): hypotheses, lengths and scores must be the same bits (the Python oracle covers the rows above)
-        for b0 in range(0, 64, 8):
-            ids_g, n_g, score_g = dec.decode_ids(logp[b0:b0 + 8].contiguous(), 128)
-            assert np.array_equal(n_g.cpu().numpy(), n[b0:b0 + 8]), (tag, b0)
-            assert np.array_equal(score_g.cpu().numpy(), score[b0:b0 + 8]), (tag, b0)
-            ig = ids_g.cpu().numpy()
-            for r_ in range(8):
-                assert np.array_equal(ig[r_, : n[b0 + r_]], ids[b0 + r_, : n[b0 + r_]]), (tag, b0 + r_)
-        if tag == "ctc-like":
-            plain = nolm.decode_batch(logp, 128)
-            changed = sum(a != b for a, b in zip(plain, texts))
-            assert changed >= 1, "the language model never changed a transcript: it is not being exercised"
-            wset = set(words)
-            in_vocab = lambda t: np.mean([w in wset for w in t.split()] or [0])
-            assert np.mean([in_vocab(t) for t in texts]) >= np.mean([in_vocab(t) for t in plain])
+    # round 6: BOTH of pyctcdecode's LM behaviours (oracle/beam_oracle.py header) -- "arpa" = what build_ctcdecoder does for the
+    # .arpa path handed over here (unigram set + character trie: the default), "binary" = no unigram list
+    texts_by_mode = {}
+    for mode in ("arpa", "binary"):
+        dec = BeamSearchDecoder(labels, lm_path=arpa, alpha=0.5, beta=1.5, unigrams="auto" if mode == "arpa" else None)
+        olm = BO.LanguageModel(BO.NgramLM.from_arpa(arpa), alpha=0.5, beta=1.5, unigrams=BO.unigrams_for_path(arpa) if mode == "arpa" else None)
+        # (round 5: EVERY row against the Python oracle -- 0.1 s per row -- where rounds 2-4 sampled five of the 128)
+        for tag, logp, rows in (("model", logp_model, range(64)), ("ctc-like", logp_ctc, range(64))):
+            ids, n, score = dec.decode_ids(logp, 128)
+            ids_b, n_b, score_b = dec.decode_ids(logp, 128)
+            assert torch.equal(n, n_b) and torch.equal(score, score_b) and _prefix_equal(ids, ids_b, n), tag   # deterministic
+            ids, n, score = ids.cpu().numpy(), n.cpu().numpy(), score.cpu().numpy()
+            assert np.isfinite(score).all()
+            texts = ["".join(labels[c] for c in ids[b, : n[b]]) for b in range(64)]
+            for b, t in enumerate(texts):
+                assert (ids[b, : n[b]] >= 0).all() and (ids[b, : n[b]] < 28).all()
+                assert "  " not in t and t == t.strip(), (tag, b, t[:60])
+            _beam_rows_match_oracle(texts, score, logp, rows, labels, olm, tag + "/" + mode)
+            texts_by_mode[(tag, mode)] = texts
+            # round 5: ALL 64 rows cross-checked between the two independent kernel forms -- the batch went through beam_wave.hip
+            # (one wavefront per utterance), slices of 8 rows go through beam_group.hip (four wavefronts per utterance, twice the
+            # pairs per pass): hypotheses, lengths and scores must be the same bits (the Python oracle covers the rows above)
+            for b0 in range(0, 64, 8):
+                ids_g, n_g, score_g = dec.decode_ids(logp[b0:b0 + 8].contiguous(), 128)
+                assert np.array_equal(n_g.cpu().numpy(), n[b0:b0 + 8]), (tag, b0)
+                assert np.array_equal(score_g.cpu().numpy(), score[b0:b0 + 8]), (tag, b0)
+                ig = ids_g.cpu().numpy()
+                for r_ in range(8):
+                    assert np.array_equal(ig[r_, : n[b0 + r_]], ids[b0 + r_, : n[b0 + r_]]), (tag, b0 + r_)
+            if tag == "ctc-like":
+                plain = nolm.decode_batch(logp, 128)
+                changed = sum(a != b for a, b in zip(plain, texts))
+                assert changed >= 1, "the language model never changed a transcript: it is not being exercised"
+                wset = set(words)
+                in_vocab = lambda t: np.mean([w in wset for w in t.split()] or [0])
+                assert np.mean([in_vocab(t) for t in texts]) >= np.mean([in_vocab(t) for t in plain])
+    # the two behaviours are not the same search: on word-spelling posteriors the trie keeps partial words of the vocabulary alive
+    assert texts_by_mode[("ctc-like", "arpa")] != texts_by_mode[("ctc-like", "binary")]
+    from test_gpu_parity import _record
+    _record("config4_lm_modes", rows_that_differ={t: sum(a != b for a, b in zip(texts_by_mode[(t, "arpa")], texts_by_mode[(t, "binary")]))
+                                                   for t in ("model", "ctc-like")})
+    dec = BeamSearchDecoder(labels, lm_path=arpa, alpha=0.5, beta=1.5)
     lm = dec._get_lm()
     assert lm.n_ngrams == len(ng) and 0.05 < lm.table_load < 0.6
     # batched + overlapped form (search of batch k on a side stream): same answer as the serial call

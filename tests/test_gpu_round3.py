@@ -151,21 +151,21 @@ def test_beam_final_pass_goes_through_the_lm_score_cache(gpu, tmp_path):
         p /= p.sum(1, keepdims=True)
         return np.log(p).astype(np.float32)
 
-    dec = BeamSearchDecoder(T.LABELS, lm_path=path, alpha=0.7, beta=1.1)
-    lm = BO.LanguageModel(BO.NgramLM.from_arpa(path), alpha=0.7, beta=1.1)
-    scores = {}
-    for name, sp in (("space_was_a_candidate", 0.02), ("never", 1e-6)):       # token_min_logp = -5 -> p >= 6.7e-3
-        lp = posteriors(sp)
-        ids, n, score = dec.decode_ids(torch.from_numpy(lp[None]).to(gpu), 16)
-        text = dec.decode_batch(torch.from_numpy(lp[None]).to(gpu), 16)[0]
-        ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, 16, lm=lm)
-        assert text == ref[0][0] == "ab", (name, text, ref[:2])
-        assert abs(float(score[0]) - ref[0][2]) < 2e-3, (name, float(score[0]), ref[0][2])
-        scores[name] = ref[0][2] - ref[0][1]                    # the LM part of the best hypothesis
-    with_eos, _ = lm.score(lm.get_start_state(), "ab", is_last_word=True)
-    without, _ = lm.score(lm.get_start_state(), "ab", is_last_word=False)
-    assert abs(with_eos - without) > 0.1
-    assert abs(scores["never"] - with_eos) < 1e-6 and abs(scores["space_was_a_candidate"] - without) < 1e-6
+    for mode in ("binary", "arpa"):                         # both of pyctcdecode's LM behaviours (test_beam.LM_MODES)
+        dec, lm = T.make_decoder(T.LABELS, path, mode), T.oracle_lm(path, mode)
+        scores = {}
+        for name, sp in (("space_was_a_candidate", 0.02), ("never", 1e-6)):       # token_min_logp = -5 -> p >= 6.7e-3
+            lp = posteriors(sp)
+            ids, n, score = dec.decode_ids(torch.from_numpy(lp[None]).to(gpu), 16)
+            text = dec.decode_batch(torch.from_numpy(lp[None]).to(gpu), 16)[0]
+            ref = BO.decode_beams(np.exp(lp.astype(np.float64)), T.LABELS, 16, lm=lm)
+            assert text == ref[0][0] == "ab", (name, text, ref[:2])
+            assert abs(float(score[0]) - ref[0][2]) < 2e-3, (name, float(score[0]), ref[0][2])
+            scores[name] = ref[0][2] - ref[0][1]                    # the LM part of the best hypothesis
+        with_eos, _ = lm.score(lm.get_start_state(), "ab", is_last_word=True)
+        without, _ = lm.score(lm.get_start_state(), "ab", is_last_word=False)
+        assert abs(with_eos - without) > 0.1
+        assert abs(scores["never"] - with_eos) < 1e-6 and abs(scores["space_was_a_candidate"] - without) < 1e-6
 
 
 _FUSED_FUZZ = r"""

@@ -56,12 +56,14 @@ def main():
         arpa = os.path.join(tempfile.mkdtemp(prefix="vasr_lm_"), "synthetic3.arpa")
         synth.synthetic_arpa(arpa, cfg["labels"], seed=3)
         words = sorted(w[0] for w in read_arpa(arpa)[1] if len(w) == 1 and not w[0].startswith("<"))
-        dec = BeamSearchDecoder(cfg["labels"], lm_path=arpa, alpha=0.5, beta=1.5)
         lp = eng.forward(wav, ln, want_logp=True, want_pred=False)["logp"]
         lp_ctc = torch.from_numpy(synth.ctc_like_log_probs(a.batch, lp.shape[1], cfg["labels"], words, seed=5)).to(dev)
-        for width in (20, 50, 100, 128):
-            out[f"beam{width}_search_model_ms"] = lat(lambda: dec.decode_ids(lp, width), max(10, a.calls // 3))
-            out[f"beam{width}_search_ctc_like_ms"] = lat(lambda: dec.decode_ids(lp_ctc, width), max(10, a.calls // 3))
+        # both of pyctcdecode's LM behaviours (viet_asr_amd/beam.py): no unigram list ("binary"), unigram set + trie ("arpa")
+        for mode in ("binary", "arpa"):
+            dec = BeamSearchDecoder(cfg["labels"], lm_path=arpa, alpha=0.5, beta=1.5, unigrams=None if mode == "binary" else "auto")
+            for width in (20, 50, 100, 128):
+                out[f"beam{width}_search_model_{mode}_ms"] = lat(lambda: dec.decode_ids(lp, width), max(10, a.calls // 3))
+                out[f"beam{width}_search_ctc_like_{mode}_ms"] = lat(lambda: dec.decode_ids(lp_ctc, width), max(10, a.calls // 3))
     print(json.dumps(out))
 
 

@@ -33,10 +33,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-BEAM_CASES = [  # (classes incl. blank, frames, beam width, with LM, seed) -- the reference's own widths: 20 ctor, 50 app.py, 100 CLI
-    (29, 120, 20, True, 1), (29, 200, 50, True, 2), (29, 200, 100, True, 3), (29, 150, 128, True, 4),
-    (29, 150, 50, False, 5), (91, 120, 100, True, 6),
+# (classes incl. blank, frames, beam width, LM mode, seed) -- the reference's own widths: 20 ctor, 50 app.py, 100 CLI.
+# LM mode: 0 = no LM; 2 = the model handed over as "lmK.arpa" -- build_ctcdecoder then reads the file's unigrams and builds its
+# character trie (oracle/beam_oracle.py header); 1 = the SAME ARPA text as "lmK.txt": kenlm reads it all the same (it sniffs
+# the content), but pyctcdecode loads unigrams for the ".arpa" suffix only, so this is the behaviour the reference got from
+# its `3-gram-lm.binary` (no unigram list).  Both are pinned; `caseK_mode` records which one a case used.
+LM_MODE_NAMES = ["none", "binary", "arpa"]
+BEAM_CASES = [
+    (29, 120, 20, 2, 1), (29, 200, 50, 2, 2), (29, 200, 100, 2, 3), (29, 150, 128, 2, 4),
+    (29, 150, 50, 0, 5), (91, 120, 100, 2, 6),
+    (29, 120, 20, 1, 1), (29, 200, 100, 1, 3), (91, 120, 100, 1, 6),
 ]
+
+
+def lm_file_for(d, k, lm_mode, labels, seed):
+    """Writes case k's synthetic 3-gram model under the name its mode asks for; -> (path or None, n-grams)."""
+    from viet_asr_amd import synth
+    path = os.path.join(d, f"lm{k}" + (".arpa" if lm_mode != 1 else ".txt"))
+    ng = synth.synthetic_arpa(path, labels, n_words=2000, n_bigrams=4000, n_trigrams=4000, seed=seed)
+    return (path if lm_mode else None), ng
 
 
 def versions(*mods):
@@ -57,7 +72,9 @@ def pin_mel(out):
         fb = librosa.filters.mel(sr=16000, n_fft=512, n_mels=64, fmin=0, fmax=8000)   # same function, keyword-only API
     np.savez_compressed(os.path.join(out, "thirdparty_mel.npz"), fb=np.asarray(fb, dtype=np.float32),
                         versions=str(versions("librosa", "numpy")))
-    print("mel", fb.shape, float(fb.sum()), float(fb.max()))
+    from oracle.quartznet_oracle import slaney_mel_filterbank
+    same = [v for v in ("librosa", "f64") if np.array_equal(slaney_mel_filterbank(16000, 512, 64, 0.0, 8000.0, variant=v), fb)]
+    print("mel", fb.shape, fb.dtype, float(fb.sum()), float(fb.max()), "| equals the restatement's variant(s):", same or "NONE")
 
 
 def pin_resample(out):
@@ -71,9 +88,16 @@ def pin_resample(out):
     path = os.path.join(d, "pin8k.wav")
     sf.write(path, pcm, 8000, subtype="PCM_16")
     y, sr = librosa.load(path, sr=16000)                                                # infer.py:200
+    # a second file at 11 025 Hz: ceil(n * ratio) != int(n * ratio) there (5 000 samples -> 7 256 computed, 7 257 returned),
+    # which pins librosa's fix_length rule around resampy's int(n * ratio) output -- at 8 -> 16 kHz the two rules cannot be told apart
+    pcm2 = pcm[:5000]
+    path2 = os.path.join(d, "pin11k.wav")
+    sf.write(path2, pcm2, 11025, subtype="PCM_16")
+    y2, sr2 = librosa.load(path2, sr=16000)
     np.savez_compressed(os.path.join(out, "thirdparty_resample.npz"), pcm=pcm, y=np.asarray(y, dtype=np.float32), sr_in=8000,
-                        sr_out=int(sr), versions=str(versions("librosa", "resampy", "soundfile")))
-    print("resample", pcm.shape, "->", y.shape)
+                        sr_out=int(sr), pcm2=pcm2, y2=np.asarray(y2, dtype=np.float32), sr_in2=11025, sr_out2=int(sr2),
+                        versions=str(versions("librosa", "resampy", "soundfile")))
+    print("resample", pcm.shape, "->", y.shape, "|", pcm2.shape, "->", y2.shape)
 
 
 def pin_stftconv(out):
@@ -94,16 +118,16 @@ def pin_beam(out):
     from viet_asr_amd import configs, synth
     store = {"versions": str(versions("pyctcdecode", "kenlm")), "n_cases": len(BEAM_CASES)}
     d = tempfile.mkdtemp(prefix="vasr_pin_")
-    for k, (classes, frames, width, with_lm, seed) in enumerate(BEAM_CASES):
+    for k, (classes, frames, width, lm_mode, seed) in enumerate(BEAM_CASES):
         labels = configs.builtin("quartznet15x5" if classes == 29 else "quartznet12x1_vi")["labels"]
-        arpa = os.path.join(d, f"lm{k}.arpa")
-        ng = synth.synthetic_arpa(arpa, labels, n_words=2000, n_bigrams=4000, n_trigrams=4000, seed=seed)
+        lm_path, ng = lm_file_for(d, k, lm_mode, labels, seed)
         words = sorted(w[0] for w in ng if len(w) == 1 and not w[0].startswith("<"))
         logp = synth.ctc_like_log_probs(1, frames, labels, words, seed=seed)[0]
         probs = np.exp(logp.astype(np.float64)).astype(np.float32)                      # what the reference hands over (:97)
-        dec = build_ctcdecoder(list(labels), kenlm_model_path=arpa if with_lm else None, alpha=0.5, beta=1.5)
+        dec = build_ctcdecoder(list(labels), kenlm_model_path=lm_path, alpha=0.5, beta=1.5)   # the reference's call (:82-87)
         beams = dec.decode_beams(probs, beam_width=width)[:5]
-        store[f"case{k}_meta"] = np.array([classes, frames, width, int(with_lm), seed])
+        store[f"case{k}_meta"] = np.array([classes, frames, width, lm_mode, seed])
+        store[f"case{k}_mode"] = np.array(LM_MODE_NAMES[lm_mode])
         store[f"case{k}_text"] = np.array([b[0] for b in beams])
         store[f"case{k}_logit_score"] = np.array([b[-2] for b in beams], dtype=np.float64)
         store[f"case{k}_lm_score"] = np.array([b[-1] for b in beams], dtype=np.float64)

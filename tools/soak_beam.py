@@ -56,10 +56,6 @@ def run_case(seed, vocabs, decs, repeats, dev, stats):
     labels, arpa, words = vocabs[name]
     use_lm = bool(r.randint(2))
     alpha, beta = float(r.choice([0.3, 0.5, 1.2])), float(r.choice([0.0, 1.5, 2.5]))
-    key = (name, use_lm, alpha, beta)
-    if key not in decs:
-        decs[key] = BeamSearchDecoder(labels, lm_path=arpa if use_lm else None, alpha=alpha, beta=beta)
-    dec = decs[key]
     frames = int(r.choice([20, 77, 140, 331, 501, 1200]))
     width = int(r.choice([8, 20, 50, 100, 128]))
     kind = int(r.randint(3))
@@ -68,6 +64,20 @@ def run_case(seed, vocabs, decs, repeats, dev, stats):
     rows = 16
     lp = torch.from_numpy(posteriors(kind, rows, frames, labels, words, seed, r)).to(dev)
     ragged = torch.from_numpy(r.randint(1, frames + 1, size=rows).astype(np.int32)) if r.randint(2) else None
+    # with an LM: BOTH of pyctcdecode's behaviours (viet_asr_amd/beam.py) -- no unigram list ("binary"), unigram set + trie ("arpa")
+    for mode in (("binary", "arpa") if use_lm else ("none",)):
+        m = _run_mode(seed, name, mode, alpha, beta, labels, arpa, decs, lp, width, ragged, repeats, stats, frames, kind)
+        if m:
+            return m
+    return None
+
+
+def _run_mode(seed, name, mode, alpha, beta, labels, arpa, decs, lp, width, ragged, repeats, stats, frames, kind):
+    key = (name, mode, alpha, beta)
+    if key not in decs:
+        decs[key] = BeamSearchDecoder(labels, lm_path=arpa if mode != "none" else None, alpha=alpha, beta=beta,
+                                      unigrams=None if mode == "binary" else "auto")
+    dec = decs[key]
     ref = [t.cpu() for t in dec.decode_ids(lp, width, frames=ragged)]            # 16 rows: beam_wave.hip
     stats["searches"] += 1
     stats["overflow_rows"] += int((ref[1] < 0).sum())
@@ -82,7 +92,7 @@ def run_case(seed, vocabs, decs, repeats, dev, stats):
                 k = int(n[j])
                 if (k != int(ref[1][lo + j]) or not torch.equal(ids[j, :k], ref[0][lo + j, :k])
                         or float(score[j]).hex() != float(ref[2][lo + j]).hex()):
-                    return {"case": seed, "vocab": name, "lm": use_lm, "frames": frames, "width": width, "kind": kind,
+                    return {"case": seed, "vocab": name, "lm": mode, "frames": frames, "width": width, "kind": kind,
                             "batch_rows": [lo, hi], "row": lo + j, "repeat": rep, "ragged": ragged is not None,
                             "lengths": [k, int(ref[1][lo + j])], "scores": [float(score[j]), float(ref[2][lo + j])]}
     return None

@@ -68,7 +68,7 @@ SIGNATURES = {
                                        _P, _P, _P, _P, C.c_size_t, _P]),
     "vasr_beam_search_rows_f32": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                             _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "vasr_lm_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+    "vasr_lm_create": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_float, C.c_float, C.POINTER(_P)]),
     "vasr_lm_destroy": (None, [_P]),
     "vasr_beam_workgroups": (C.c_int, [C.c_int]),
@@ -101,7 +101,7 @@ DEV_SIGNATURES = {
     "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
-ABI_VERSION = 5          # VASR_ABI_VERSION of the include/vasr.h these signatures were written against
+ABI_VERSION = 6          # VASR_ABI_VERSION of the include/vasr.h these signatures were written against
 
 _lib = None
 _dev = None

@@ -71,7 +71,11 @@ _tables = {}
 
 
 def resample(signal, length, sr_in, sr_out, filter="kaiser_best"):
-    """signal [B, L] float32 cuda (zero padded), length [B] int64 cuda -> (signal' [B, L'], length')."""
+    """signal [B, L] float32 cuda (zero padded), length [B] int64 cuda -> (signal' [B, L'], length').
+
+    Lengths follow ``librosa.load(sr=...)`` -> ``librosa.resample(fix=True)`` (infer.py:200): resampy computes
+    ``int(n * ratio)`` samples, librosa pads them with zeros to ``ceil(n * ratio)`` (both in float64: 5 000 samples at
+    11 025 -> 16 000 Hz come out as 7 257, the last one zero)."""
     if sr_in == sr_out:
         return signal, length
     if signal.device.type != "cuda":
@@ -86,7 +90,7 @@ def resample(signal, length, sr_in, sr_out, filter="kaiser_best"):
     x = signal.to(torch.float32).contiguous()
     ln = length.to(torch.int64).contiguous()
     B, L = x.shape
-    L_out = int(L * ratio)
+    L_out = int(np.ceil(L * ratio))
     y = torch.empty((B, max(L_out, 1)), dtype=torch.float32, device=x.device)
     ln_out = torch.empty((B,), dtype=torch.int64, device=x.device)
     _lib.check(_lib.lib().vasr_resample_f32(x.data_ptr(), L, ln.data_ptr(), B, tab.data_ptr(), tab.shape[0], num_table,

@@ -4,6 +4,13 @@ Counterpart of what ``BeamSearchDecoderWithLM.__init__`` builds with ``pyctcdeco
 kenlm_model_path, alpha, beta)`` (nemo/collections/asr/beam_search_decoder.py:82-87).  The language model is
 read from ARPA text; KenLM's binary formats (``*.binary``; the reference's own files are missing anyway,
 .MISSING_LARGE_BLOBS:4-7) are a third-party on-disk layout and are refused with a clear error.
+
+pyctcdecode treats the two kinds of file differently, by the path's SUFFIX (``build_ctcdecoder``): for ``*.arpa`` it reads
+the file's unigrams, keeps a unigram set and a character trie of it -- a partial word that is a prefix of a known word
+carries no out-of-vocabulary penalty, a committed word outside the set gets the unk offset; for anything else there is no
+set and every partial word is penalised.  ``unigrams="auto"`` (the default here) does exactly that: ".arpa" => the set
+``load_unigram_set_from_arpa`` would read, other suffixes => None.  ``unigrams=None`` asks for the no-unigram behaviour on
+any file -- what the reference got from the ``.binary`` its ARPA text was compiled to.
 """
 import ctypes as C
 
@@ -42,6 +49,56 @@ def read_arpa(path):
             words = tuple(parts[1:1 + cur])
             ngrams[words] = (float(parts[0]), float(parts[1 + cur]) if len(parts) > 1 + cur else 0.0)
     return order, ngrams
+
+
+def load_unigram_set_from_arpa(path):
+    """The unigram list pyctcdecode's ``build_ctcdecoder`` reads from an ``.arpa`` path (its
+    ``language_model.load_unigram_set_from_arpa``): the words of the ``\\1-grams:`` section whose line has exactly three
+    TAB-separated fields -- probability, word, back-off.  A 1-gram printed without a back-off weight (KenLM prints ``</s>``
+    so, and every word of a unigram-only model) is NOT in the list."""
+    unigrams = set()
+    with open(path, encoding="utf-8") as f:
+        inside = False
+        for line in f:
+            line = line.strip()
+            if line == "\\1-grams:":
+                inside = True
+            elif line == "\\2-grams:":
+                break
+            if inside and line:
+                parts = line.split("\t")
+                if len(parts) == 3:
+                    unigrams.add(parts[1])
+    if not unigrams:
+        raise ValueError(f"{path}: no unigrams found in the ARPA file (pyctcdecode raises here as well)")
+    return unigrams
+
+
+def _trie_buckets(keys):
+    """The character trie's node keys as the bucketed set vasr_lm_create() takes (include/vasr.h): 2^lg buckets of two u64
+    cells, a key sits in its home bucket ``_home(key, buckets)`` or the next one with a free cell; <= 25 % of the cells used
+    (a full bucket -- the only thing that sends a lookup past its first 16-byte load -- is then ~9 % of them)."""
+    keys = np.unique(np.asarray(keys, dtype=np.uint64) | np.uint64(1))
+    nb = 16
+    while 2 * nb < 4 * len(keys):
+        nb *= 2
+    cells = np.zeros((nb, 2), dtype=np.uint64)
+    fill = np.zeros(nb, dtype=np.int64)
+    pos = _home(keys, nb) if len(keys) else np.zeros(0, dtype=np.int64)
+    todo = np.arange(len(keys))
+    while len(todo):                                          # rounds: per bucket the first (free cells) claimants win
+        p = pos[todo]
+        order = np.argsort(p, kind="stable")
+        ps, ts = p[order], todo[order]
+        first = np.r_[True, ps[1:] != ps[:-1]]
+        start = np.maximum.accumulate(np.where(first, np.arange(len(ps)), 0))
+        rank = np.arange(len(ps)) - start                     # position among this round's claimants of the same bucket
+        ok = rank < (2 - fill[ps])
+        cells[ps[ok], fill[ps[ok]] + rank[ok]] = keys[ts[ok]]
+        np.add.at(fill, ps[ok], 1)
+        todo = ts[~ok]
+        pos[todo] = (pos[todo] + 1) & (nb - 1)
+    return cells
 
 
 def _hstep_np(h, v):
@@ -98,8 +155,14 @@ _ENTRY = np.dtype([("key", "<u8"), ("a", "<u4"), ("b", "<u4")])      # 16-byte t
 class DeviceLM:
     """Uploads an ARPA model as the two hash tables vasr_lm_create() expects."""
 
-    def __init__(self, path, labels, alpha, beta, unk_offset=-10.0):
+    def __init__(self, path, labels, alpha, beta, unk_offset=-10.0, unigrams="auto"):
+        """unigrams: "auto" = what build_ctcdecoder does for this path (the ARPA's own list for a "*.arpa" suffix, else none),
+        None = no unigram list, or an iterable of words (build_ctcdecoder's ``unigrams=`` argument)."""
         order, ngrams = read_arpa(path)
+        if isinstance(unigrams, str):
+            if unigrams != "auto":
+                raise ValueError("unigrams: 'auto', None or an iterable of words")
+            unigrams = load_unigram_set_from_arpa(path) if str(path).endswith(".arpa") else None
         if order > 5:
             raise NotImplementedError("n-gram order > 5")
         L = _lib.lib()
@@ -111,8 +174,13 @@ class DeviceLM:
             if special not in words:
                 words.append(special)
         wid = {w: i for i, w in enumerate(words)}
+        # pyctcdecode LanguageModel.__init__: the unigrams the model knows ("t in kenlm_model": in its vocabulary, not <unk>)
+        model_words = {ng[0] for ng in ngrams if len(ng) == 1} - {"<unk>"}
+        self.unigram_set = None if unigrams is None else {t for t in set(unigrams) if t in model_words}
+        if self.unigram_set is not None and not self.unigram_set:
+            self.unigram_set = None          # an empty set behaves exactly like none (score: len(set) > 0; trie: no node)
         # word string -> hash over its label ids; words with characters outside the labels can never be emitted
-        vkeys, vvals = [], []
+        vkeys, vvals, vflags = [], [], []
         for w in words:
             if w in ("<s>", "</s>", "<unk>") or any(ch not in lab for ch in w):
                 continue
@@ -121,11 +189,27 @@ class DeviceLM:
                 h = _hstep(h, lab[ch])
             vkeys.append(h)
             vvals.append(wid[w])
+            vflags.append(1 if self.unigram_set is not None and w in self.unigram_set else 0)
         vcap = _cap(len(vkeys))
         vslots, vwhere = _table(vkeys, vcap)
         vocab = np.zeros(vcap, dtype=_ENTRY)
         vocab["key"] = vslots
         vocab["a"][vwhere] = np.asarray(vvals, dtype=np.int32).view(np.uint32)
+        vocab["b"][vwhere] = np.asarray(vflags, dtype=np.uint32)
+        # the character trie's nodes: every non-empty prefix of every set member, as far as the labels spell it (has_node of a
+        # partial word the search can form)
+        trie = None
+        if self.unigram_set is not None:
+            tkeys = set()
+            for w in self.unigram_set:
+                h = h0
+                for ch in w:
+                    if ch not in lab:
+                        break
+                    h = _hstep(h, lab[ch])
+                    tkeys.add(h)
+            trie = _trie_buckets(sorted(tkeys))
+            self.n_trie_nodes = len(tkeys)
         # n-gram keys: the word ids folded from the LAST word backwards (the keys of every suffix of a history then come
         # out of one chain on the device), one vectorised pass per order
         by_n = {}
@@ -152,8 +236,10 @@ class DeviceLM:
         self.order, self.n_words, self.n_ngrams = order, len(words), len(ngrams)
         self.table_load = len(nkeys) / ncap
         self._h = C.c_void_p()
-        _lib.check(L.vasr_lm_create(vocab.ctypes.data, vcap, ngram.ctypes.data, ncap, order, wid["<s>"], wid["</s>"],
-                                    wid["<unk>"], float(alpha), float(beta), float(unk_offset), C.byref(self._h)))
+        _lib.check(L.vasr_lm_create(vocab.ctypes.data, vcap, ngram.ctypes.data, ncap,
+                                    trie.ctypes.data if trie is not None else None, len(trie) if trie is not None else 0,
+                                    order, wid["<s>"], wid["</s>"], wid["<unk>"], float(alpha), float(beta),
+                                    float(unk_offset), C.byref(self._h)))
 
     @property
     def handle(self):
@@ -187,7 +273,7 @@ LM_HELP = ("this library reads n-gram models as ARPA text only.  The reference's
 
 class BeamSearchDecoder:
     def __init__(self, labels, lm_path=None, alpha=0.5, beta=1.5, token_min_logp=-5.0, beam_prune_logp=-10.0,
-                 allow_missing_lm=False):
+                 allow_missing_lm=False, unigrams="auto"):
         self.labels = list(labels)
         if len(self.labels) + 1 > 128:
             raise NotImplementedError("beam search supports at most 127 labels + blank")
@@ -205,12 +291,14 @@ class BeamSearchDecoder:
                 warnings.warn(f"language model {lm_path!r} not usable ({why}); beam search runs without a language model")
                 lm_path = None
         self.lm_path, self.alpha, self.beta = lm_path, alpha, beta
+        # "auto": pyctcdecode's rule for the path's suffix (module docstring); None: no unigram list; or a list of words
+        self.unigrams = unigrams
         self._lm = None
         self._ws = None
 
     def _get_lm(self):
         if self.lm_path and self._lm is None:
-            self._lm = DeviceLM(self.lm_path, self.labels, self.alpha, self.beta)
+            self._lm = DeviceLM(self.lm_path, self.labels, self.alpha, self.beta, unigrams=self.unigrams)
         return self._lm
 
     def decode_ids(self, log_probs, beam_width, frames=None):

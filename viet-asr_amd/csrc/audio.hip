@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
   const int b = blockIdx.y;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n_orig = len_in[b];
-  const int64_t n_out = (int64_t)((double)n_orig * ratio);   // resampy: int(n_orig * ratio)
-  if (t == 0) len_out[b] = n_out;
+  const int64_t n_out = (int64_t)((double)n_orig * ratio);   // resampy: int(n_orig * ratio) samples are COMPUTED ...
+  if (t == 0) len_out[b] = (int64_t)ceil((double)n_orig * ratio);   // ... librosa.resample(fix=True) pads them to ceil(n_orig * ratio)
   if (t >= ld_out) return;
   float* yo = y + (int64_t)b * ld_out;
   if (t >= n_out) { yo[t] = 0.f; return; }
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void resample_phase_kernel(const float* __rest
   const int b = blockIdx.y, tid = threadIdx.x;
   const int64_t t0 = (int64_t)blockIdx.x * kPhaseTile;
   const int64_t n_orig = len_in[b];
-  const int64_t n_out = (int64_t)((double)n_orig * ratio);   // resampy: int(n_orig * ratio)
-  if (blockIdx.x == 0 && tid == 0) len_out[b] = n_out;
+  const int64_t n_out = (int64_t)((double)n_orig * ratio);   // resampy: int(n_orig * ratio) samples are COMPUTED ...
+  if (blockIdx.x == 0 && tid == 0) len_out[b] = (int64_t)ceil((double)n_orig * ratio);   // ... librosa pads to ceil(n_orig * ratio)
   const float* xi = x + (int64_t)b * ld_in;
   const double scale = ratio < 1.0 ? ratio : 1.0;
   const int index_step = (int)(scale * num_table);

@@ -33,31 +33,72 @@ __device__ inline double unord64(long long o) {
 // lm_home(key, lg) = ((u32)(key ^ key >> 32) * 0x9E3779B1) >> (32 - lg)  (the keys are FNV-style products of small word ids:
 // their entropy sits in bits 0-24 and 40+, any plain bit field of them clusters -- a first version that used bits 17.. sent
 // 20 000 unigrams to 256 home slots and probe chains ran to thousands of entries):
-//   vocabulary  {u64 key = hash of the word's label ids | 1, i32 word id, i32 0}
+//   vocabulary  {u64 key = hash of the word's label ids | 1, i32 word id, u32 flags: bit 0 = member of pyctcdecode's unigram set}
 //   n-grams     {u64 key | 1, f32 log10 p, f32 log10 back-off}; the key of (w_1 .. w_n) is folded from the LAST word
 //               backwards, key = hmix(... hmix(hmix(offset, w_n), w_{n-1}) ..., w_1): the keys of all suffixes of a history
 //               come out of one chain, and a back-off walk needs every one of them.
+// and, when the decoder was built with a unigram list (pyctcdecode's behaviour for an ".arpa" path: LanguageModel's
+// unigram_set + CharTrie), the NODES of the character trie as a set of 64-bit keys:
+//   trie        2^tlg buckets of TWO u64 keys (16 bytes, one load): key = hash of a word PREFIX's label ids | 1 -- the rolling
+//               hash every beam already carries for its pending word -- for every non-empty prefix of every word of the
+//               unigram set; home bucket lm_home(key, tlg), linear probing over buckets, a bucket with a free cell ends the walk.
 struct LmView {
   const uint4* vocab; int vcap, vlg;      // capacity 2^vlg
   const uint4* ngram; int ncap, nlg;
+  const ulonglong2* trie; int tlg;        // trie == nullptr: no unigram list (every partial word is "OOV")
   int order, bos, eos, unk;
   float alpha, beta, unk_offset;
 };
+
+inline LmView make_lm_view(const BeamLm* lm) {
+  LmView v{};
+  if (!lm) return v;
+  v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
+  v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
+  v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
+  v.trie = static_cast<const ulonglong2*>(lm->trie);
+  v.tlg = lm->trie ? 31 - __builtin_clz((unsigned)lm->tbuckets) : 0;
+  v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
+  return v;
+}
 
 __device__ inline unsigned long long entry_key(const uint4& e) { return ((unsigned long long)e.y << 32) | e.x; }
 __host__ __device__ inline int lm_home(unsigned long long k, int lg) {
   return (int)((((unsigned)k ^ (unsigned)(k >> 32)) * 0x9E3779B1u) >> (32 - lg));
 }
 
-__device__ __forceinline__ int lm_word_id(const LmView& lm, unsigned long long whash) {
+// word id of a committed word (-1: not in the n-gram model's vocabulary); *in_set: member of the unigram set (entry flags bit 0)
+__device__ __forceinline__ int lm_word_id(const LmView& lm, unsigned long long whash, bool* in_set) {
   const unsigned long long k = whash | 1ull;
+  *in_set = false;
   for (int i = lm_home(k, lm.vlg), n = 0; n < lm.vcap; ++n, i = (i + 1) & (lm.vcap - 1)) {
     const uint4 e = lm.vocab[i];
     const unsigned long long ek = entry_key(e);
-    if (ek == k) return (int)e.z;
+    if (ek == k) { *in_set = (e.w & 1u) != 0u; return (int)e.z; }
     if (ek == 0) break;
   }
   return -1;  // out of vocabulary
+}
+
+// pygtrie CharTrie.has_node(partial word) on the key set: `first` is the home bucket, requested by the caller long before
+// the answer is needed (the expand step issues it, the score step -- a table phase and, in the four-wavefront kernel, a
+// barrier later -- consumes it); only a FULL bucket that holds neither the key nor a free cell sends the lane on (the next
+// bucket is 16 bytes further: as a rule the same cache line).
+__device__ __forceinline__ ulonglong2 trie_first(const LmView& lm, unsigned long long whash) {
+  return lm.trie[lm_home(whash | 1ull, lm.tlg)];
+}
+__device__ __forceinline__ bool trie_has_node(const LmView& lm, unsigned long long whash, ulonglong2 first) {
+  const unsigned long long k = whash | 1ull;
+  const int nb = 1 << lm.tlg;
+  int i = lm_home(k, lm.tlg);
+  ulonglong2 e = first;
+  for (int n = 0; n < nb; ++n) {
+    if (e.x == k || e.y == k) return true;
+    if (e.x == 0ull || e.y == 0ull) return false;
+    i = (i + 1) & (nb - 1);
+    e = lm.trie[i];
+  }
+  return false;
 }
 
 // the rest of a probe chain whose first entry `e` was neither the key nor empty (rare at <= 50 % load)
@@ -121,13 +162,16 @@ __device__ __forceinline__ float lm_base_score(const LmView& lm, const int* ctx,
   return score;
 }
 
-// pyctcdecode LanguageModel.score (alpha * log10 * ln10 + beta, OOV offset, optional </s>)
+// pyctcdecode LanguageModel.score (alpha * log10 * ln10 + beta, unk offset, optional </s>).  The unk offset: "word not in
+// kenlm_model", and -- with a (non-empty) unigram set -- also "word not in unigram_set" (a word of the model whose 1-gram line
+// carries no back-off weight is outside the set pyctcdecode reads from the ARPA file: oracle/beam_oracle.py header)
 __device__ __forceinline__ float lm_word_score(const LmView& lm, const int* ctx, unsigned long long whash, bool eos, int* wid_out) {
-  int wid = lm_word_id(lm, whash);
+  bool in_set;
+  int wid = lm_word_id(lm, whash, &in_set);
   const bool oov = wid < 0;
   if (oov) wid = lm.unk;
   float s = lm_base_score(lm, ctx, wid);
-  if (oov) s += lm.unk_offset;
+  if (oov || (lm.trie != nullptr && !in_set)) s += lm.unk_offset;
   if (eos) {
     int c2[kMaxCtx];
     for (int i = 0; i < kMaxCtx - 1; ++i) c2[i] = ctx[i + 1];
@@ -138,9 +182,11 @@ __device__ __forceinline__ float lm_word_score(const LmView& lm, const int* ctx,
   return lm.alpha * s * 2.302585092994046f + lm.beta;
 }
 
-__device__ inline float partial_penalty(float unk_offset, int wlen) {
-  if (wlen <= 0) return 0.f;
-  float u = unk_offset;                    // no character trie: every partial word is OOV (is_oov = 1.0)
+// pyctcdecode LanguageModel.score_partial_token: unk_offset * is_oov, stretched by len / 6 beyond six characters.  is_oov: 1.0
+// without a character trie, else "the partial word is not a node of it" (the beams carry that as a meta bit)
+__device__ inline float partial_penalty(float unk_offset, int wlen, bool is_oov) {
+  if (wlen <= 0 || !is_oov) return 0.f;
+  float u = unk_offset;
   if (wlen > 6) u = u * (float)wlen / 6.0f;
   return u;
 }

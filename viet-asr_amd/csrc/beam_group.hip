@@ -115,7 +115,8 @@ static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3
 static_assert(sizeof(GroupLds<4>) <= 160 * 1024, "one workgroup per compute unit");
 static_assert(kFill <= 3 * 256 && kFill <= kTab * 7 / 20, "pairs per pass: three per lane at most, table at most 35 % full");
 
-constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25;
+constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25, kMetaOov = 1u << 26;   // (beam_wave.hip WaveLds::meta)
+constexpr int kSrcOov = 1 << 16;          // a pair record (beam << 8 | class) carries its child's "OOV" bit here
 __device__ inline int meta_last(unsigned m) { return (int)(m & 0xffu) - 1; }
 __device__ inline int meta_wlen(unsigned m) { return (int)((m >> 8) & 0xffffu); }
 __device__ inline unsigned make_meta(int last, int wlen, unsigned flags) {
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = (int)blockIdx.x;
   const int V = V1 - 1;
+  const bool trie = use_lm && lm.trie != nullptr;             // pyctcdecode's unigram set + character trie (".arpa" semantics)
   const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
   const float* lrow = logp + (int64_t)b * frames_ld * V1;
   unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   // One new beam at rank r from pair (parent bi, character c) with merged logit bits lgt
   auto build_child = [&](int t, int r, int src, long long lgt, bool has_space) __attribute__((always_inline)) {
     const int nxt = cur ^ 1;
-    const int bi = src >> 8, c = src & 255;
+    const int bi = (src >> 8) & 255, c = src & 255;
     const unsigned m = S.meta[cur][bi];
     const int last = meta_last(m), wlen = meta_wlen(m);
     const bool stay = (c == V || c == last);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     const int p_wid = S.commit_wid[cur][bi];
     int wlen_new = wlen;
     unsigned int appended = 0;
-    unsigned flags = 0;
+    unsigned flags = (src & kSrcOov) ? kMetaOov : 0u;       // (the score step decided it: same pending word, same bit)
     if (stay) {
       if ((m & kMetaCached) || (has_space && wlen > 0)) flags |= kMetaCached;
       flags |= m & kMetaCommit;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
 
     // table key of pair (beam bi, character c) = src -- (prefix text, last character), as the expand step forms it
     auto pair_key = [&](int sr) __attribute__((always_inline)) -> unsigned long long {
-      const int bi = sr >> 8, c = sr & 255;
+      const int bi = (sr >> 8) & 255, c = sr & 255;
       const unsigned m = S.meta[cur][bi];
       const bool grows = !(c == V || c == meta_last(m)) && !(c == space_id && meta_wlen(m) == 0);
       const unsigned long long key = S.key[cur][bi];
@@ -390,6 +392,10 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       unsigned claimed = 0, act = 0;
       unsigned long long kk[PPL];
       int stride[PPL];
+      // character trie (LM built with a unigram list): the home bucket of the child's pending word is requested here, the
+      // score step -- behind the claims and barrier B1 -- reads the answer
+      ulonglong2 tfirst[PPL];
+      unsigned long long wnew[PPL];
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int p = 64 * (W * j + wv) + lane;
@@ -410,6 +416,10 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         kk[j] = k;
         slot[j] = (int)((k >> 17) & (kTab - 1));
         stride[j] = (int)((k >> 40) & (kTab - 1)) | 1;
+        if (trie) {                                                                     // (uniform)
+          wnew[j] = hmix(S.whash[cur][bi], (unsigned long long)c);
+          tfirst[j] = trie_first(lm, wnew[j]);
+        }
       }
       // the table is at most a sixth full: a home slot is usually empty, so the first probe IS the compare-and-swap (one LDS
       // round trip instead of read + swap); its answer says empty (claimed), our key (a merge) or a foreign key (walk on)
@@ -470,7 +480,14 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           const float commit = S.commit_lmd[cur][bi];
           // partial_penalty(unk_offset, wlen_new), its division only when some lane's pending word is longer than six
           // characters (as a select the compiler runs the ~12-instruction division in every frame)
-          float pen = wlen_new > 0 ? lm.unk_offset : 0.f;
+          // is_oov of the child's pending word: the parent's when the word stays; once outside the trie, outside for good
+          bool oov = true;
+          if (trie) {
+            if (stay) oov = (m & kMetaOov) != 0u;
+            else if (c != space_id && !(wlen > 0 && (m & kMetaOov))) oov = !trie_has_node(lm, wnew[j], tfirst[j]);
+          }
+          if (oov) src[j] |= kSrcOov;
+          float pen = (wlen_new > 0 && oov) ? lm.unk_offset : 0.f;
           if (__ballot(wlen_new > 6) != 0ull) pen = wlen_new > 6 ? pen * (float)wlen_new / 6.0f : pen;
           lmt = S.lm_text[cur][bi] + pen + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
         }
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       }
       fin[i] = total;
       fkey[i] = wlen > 0 ? hmix(S.key[cur][i], (unsigned long long)space_id) : S.key[cur][i];
-      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen)) : 0.0);
+      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen, (m & kMetaOov) != 0u)) : 0.0);
     }
   }
   wave_sync();
@@ -940,15 +957,8 @@ int launch_beam_search_group(const float* logp, int batch, int frames, int V1, i
   if (W == 1) return launch_beam_search_wave(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, lm,
                                              bp, out_ids, out_len, out_score, st, row_frames);
   unsigned long long* eoslog = reinterpret_cast<unsigned long long*>(bp + (size_t)batch * frames * kMaxBeams);
-  LmView v{};
-  int use_lm = 0;
-  if (lm) {
-    use_lm = 1;
-    v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
-    v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
-    v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
-    v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
-  }
+  const LmView v = make_lm_view(lm);
+  const int use_lm = lm ? 1 : 0;
   return launch_group<4>(logp, batch, frames, V1, space_id, beam_width, token_min_logp, beam_prune_logp, v, use_lm, bp, eoslog,
                          out_ids, out_len, out_score, st, row_frames);
 }

@@ -57,7 +57,8 @@ struct WaveLds {
   unsigned long long whash[2][kMaxBeams];  // rolling hash of the pending word (label ids)
   double logit[2][kMaxBeams];
   float lm_text[2][kMaxBeams];             // LM score of the committed words
-  // (last + 1) [7:0] (0 = none, blank = V + 1) | wlen [23:8] | cached [24] | commit_valid [25]
+  // (last + 1) [7:0] (0 = none, blank = V + 1) | wlen [23:8] | cached [24] | commit_valid [25] | pending word is "OOV" [26]
+  // (is_oov of pyctcdecode's score_partial_token: always with no unigram list, else "not a node of the character trie")
   unsigned int meta[2][kMaxBeams];
   int ctx[2][kMaxBeams][kMaxCtx];          // LM history, most recent last, -1 = empty
   float commit_lmd[2][kMaxBeams];          // LM score the pending word gets when ' ' commits it (valid: meta bit 25)
@@ -83,7 +84,8 @@ static_assert(sizeof(WaveLds) == 38528, "a new field changes the LDS per utteran
 static_assert(2 * kTbRows * kMaxBeams * 4 <= (int)(sizeof(unsigned long long) * kTab * 3), "trace-back batches alias tkey + tmx + tsum");
 static_assert(kChars * 2 <= (int)(sizeof(unsigned long long) * 2 * kMaxBeams * 3), "transcript characters alias the beam keys / hashes / logits");
 
-constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25;
+constexpr unsigned kMetaCached = 1u << 24, kMetaCommit = 1u << 25, kMetaOov = 1u << 26;
+constexpr int kSrcOov = 1 << 16;          // a pair record (beam << 8 | class) carries its child's "OOV" bit here
 __device__ inline int meta_last(unsigned m) { return (int)(m & 0xffu) - 1; }
 __device__ inline int meta_wlen(unsigned m) { return (int)((m >> 8) & 0xffffu); }
 __device__ inline unsigned make_meta(int last, int wlen, unsigned flags) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   if (b >= batch) return;                                   // (no barrier anywhere below: a wavefront may leave)
   WaveLds& S = *reinterpret_cast<WaveLds*>(smem + (size_t)wv * sizeof(WaveLds));
   const int V = V1 - 1;
+  const bool trie = use_lm && lm.trie != nullptr;             // pyctcdecode's unigram set + character trie (".arpa" semantics)
   const int frames = row_frames ? max(0, min(frames_ld, row_frames[b])) : frames_ld;
   const float* lrow = logp + (int64_t)b * frames_ld * V1;
   unsigned int* bp = bp_all + (int64_t)b * frames_ld * kMaxBeams;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   // from the current buffer, the child goes to the other one, one back-pointer word per rank and frame.
   auto build_child = [&](int t, int r, int src, long long lgt, bool has_space, bool& any_char) __attribute__((always_inline)) {
     const int nxt = cur ^ 1;
-    const int bi = src >> 8, c = src & 255;
+    const int bi = (src >> 8) & 255, c = src & 255;
     const unsigned m = S.meta[cur][bi];
     const int last = meta_last(m), wlen = meta_wlen(m);
     const bool stay = (c == V || c == last);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     const int p_wid = S.commit_wid[cur][bi];
     int wlen_new = wlen;
     unsigned int appended = 0;
-    unsigned flags = 0;
+    unsigned flags = (src & kSrcOov) ? kMetaOov : 0u;       // (the score step decided it: same pending word, same bit)
     if (stay) {
       // same text and pending word as the parent: in the LM cache if the parent was, or if this frame put it there; the
       // commit score of the pending word is inherited with them
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
 
     // table key of pair (beam bi, character c) = src -- (prefix text, last character), as the expand step forms it
     auto pair_key = [&](int sr) __attribute__((always_inline)) -> unsigned long long {
-      const int bi = sr >> 8, c = sr & 255;
+      const int bi = (sr >> 8) & 255, c = sr & 255;
       const unsigned m = S.meta[cur][bi];
       const bool grows = !(c == V || c == meta_last(m)) && !(c == space_id && meta_wlen(m) == 0);
       const unsigned long long key = S.key[cur][bi];
@@ -346,6 +349,10 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       //      maximum -- took 1 500-2 500 cycles per 64 pairs, and a frame of 400 pairs ran six of those in a row ----
       unsigned long long kk[PPL];
       int stride[PPL];
+      // character trie (LM built with a unigram list): the home bucket of the child's pending word, requested HERE so that
+      // the table phases below hide the trip; the score step reads the answer
+      ulonglong2 tfirst[PPL];
+      unsigned long long wnew[PPL];
       // (branch-free: a lane whose pair index is past the end recomputes the last pair and merely takes no part in the
       // claims -- with a predicate around each pair's reads the PPL chains ran one after the other instead of together)
 #pragma unroll
@@ -371,6 +378,10 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         kk[j] = k;
         slot[j] = (int)((k >> 17) & (kTab - 1));
         stride[j] = (int)((k >> 40) & (kTab - 1)) | 1;
+        if (trie) {                                                                     // (uniform)
+          wnew[j] = hmix(S.whash[cur][bi], (unsigned long long)c);
+          tfirst[j] = trie_first(lm, wnew[j]);
+        }
       }
       unsigned long long seen[PPL];
 #pragma unroll
@@ -450,7 +461,14 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
           const bool stay = (c == V || c == last);
           const int wlen_new = stay ? wlen : (c == space_id ? 0 : wlen + 1);
           const float commit = S.commit_lmd[cur][bi];                                   // filled by step 2 when it is needed
-          lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new) + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
+          // is_oov of the child's pending word: the parent's when the word stays; once outside the trie, outside for good
+          bool oov = true;
+          if (trie) {
+            if (stay) oov = (m & kMetaOov) != 0u;
+            else if (c != space_id && !(wlen > 0 && (m & kMetaOov))) oov = !trie_has_node(lm, wnew[j], tfirst[j]);
+          }
+          if (oov) src[j] |= kSrcOov;
+          lmt = S.lm_text[cur][bi] + partial_penalty(lm.unk_offset, wlen_new, oov) + ((!stay && c == space_id && wlen > 0) ? commit : 0.f);
         }
         if (mine) S.tkey[i] = 0;
         // a prefix with a single contributor keeps that pair's score, exactly (exp(0) = 1: no logarithm)
@@ -728,7 +746,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       }
       fin[i] = total;
       fkey[i] = wlen > 0 ? hmix(S.key[cur][i], (unsigned long long)space_id) : S.key[cur][i];
-      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen)) : 0.0);
+      frank[i] = S.logit[cur][i] + (use_lm ? (double)(S.lm_text[cur][i] + partial_penalty(lm.unk_offset, wlen, (m & kMetaOov) != 0u)) : 0.0);
     }
   }
   wave_sync();
@@ -860,15 +878,8 @@ int launch_beam_search_wave(const float* logp, int batch, int frames, int V1, in
                             int32_t* out_ids, int32_t* out_len, float* out_score, hipStream_t st,
                             const int32_t* row_frames) {
   unsigned long long* eoslog = reinterpret_cast<unsigned long long*>(bp + (size_t)batch * frames * kMaxBeams);
-  LmView v{};
-  int use_lm = 0;
-  if (lm) {
-    use_lm = 1;
-    v.vocab = static_cast<const uint4*>(lm->vocab); v.vcap = lm->vcap; v.ngram = static_cast<const uint4*>(lm->ngram);
-    v.ncap = lm->ncap; v.order = lm->order; v.bos = lm->bos;
-    v.vlg = 31 - __builtin_clz((unsigned)lm->vcap); v.nlg = 31 - __builtin_clz((unsigned)lm->ncap);
-    v.eos = lm->eos; v.unk = lm->unk; v.alpha = lm->alpha; v.beta = lm->beta; v.unk_offset = lm->unk_offset;
-  }
+  const LmView v = make_lm_view(lm);
+  const int use_lm = lm ? 1 : 0;
   const int upw = beam_wave_utts_per_workgroup(batch);
   const size_t lds = sizeof(WaveLds) * (size_t)upw;
   static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)

@@ -1138,24 +1138,28 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   return check_launch("beam_search");
 }
 
-int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, int order, int bos_id, int eos_id,
-                   int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out) {
+int vasr_lm_create(const void* h_vocab, int vcap, const void* h_ngram, int ncap, const void* h_trie, int trie_buckets,
+                   int order, int bos_id, int eos_id, int unk_id, float alpha, float beta, float unk_offset, vasr_lm** out) {
   if (!h_vocab || !h_ngram || !out || vcap <= 0 || ncap <= 0) return fail(VASR_ERR_INVALID, "bad argument");
   if ((vcap & (vcap - 1)) || (ncap & (ncap - 1)) || vcap < 16 || ncap < 16)
     return fail(VASR_ERR_INVALID, "table capacities must be powers of two >= 16");
+  if (h_trie && ((trie_buckets & (trie_buckets - 1)) || trie_buckets < 16))
+    return fail(VASR_ERR_INVALID, "the trie's bucket count must be a power of two >= 16");
   if (order < 1 || order > 5) return fail(VASR_ERR_UNSUPPORTED, "n-gram order %d (supported: 1..5)", order);
   auto* lm = new vasr_lm();
-  void *p0 = nullptr, *p1 = nullptr;
+  void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
   hipError_t e = hipMalloc(&p0, (size_t)vcap * 16);
   if (e == hipSuccess) e = hipMalloc(&p1, (size_t)ncap * 16);
+  if (e == hipSuccess && h_trie) e = hipMalloc(&p2, (size_t)trie_buckets * 16);
   if (e == hipSuccess) e = hipMemcpy(p0, h_vocab, (size_t)vcap * 16, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p1, h_ngram, (size_t)ncap * 16, hipMemcpyHostToDevice);
-  lm->allocs = {p0, p1};
+  if (e == hipSuccess && h_trie) e = hipMemcpy(p2, h_trie, (size_t)trie_buckets * 16, hipMemcpyHostToDevice);
+  lm->allocs = {p0, p1, p2};
   if (e != hipSuccess) {
     vasr_lm_destroy(lm);
     return fail(VASR_ERR_HIP, "uploading the n-gram tables: %s", hipGetErrorString(e));
   }
-  lm->view = BeamLm{p0, vcap, p1, ncap, order, bos_id, eos_id, unk_id, alpha, beta, unk_offset};
+  lm->view = BeamLm{p0, vcap, p1, ncap, p2, h_trie ? trie_buckets : 0, order, bos_id, eos_id, unk_id, alpha, beta, unk_offset};
   *out = lm;
   return 0;
 }

@@ -245,8 +245,9 @@ void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int b
 
 // ---- beam search (beam_wave.hip, beam_group.hip) ----
 struct BeamLm {  // device-resident hashed back-off n-gram model
-  const void* vocab; int vcap;    // [vcap] 16-byte entries {u64 word hash | 1, i32 word id, i32 0}, vcap a power of two
+  const void* vocab; int vcap;    // [vcap] 16-byte entries {u64 word hash | 1, i32 word id, u32 flags}, vcap a power of two
   const void* ngram; int ncap;    // [ncap] 16-byte entries {u64 n-gram key | 1, f32 log10 p, f32 log10 back-off}
+  const void* trie; int tbuckets; // [tbuckets] 16-byte buckets of two u64 word-prefix keys; nullptr: no unigram list
   int order, bos, eos, unk;
   float alpha, beta, unk_offset;
 };

@@ -185,7 +185,8 @@ def synthetic_arpa(path, labels, n_words=20000, n_bigrams=50000, n_trigrams=5000
             f.write(f"\n\\{n}-grams:\n")
             for k in by_n[n]:
                 p, bo = ng[k]
-                f.write(f"{p:.6f}\t{' '.join(k)}" + (f"\t{bo:.6f}" if n < 3 else "") + "\n")
+                # (</s> without a back-off field, as KenLM prints it: in the model, not in the unigram list pyctcdecode reads)
+                f.write(f"{p:.6f}\t{' '.join(k)}" + (f"\t{bo:.6f}" if n < 3 and k != ("</s>",) else "") + "\n")
         f.write("\n\\end\\\n")
     return ng
 
