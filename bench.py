@@ -569,12 +569,8 @@ def main():
             r = np.random.RandomState(seed)
             dur = r.uniform(seconds / 2, seconds, JOB_CLIPS)
             bucket = 64
-            shards = vdist.balanced_shards(dur, world, bucket)
-            costs = [vdist.shard_cost(s, dur) for s in shards]
-            mine = sorted((b for b in shards[rank]), key=lambda b: -dur[b[0]])
             # passes of up to `batch` clips out of consecutive length buckets (similar lengths share a pass)
-            flat = [i for b in mine for i in b]
-            groups = [flat[i:i + batch] for i in range(0, len(flat), batch)]
+            groups, costs = vdist.job_passes(dur, rank, world, batch, bucket)
             for g in groups:
                 n_in = int(max(dur[i] for i in g) * rate)
                 sig, lens = synth.audio_batch(len(g), n_in, seed + 1000 * rank + len(passes), ragged=False)

@@ -209,8 +209,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4, 8])        # 8 = the node the path is built for (BASELINE configs[4])
 def test_gather_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -218,10 +218,80 @@ def test_gather_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=150) for _ in procs)
+    res = dict(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(30)
     assert res == {r: "ok" for r in range(world)}, res
+
+
+def _job_worker(rank, world, port, q, n_clips, batch):
+    """bench.py --config 5 --ragged on CPU with a stub engine: the job's sharding and gather logic exactly as the bench runs
+    it -- dist.job_passes (balanced_shards -> this rank's passes) -> one 'acoustic pass' per pass -> ONE
+    gather_id_sequences per step carrying the rows' manifest indices."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import viet_asr_amd  # noqa: F401
+    from viet_asr_amd import dist as vdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = np.random.RandomState(3)                              # every rank draws the same manifest
+        dur = np.concatenate([r.uniform(15.0, 30.0, n_clips - n_clips // 5), r.uniform(1.0, 4.0, n_clips // 5)])
+        passes, costs = vdist.job_passes(dur, rank, world, batch, bucket=16)
+        if n_clips >= 2000:                                       # (13 buckets cannot be dealt evenly to 8 ranks)
+            assert (max(costs) - min(costs)) / max(costs) < 0.1, costs
+
+        def stub_engine(idx):
+            """'Transcribes' clip i as the id sequence [i, i + 1, ...] of a length that depends on its duration; the pass's
+            width is its longest row (as the engine's [B, T'] is)."""
+            n = [2 + int(dur[i] * 3) % 11 for i in idx]
+            ids = torch.zeros((len(idx), max(n)), dtype=torch.int32)
+            for k, i in enumerate(idx):
+                ids[k, : n[k]] = torch.arange(i, i + n[k], dtype=torch.int32)
+            return ids, torch.tensor(n, dtype=torch.int32)
+
+        for step in range(2):                                     # two steps: nothing is left over from the first
+            parts = [stub_engine(idx) for idx in passes]
+            # a rank with NO pass still takes part in the collective with zero rows
+            width = max([p[0].shape[1] for p in parts] or [1])
+            ids = torch.cat([torch.nn.functional.pad(p[0], (0, width - p[0].shape[1])) for p in parts]
+                            or [torch.zeros((0, width), dtype=torch.int32)])
+            n = torch.cat([p[1] for p in parts] or [torch.zeros((0,), dtype=torch.int32)])
+            where = torch.tensor([i for idx in passes for i in idx], dtype=torch.int32)
+            g_ids, g_n, g_idx = vdist.gather_id_sequences(ids, n, extra=where)
+            # every manifest index exactly once; put back in manifest order every row is what the stub produced for it
+            assert sorted(g_idx.tolist()) == list(range(n_clips)), (rank, step)
+            order = torch.argsort(g_idx.long())
+            for i, row in zip(range(n_clips), order.tolist()):
+                k = 2 + int(dur[i] * 3) % 11
+                assert int(g_n[row]) == k and g_ids[row, :k].tolist() == list(range(i, i + k)), (rank, step, i)
+                assert not bool(g_ids[row, k:].any())
+        q.put((rank, ("ok", len(passes))))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, (repr(e), -1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n_clips,batch", [(8, 4096, 512), (8, 203, 16), (2, 37, 64), (4, 3, 2)])
+def test_ragged_job_sharding_and_gather_gloo(world, n_clips, batch):
+    """The 8-rank rehearsal of BASELINE configs[4]'s job form (no 8-GPU node has been available to any round): 4 096 ragged
+    clips over 8 ranks in passes of 512 -- and small shapes where ranks get unequal numbers of passes, a single short pass,
+    or none at all (3 clips on 4 ranks).  Mirrors actions.py:669-693 (sharding) and :774-807 (gather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q, n_clips, batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(v[0] == "ok" for v in res.values()), res
+    counts = [res[r][1] for r in range(world)]
+    if (world, n_clips) in ((8, 203), (4, 3)):
+        assert len(set(counts)) > 1, counts                        # the case the fixed-shape ring could not carry
 
 
 def test_duration_balanced_shards_of_a_ragged_4096_clip_manifest():

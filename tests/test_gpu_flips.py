@@ -14,7 +14,12 @@ fp32-equivalent arithmetics, and
     than the library's exact-fp32 mode; the near-tie stress test (CTC head scaled down) has many and checks the same bound;
   * {frames, flips, min_margin, err, the oracle's own flips against float64, ...} go to gpurun_out/parity_errors.jsonl per
     arithmetic (committed as profiles/rNN_parity_errors.jsonl);
-  * the collapsed transcripts (helpers.py:7-33) of all rows equal the oracle's.
+  * the collapsed transcripts (helpers.py:7-33) are compared on EVERY row in EVERY arithmetic (round 6; rounds 4-5 skipped
+    all 64 rows of an arithmetic as soon as it had one flipped frame): a row without a flipped frame must equal the oracle's
+    transcript exactly; a row with one must equal the oracle's transcript or the collapse of the FLOAT64 predictions of that
+    row; `transcripts_equal: n/B` and the flipped (row, frame) pairs go to the parity record;
+  * the flip counts at BASELINE's shapes are asserted `==` the recorded ones (the kernels are deterministic: fewer flips, or
+    a flip that moved, is a changed kernel and has to be looked at and re-recorded, exactly like more flips).
 """
 import numpy as np
 import pytest
@@ -67,7 +72,8 @@ def _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict):
     for v in res.values():
         any_flip |= v["flip"]
     rows = sorted(set(((margin < 4 * worst_err) | any_flip).nonzero()[:, 0].tolist()))
-    rec = {g: dict(flips=int(v["flip"].sum()), err=v["err"]) for g, v in res.items()}
+    rec = {g: dict(flips=int(v["flip"].sum()), err=v["err"], flipped_row_frame=v["flip"].nonzero().tolist()[:16]) for g, v in res.items()}
+    pred64 = {}                              # row -> float64 predictions of that row (rows examined below)
     summary = dict(tag=tag, frames=int(margin.numel()), min_margin=float(margin.min()), rows_examined_in_f64=len(rows))
     if rows:
         assert len(rows) <= 24, (tag, "too many near-tie rows for the float64 pass", len(rows))
@@ -75,6 +81,7 @@ def _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict):
         e64, _ = O.encoder_forward(ref["mel"][idx], ref["seq"][idx], enc_sd, jas, dtype=torch.float64)
         l64 = O.decoder_forward(e64, dec_sd)
         p64 = l64.argmax(-1)
+        pred64 = {row: p64[k] for k, row in enumerate(rows)}
         t2 = l64.topk(2, -1).values
         m64 = t2[..., 0] - t2[..., 1]
         e_ref = float((ref["logp"][idx].double() - l64).abs().max())
@@ -93,7 +100,7 @@ def _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict):
                 assert float(m64[f].max()) <= tie, (tag, g, float(m64[f].max()), tie)
     for g, v in rec.items():
         _record("flips", gemm=g, **summary, **v)
-    return rec
+    return rec, pred64
 
 
 def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0, measured=None):
@@ -107,26 +114,40 @@ def _whole_batch(gpu, tag, name, classes, seed, batch, ragged, head_gain=1.0, me
     ref = O.forward_all(sig, lens, enc_sd, dec_sd, jas)                     # the WHOLE padded batch on the host cores
     want_text = O.ctc_decode_strings(ref["pred"], cfg["labels"])
     wav, ln = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
-    res = {}
+    res, texts = {}, {}
     for gemm in ARITHMETICS:
         eng = QuartzNetCTC(cfg, enc_sd, dec_sd, gemm=gemm)
         r = eng.forward(wav, ln, want_logp=True)
         res[gemm] = _compare(tag, gemm, r, ref)
-        if not bool(res[gemm]["flip"].any()):
-            assert eng.texts(r["ids"], r["id_len"]) == want_text, (tag, gemm)
+        texts[gemm] = eng.texts(r["ids"], r["id_len"])
         del eng, r
         torch.cuda.empty_cache()
-    rec = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=head_gain == 1.0)
+    rec, pred64 = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=head_gain == 1.0)
+    # transcripts, ALWAYS and on every row: exact where no frame flipped; a row with a flipped frame must read as the float32
+    # oracle or as the float64 graph does (the flip itself was judged against float64 above)
+    for gemm in ARITHMETICS:
+        flip_rows = sorted(set(res[gemm]["flip"].nonzero()[:, 0].tolist()))
+        differ = [b for b in range(batch) if texts[gemm][b] != want_text[b]]
+        assert set(differ) <= set(flip_rows), (tag, gemm, "a row without a flipped frame has a different transcript", differ, flip_rows)
+        as_f64 = {}
+        for b in flip_rows:
+            t64 = O.ctc_decode_strings(pred64[b][None], cfg["labels"])[0]
+            as_f64[b] = texts[gemm][b] == t64
+            assert texts[gemm][b] in (want_text[b], t64), (tag, gemm, b, texts[gemm][b][:80], want_text[b][:80], t64[:80])
+        _record("transcripts", tag=tag, gemm=gemm, transcripts_equal=f"{batch - len(differ)}/{batch}", rows_not_equal=differ,
+                rows_with_a_flipped_frame=flip_rows, flipped_rows_equal_the_float64_transcript=as_f64)
     # the headline arithmetic against the strict-fp32 mode of the same library, every frame (no oracle involved)
     cross = int((res["f16x2"]["pred"] != res["fp32"]["pred"]).sum())
     _record("flips_f16x2_vs_fp32_mode", tag=tag, frames=int(res["fp32"]["pred"].numel()), flips=cross)
     if head_gain == 1.0:
         # BASELINE shapes: the split arithmetic must not be noisier than the exact-fp32 MFMA mode of the same library, and
-        # the counts are the MEASURED ones (rounds 4 and 5; the kernels are deterministic, so a different count is a changed
-        # kernel, to be looked at and re-recorded -- not noise): `measured` = flips of (f16x2, bf16x3, fp32)
+        # the counts are the MEASURED ones (the kernels are deterministic, so a different count -- more OR fewer -- is a
+        # changed kernel or a changed input, to be looked at and re-recorded, not noise): `measured` = flips of (f16x2,
+        # bf16x3, fp32).  Round 6 re-recorded them with librosa's order of roundings in the mel bank (the inputs moved by an
+        # ulp in 140 filter coefficients).
         assert rec["f16x2"]["flips"] <= rec["fp32"]["flips"], rec
         for g, n in zip(ARITHMETICS, measured):
-            assert rec[g]["flips"] <= n, (g, rec)
+            assert rec[g]["flips"] == n, (g, n, rec)
 
 
 def test_config3_every_frame_of_the_whole_batch(gpu):
@@ -216,7 +237,7 @@ def test_config5_every_eighth_row_every_frame(gpu):
     sub = {k: r[k][rg] for k in ("pred", "logp", "enc_len")}
     tag = "configs[4] shard 512x30s, rows 0::8"
     res = {"f16x2": _compare(tag, "f16x2", sub, ref)}
-    rec = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=True)
+    rec, _ = _judge_flips(tag, res, ref, enc_sd, dec_sd, jas, strict=True)
     assert rec["f16x2"]["flips"] == 0, rec      # measured (rounds 4, 5): none in 96 064 frames
     assert eng.texts(r["ids"][rg], r["id_len"][rg]) == O.ctc_decode_strings(ref["pred"], cfg["labels"])
     # ---- (c) RECORDED, not asserted: the same 64 rows end to end, wav -> prediction, against the oracle

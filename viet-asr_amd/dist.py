@@ -49,6 +49,20 @@ def shard_cost(shard, durations):
     return sum(len(b) * max(float(durations[i]) for i in b) for b in shard if b)
 
 
+def job_passes(durations, rank, world_size, batch, bucket=64):
+    """The passes ONE rank runs over its share of a ragged job (bench.py --config 5 --ragged; a manifest walked once):
+    length buckets of ``bucket`` clips dealt to the ranks by ``balanced_shards``, this rank's buckets taken longest first and
+    cut into passes of up to ``batch`` clips (similar lengths share a pass).  -> (passes: lists of manifest indices, padded
+    work of every rank).  Ranks end up with DIFFERENT numbers of passes of different shapes, which is why the job's results
+    go through ``gather_id_sequences`` (one shape-exchanging gather per step) and not through the fixed-shape ring."""
+    shards = balanced_shards(durations, world_size, bucket)
+    costs = [shard_cost(s, durations) for s in shards]
+    mine = sorted((b for b in shards[rank]), key=lambda b: -float(durations[b[0]]))
+    flat = [i for b in mine for i in b]
+    batch = max(1, int(batch))
+    return [flat[i:i + batch] for i in range(0, len(flat), batch)], costs
+
+
 def gather_id_sequences(ids, id_len, group=None, extra=None):
     """ids [B_loc, T] int32 (compacted rows), id_len [B_loc] int32 -> on every rank the concatenation over
     ranks in rank order as (ids [B_tot, T_max], id_len [B_tot]).  Shards may differ in B_loc and T.
