@@ -430,12 +430,15 @@ def model_traffic_bytes(jas, feat_in, classes, batch, T):
     return unf + w, fus + w
 
 
-def box_normalisers(dev):
+def box_normalisers(dev, gemm="f16x2"):
     """What THIS box sustains, measured right after the timed region (chip warm) so that rounds on different boxes can be
     compared (three of four rounds' headline deltas were inside the box-to-box spread):
-      * measured_mfma_tflops: the GEMM's instruction stream with everything but its MFMAs removed (8 wavefronts per CU, 48
-        16-bit MFMAs per k-step on 8 accumulators, operands of realistic bit patterns resident in registers;
-        csrc/encoder_pw_split.hip mfma_bf16_sustained_kernel through the devtools build), 4 launches of ~8 ms;
+      * measured_mfma_tflops: the instruction stream of the GEMM in the arithmetic the line is quoted in (`gemm`), with
+        everything but its MFMAs removed -- f16x2: three v_mfma_f32_32x32x16_f16 per tile pair and k-step on fp16 hi / lo
+        planes; bf16x3: six bf16 ones on three planes -- 8 wavefronts per CU, the kernel's 2 x 4 tile order, operands with the
+        bit statistics of scaled weights and rectified activations resident in registers (csrc/encoder_pw_split.hip
+        mfma_sustained_kernel through the devtools build), 4 launches of ~8 ms.  Round 6: like for like (rounds 4-5 divided
+        the f16x2 kernel by the bf16x3 stream); `measured_mfma_stream` names the stream;
       * measured_copy_gbs: read + write rate of a float4 streaming pass over 2 x 1 GiB (far beyond the 256 MiB Infinity
         Cache: HBM itself); measured_copy_gbs_cache_resident: the same over 2 x 67 MB -- the size of the headline workload's
         512-channel activations, which is what its depthwise layers are really bounded by.
@@ -448,7 +451,9 @@ def box_normalisers(dev):
         fl = ctypes.c_double()
         st = torch.cuda.current_stream().cuda_stream
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        run = lambda: _lib.check(D.vasr_bench_mfma_bf16_sustained(n_cu, 4000, sink.data_ptr(), ctypes.byref(fl), st), D)
+        mode = {"bf16x3": 1, "f16x2": 3}.get(gemm, 3)       # (fp32 mode: no 16-bit stream; the f16 one is reported, unused)
+        ksteps = 8000 if mode == 3 else 4000                # ~8 ms per launch either way (24 / 48 MFMAs per k-step)
+        run = lambda: _lib.check(D.vasr_bench_mfma_sustained(mode, n_cu, ksteps, sink.data_ptr(), ctypes.byref(fl), st), D)
         run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -457,22 +462,27 @@ def box_normalisers(dev):
         e1.record()
         torch.cuda.synchronize()
         out["measured_mfma_tflops"] = round(4 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+        out["measured_mfma_stream"] = {1: "bf16x3: 6 x v_mfma_f32_32x32x16_bf16 per tile pair and k-step",
+                                       3: "f16x2: 3 x v_mfma_f32_32x32x16_f16 per tile pair and k-step"}[mode]
     except Exception as e:  # noqa: BLE001 -- a normaliser must not take the bench line down
         out["measured_mfma_error"] = repr(e)[:200]
-    for key, n in (("measured_copy_gbs", 1 << 28), ("measured_copy_gbs_cache_resident", 64 * 512 * 512)):
-        x = torch.randn(n, device=dev)
-        y = torch.empty_like(x)
-        for _ in range(3):
-            torch.clamp_min(x, 0, out=y)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10 if n > (1 << 26) else 50
-        e0.record()
-        for _ in range(reps):
-            torch.clamp_min(x, 0, out=y)
-        e1.record()
-        torch.cuda.synchronize()
-        out[key] = round(reps * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-        del x, y
+    try:                    # (2 x 1 GiB after a 10 GB workspace -- an allocation failure here must not lose the line either)
+        for key, n in (("measured_copy_gbs", 1 << 28), ("measured_copy_gbs_cache_resident", 64 * 512 * 512)):
+            x = torch.randn(n, device=dev)
+            y = torch.empty_like(x)
+            for _ in range(3):
+                torch.clamp_min(x, 0, out=y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10 if n > (1 << 26) else 50
+            e0.record()
+            for _ in range(reps):
+                torch.clamp_min(x, 0, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            out[key] = round(reps * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del x, y
+    except Exception as e:  # noqa: BLE001
+        out["measured_copy_error"] = repr(e)[:200]
     torch.cuda.empty_cache()
     return out
 
@@ -842,7 +852,7 @@ def main():
             out.update(rccl)
         if other is not None:
             out["other_gemm_arithmetic"] = other
-        norm = box_normalisers(dev)
+        norm = box_normalisers(dev, gemm)
         if norm.get("measured_mfma_tflops") and gemm != "fp32":
             out["roofline"]["measured_sustained_peak"] = norm["measured_mfma_tflops"]
             out["roofline"]["frac_of_measured"] = round(cr["exec_tflops"] / norm["measured_mfma_tflops"], 4)

@@ -41,11 +41,13 @@ VASR_API int vasr_pack_pointwise(const float* h_w, int cout, int cin, int m_pad,
 VASR_API int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_scale, const float* d_shift,
                          int batch, int cin, int cout, int64_t frames, float* d_y, vasr_stream stream);
 
-/* Reference point for the GEMM roofline: launches `workgroups` x 8 wavefronts that do nothing but
- * v_mfma_f32_32x32x16_bf16 on register operands (the pointwise kernel's MFMA stream without loads, LDS or barriers),
- * `steps` x 48 per wavefront; *flops = bf16 flops issued.  Timed by the caller; what it sustains is the rate the chip
- * holds under its power limit, against which bench.py also quotes the GEMM (roofline.sustained_peak). */
-VASR_API int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
+/* Reference point for the GEMM roofline, like for like: launches `workgroups` x 8 wavefronts that issue nothing but the
+ * MFMA stream of the pointwise kernel in arithmetic `gemm_mode` (vasr_set_gemm_mode numbering: 3 = f16x2 -- three
+ * v_mfma_f32_32x32x16_f16 per tile pair and k-step on fp16 hi / lo planes, 24 per k-step; 1 = bf16x3 -- six
+ * v_mfma_f32_32x32x16_bf16 on three planes, 48 per k-step), same 2 x 4 tile order, operands in registers with the bit
+ * statistics of scaled weights and rectified activations; `steps` k-steps per wavefront; *flops = 16-bit flops issued.
+ * Timed by the caller; what it sustains is the rate the chip holds under its power limit (box.measured_mfma_tflops). */
+VASR_API int vasr_bench_mfma_sustained(int gemm_mode, int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream);
 
 /* 2 x fp16 scaled split variants (fragments: [m_pad/32][cin/16][2][64 lanes][8] fp16 bits; *inv_scale = 1 / the power
  * of two the weights were scaled by).  d_amax: [2][batch][amax_stride] u32 scratch (amax_stride >= 256 and >= cout *

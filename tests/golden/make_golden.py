@@ -185,6 +185,9 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, ba
     if band_hz:   # (only the round-5 cases carry these keys: the older fixtures regenerate bit-identically without them)
         out["band_hz"] = band_hz
         out["sig_abs_sum"] = np.float64(np.abs(sig.astype(np.float64)).sum())
+        # the band-limited input itself (np.sinc / np.kaiser / the convolution's summation order are not bit-
+        # reproducible across numpy / libm builds): a host that regenerates it differently replays the stored one
+        out["sig"], out["sig_lens"] = sig.astype(np.float32), np.asarray(lens, dtype=np.int64)
         out["margin"] = margin.numpy()          # per frame: the tests may excuse a frame only by ITS margin
         if real_decoder:
             # the shipped head answers blank on every frame of an untrained encoder (empty transcripts): the same encoder output

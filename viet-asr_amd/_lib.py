@@ -96,7 +96,7 @@ DEV_SIGNATURES = {
     "vasr_pack_pointwise": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_pack_pointwise_bf16x3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vasr_bench_pointwise_bf16x3": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
-    "vasr_bench_mfma_bf16_sustained": (C.c_int, [C.c_int, C.c_int, _P, C.POINTER(C.c_double), _P]),
+    "vasr_bench_mfma_sustained": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_double), _P]),
     "vasr_bench_depthwise": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }

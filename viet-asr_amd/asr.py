@@ -328,10 +328,9 @@ class AudioDataLayer(DataLayerNM):
         self.signal = self.signal_shape = None
 
     def set_signal(self, signal):
+        """The reference's single-utterance call (infer.py:29-33): a batch of one."""
         import numpy as np
-        self.signal = np.reshape(np.asarray(signal, dtype=np.float32), [1, -1])
-        self.signal_shape = np.expand_dims(self.signal.size, 0).astype(np.int64)
-        self.output = True
+        self.set_batch([np.asarray(signal, dtype=np.float32).reshape(-1)])
 
     def set_batch(self, signals):
         import numpy as np

@@ -294,7 +294,8 @@ class BeamSearchDecoder:
         # "auto": pyctcdecode's rule for the path's suffix (module docstring); None: no unigram list; or a list of words
         self.unigrams = unigrams
         self._lm = None
-        self._ws = None
+        self._ws = {}
+        self._ws_lock = __import__("threading").Lock()
 
     def _get_lm(self):
         if self.lm_path and self._lm is None:
@@ -314,8 +315,11 @@ class BeamSearchDecoder:
             raise ValueError(f"log_probs has {V1} classes, expected {len(self.labels)} labels + blank")
         L = _lib.lib()
         need = int(L.vasr_beam_workspace_bytes(B, T))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        with self._ws_lock:                         # one workspace per (device, stream): two threads on two streams do not share one
+            ws = self._ws.get((x.device, stream))
+            if ws is None or ws.numel() < need:
+                ws = self._ws[(x.device, stream)] = torch.empty(need, dtype=torch.uint8, device=x.device)
         ids = torch.empty((B, T), dtype=torch.int32, device=x.device)
         n = torch.empty((B,), dtype=torch.int32, device=x.device)
         score = torch.empty((B,), dtype=torch.float32, device=x.device)
@@ -328,8 +332,8 @@ class BeamSearchDecoder:
         _lib.check(L.vasr_beam_search_rows_f32(x.data_ptr(), rows.data_ptr() if rows is not None else None, B, T, V1,
                                                self.space_id, int(beam_width), float(self.token_min_logp),
                                                float(self.beam_prune_logp), lm.handle if lm is not None else None,
-                                               ids.data_ptr(), n.data_ptr(), score.data_ptr(), self._ws.data_ptr(),
-                                               self._ws.numel(), torch.cuda.current_stream().cuda_stream))
+                                               ids.data_ptr(), n.data_ptr(), score.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), stream))
         return ids, n, score
 
     def decode_batch(self, log_probs, beam_width, frames=None):

@@ -53,6 +53,7 @@
 // ::test_exact_score_ties_do_not_depend_on_the_kernel_form, every case of the randomised comparison runs both forms; soak:
 // profiles/r05_beam_soak.txt, 26 000 searches, 1 / 3 / 15 rows four times each against 16 rows).  Workgroup = 256 threads = one utterance; LDS ~136 KB, one workgroup per CU.
 // Used for batches of < 16 utterances (vasr_api.cpp); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -943,7 +944,19 @@ int launch_group(const float* logp, int batch, int frames, int V1, int space_id,
 // wavefronts an utterance of a batch gets: 4 below 16 utterances (a lone utterance, a small serving batch: latency), 1 from
 // there on (beam_wave.hip: four utterances per compute unit, the chip left to the next acoustic pass)
 int beam_group_width(int batch) {
-  static const int force = dev_env("VASR_BEAM_GROUP") ? atoi(dev_env("VASR_BEAM_GROUP")) : -1;   // 0 | 1: never, 4: always (dev: A/B runs)
+  // VASR_BEAM_GROUP (devtools build, A/B runs): 0 or 1 = never the four-wavefront form, 4 = always.  Only W = 4 is
+  // instantiated: any other value is refused loudly instead of silently falling back to the default rule (runs
+  // recorded as "W=2" and "W=8" had really been W=4).
+  static const int force = [] {
+    const char* e = dev_env("VASR_BEAM_GROUP");
+    if (!e) return -1;
+    const int v = atoi(e);
+    if (v != 0 && v != 1 && v != 4) {
+      fprintf(stderr, "vasr: VASR_BEAM_GROUP=%s is not 0, 1 or 4 -- refusing to guess\n", e);
+      abort();
+    }
+    return v;
+  }();
   if (force == 0 || force == 1) return 1;
   if (force == 4) return 4;
   return batch < 16 ? 4 : 1;

@@ -1129,7 +1129,7 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
   // < 16 utterances: an utterance on four wavefronts of a compute unit (beam_group.hip, the serving latency); from there on
   // one wavefront per utterance, four utterances per compute unit (beam_wave.hip).  Same bits either way; VASR_BEAM_GROUP
-  // (devtools build: 0 | 2 | 4) pins the form for A/B runs.
+  // (devtools build: 0 | 1 = never, 4 = always the four-wavefront form; anything else aborts) pins the form for A/B runs.
   const int e = launch_beam_search_group(
       d_logp, batch, (int)frames, num_classes, space_id < 0 ? 255 : space_id, beam_width, token_min_logp, beam_prune_logp,
       lm ? &lm->view : nullptr, static_cast<unsigned int*>(d_ws), d_ids, d_id_len, d_score, static_cast<hipStream_t>(stream),
@@ -1317,10 +1317,11 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   return check_launch("bench_pointwise");
 }
 
-int vasr_bench_mfma_bf16_sustained(int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream) {
+int vasr_bench_mfma_sustained(int gemm_mode, int workgroups, int steps, float* d_sink, double* flops, vasr_stream stream) {
   if (workgroups < 1 || steps < 1 || !d_sink || !flops) return fail(VASR_ERR_INVALID, "bad argument");
-  *flops = launch_mfma_bf16_sustained(workgroups, steps, d_sink, static_cast<hipStream_t>(stream));
-  return check_launch("mfma_bf16_sustained");
+  if (gemm_mode != 1 && gemm_mode != 3) return fail(VASR_ERR_INVALID, "gemm mode %d has no 16-bit MFMA stream (1 = bf16x3, 3 = f16x2)", gemm_mode);
+  *flops = launch_mfma_sustained(gemm_mode, workgroups, steps, d_sink, static_cast<hipStream_t>(stream));
+  return check_launch("mfma_sustained");
 }
 
 int vasr_pack_pointwise_bf16x3(const float* h_w, int cout, int cin, int m_pad, uint16_t* h_out) {

@@ -182,7 +182,7 @@ void pack_pointwise_weights(const float* w, int cout, int cin, int m_pad, float*
 // arith: 0 = 3 x bf16 (six MFMA products per multiply), 1 = 2 x bf16 (three, reduced precision), 2 = 2 x fp16 scaled
 // (three; needs amax_x / w_inv_scale and the fp16 pack).  Returns 0 or a hipError_t.
 bool pointwise_split_supported(int M, int K, int K1);
-double launch_mfma_bf16_sustained(int n_cu, int steps, float* sink, hipStream_t st);
+double launch_mfma_sustained(int gemm_mode, int n_cu, int steps, float* sink, hipStream_t st);
 int launch_pointwise_split(const PwArgs& a, int arith, hipStream_t st, int* amax_n = nullptr);
 // the 2 x fp16 arithmetic on the small-batch latency kernel (encoder_pw_lat.hip), bit-identical results; -1: shape not covered
 bool pointwise_latency_supported(int M, int K, int K1);

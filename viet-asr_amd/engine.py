@@ -120,6 +120,8 @@ class QuartzNetCTC:
         """Host side of helpers.py:32 -- ''.join(labels[c]) over the collapsed ids."""
         ids = ids.cpu().numpy()
         n = id_len.cpu().numpy()
+        if (n < 0).any():      # vasr.h: id_len = -1 = the beam search's merge cells overflowed (cannot happen; reported, not hidden)
+            raise _lib.VasrError("beam search reported an internal overflow (id_len = -1) for rows %s" % (n < 0).nonzero()[0].tolist())
         return ["".join(self.labels[c] for c in ids[b, : n[b]]) for b in range(ids.shape[0])]
 
     def transcribe(self, signals, row_independent=False):

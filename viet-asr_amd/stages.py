@@ -20,16 +20,22 @@ def _need_cuda(*ts):
                                  "there is no CPU fallback for this path")
 
 
+# One workspace per (device, STREAM): the library is re-entrant per handle + stream (include/vasr.h), so two host threads
+# driving per-module calls on two streams must not be handed the same scratch memory (rounds 1-5 kept one per device).
+# Allocated while its stream is current, so the caching allocator's stream-ordered reuse covers a replaced (grown) buffer.
 _ws_cache = {}
+_ws_lock = __import__("threading").Lock()
 
 
 def _workspace(device, nbytes):
-    ws = _ws_cache.get(device)
-    if ws is None or ws.numel() < nbytes:
-        _ws_cache[device] = None
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _ws_cache[device] = ws
-    return ws
+    key = (device, _st())
+    with _ws_lock:
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            _ws_cache[key] = None
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            _ws_cache[key] = ws
+        return ws
 
 
 def melspec(handle, input_signal, length):
