@@ -85,13 +85,15 @@ GEMM_MODES = {
 }
 
 
-def pmc_traffic(prefix, suffix=""):
+def pmc_traffic(prefix, suffix="", workload=""):
     """Launch-weighted mean HBM bytes per launch of the kernels whose name starts with ``prefix``, from the newest
-    COMMITTED PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_round.sh;
+    COMMITTED PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, `bash tools/gpu.sh prof`;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  An offline figure: reported under traffic_offline, never as a
-    live measurement.  None when no summary exists."""
+    live measurement.  None when no summary exists.  workload: "" = the headline (profiles/rNN_pmc_traffic_summary.json), "c5_" =
+    one GPU's 512 x 30 s shard of configs[4] (profiles/rNN_c5_pmc_traffic_summary.json: tensors 12 x the Infinity Cache, so
+    FETCH_SIZE there is HBM traffic, where the headline's counts hits in the 256 MiB cache as well)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}pmc_traffic_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -729,8 +731,11 @@ def main():
             ms_ctc = timed(lambda: beam_dec.decode_ids(lp_ctc, a.beam_width), max(3, a.steps // 4))
         ms_step = elapsed / a.steps * 1e3
         wgs = int(_lib.lib().vasr_beam_workgroups(batch))
-        extra["beam"] = {"kernel": "beam_wave_kernel (one wavefront per utterance, four utterances per compute unit, merge table in LDS)",
-                         "bound": "instruction issue + LDS latency of one wavefront (dependent round trips per frame)", "beam_width": a.beam_width,
+        group = wgs == batch and batch > 1
+        extra["beam"] = {"kernel": ("beam_group_kernel<4> (an utterance on four wavefronts of one compute unit, merge table in LDS; the form for "
+                                    "batches up to 64)" if group or batch == 1 else
+                                    "beam_wave_kernel (one wavefront per utterance, four utterances per compute unit, merge table in LDS)"),
+                         "bound": "instruction issue + LDS latency of one wavefront per SIMD (dependent round trips per frame)", "beam_width": a.beam_width,
                          "ms_per_batch_alone": round(ms_beam, 3), "acoustic_ms_per_batch_alone": round(ms_ac, 3),
                          "ms_per_batch_on_ctc_like_posteriors": round(ms_ctc, 3) if ms_ctc else None,
                          "serial_sum_ms": round(ms_beam + ms_ac, 3),
@@ -782,8 +787,10 @@ def main():
         headline = a.config == 3 and not (a.model or a.batch or a.seconds or a.ragged)
         kname = "pw_gemm_kernel" if gemm == "fp32" else "pw_gemm_split_kernel"
         arith_tag = {"f16x2": ", 2>", "bf16x3": ", 0>", "bf16x2": ", 1>"}.get(gemm, "")
-        pw_traffic, traffic_src = pmc_traffic(kname, arith_tag) if headline else (None, None)
-        dw_traffic, _ = pmc_traffic("dw_") if headline else (None, None)
+        shard5 = a.config == 5 and not job and not (a.model or a.batch or a.seconds or a.ragged)
+        pmc_of = "" if headline else ("c5_" if shard5 else None)
+        pw_traffic, traffic_src = pmc_traffic(kname, arith_tag, pmc_of) if pmc_of is not None else (None, None)
+        dw_traffic, _ = pmc_traffic("dw_", "", pmc_of) if pmc_of is not None else (None, None)
         what = {"greedy": "greedy CTC", "beam": f"beam search (width {a.beam_width}" + (", 3-gram LM" if lm_info else ", no LM") + ")"}[decoder]
         if job:
             wl = (f"BASELINE configs[4]: the {JOB_CLIPS}-clip job, {model} {what}, {seconds:g}s {rate // 1000}kHz clips"
@@ -812,7 +819,7 @@ def main():
                          "frac_of_fp32_mfma_peak": round(cr["pw_tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                          "traffic": None, "traffic_offline": pw_traffic,
                          "traffic_note": "HBM bytes per launch from the committed PMC pass named in traffic_source (not measured in "
-                                         "this run; null off the headline workload)", "traffic_source": traffic_src,
+                                         "this run; null off the two profiled workloads: the headline and the configs[4] shard)", "traffic_source": traffic_src,
                          "flops_per_step": cr["pw_flops"], "ms_per_step": round(cr["pw_ms"], 3),
                          "launches_per_step": prof["pointwise"]["launches"] // a.steps,
                          # every 1x1-conv GEMM of the step, fused launches included with their WHOLE duration (depthwise

@@ -235,9 +235,9 @@ VASR_API int vasr_set_busy_cus(vasr_handle* h, int cus);
 typedef struct vasr_lm vasr_lm;
 VASR_API size_t vasr_beam_workspace_bytes(int batch, int64_t frames);
 /* Compute units a search of `batch` utterances occupies while it runs: what a caller that overlaps the search with the next
- * acoustic pass hands to vasr_set_busy_cus().  Below 16 utterances an utterance is searched by four wavefronts of a compute
- * unit of its own (the latency form: `batch` units); from 16 on by one wavefront, four utterances per workgroup = per compute
- * unit (ceil(batch / 4) units).  Both forms give the same bits. */
+ * acoustic pass hands to vasr_set_busy_cus().  Up to 64 utterances an utterance is searched by four wavefronts of a compute
+ * unit of its own (`batch` units, for the shortest time); beyond that by one wavefront, four utterances per workgroup = per
+ * compute unit (ceil(batch / 4) units).  Both forms give the same bits. */
 VASR_API int vasr_beam_workgroups(int batch);
 VASR_API int vasr_beam_search_f32(const float* d_logp, int batch, int64_t frames, int num_classes, int space_id,
                          int beam_width, float token_min_logp, float beam_prune_logp, const vasr_lm* lm,

@@ -77,12 +77,12 @@ def _run_mode(case, kind, Tn, bw, lm_kind, alpha, beta, lp, x, path, mode, texts
     dec = T.make_decoder(T.LABELS, path, mode, alpha, beta)
     ids, n, score = dec.decode_ids(x, bw)          # batch 1: the latency form, an utterance on four wavefronts (beam_group.hip)
     text = dec.decode_batch(x, bw)[0]
-    # the same utterance as rows of a batch of 16: one wavefront per utterance (beam_wave.hip) -- must give the SAME BITS
-    ids16, n16, score16 = dec.decode_ids(x.expand(16, -1, -1).contiguous(), bw)
-    for row in (0, 15):
+    # the same utterance as rows of a batch of 65: one wavefront per utterance (beam_wave.hip) -- must give the SAME BITS
+    ids16, n16, score16 = dec.decode_ids(x.expand(T.WAVE_ROWS, -1, -1).contiguous(), bw)
+    for row in (0, T.WAVE_ROWS - 1):
         k = int(n[0])
         if int(n16[row]) != k or not torch.equal(ids16[row, :k], ids[0, :k]) or float(score16[row]) != float(score[0]):
-            return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} {mode}: the one-wavefront kernel (row {row} of 16) and the "
+            return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} {mode}: the one-wavefront kernel (row {row} of 65) and the "
                     f"four-wavefront kernel disagree: lengths {int(n16[row])} / {k}, scores {float(score16[row])!r} / {float(score[0])!r}")
     texts.append(text)
     lm = T.oracle_lm(path, mode, alpha, beta)

@@ -29,6 +29,9 @@ def toy_lm(tmp_path):
 # reference got from 3-gram-lm.binary), "arpa" = unigram set + character trie read from the ARPA file (what it gets from a
 # path ending in .arpa -- the only kind of file this library reads).  Every device test with an LM runs both.
 LM_MODES = ["none", "binary", "arpa"]
+# the smallest batch the library searches with ONE wavefront per utterance (beam_wave.hip); up to 64 rows an utterance gets four
+# wavefronts of a compute unit (beam_group.hip: csrc/beam_group.hip beam_group_width).  Tests reach both forms by batch size.
+WAVE_ROWS = 65
 
 
 def make_decoder(labels, path, mode, alpha=0.7, beta=1.1):
@@ -298,10 +301,10 @@ def test_device_beam_search_matches_oracle(gpu, tmp_path, lm_mode, beam_width, V
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [1, 16])
+@pytest.mark.parametrize("rows", [1, WAVE_ROWS])
 def test_device_beam_search_has_both_lm_behaviours(gpu, tmp_path, rows):
     """The hand-checkable inputs of test_the_two_lm_behaviours_rank_differently on the device, in both kernel forms (1 row:
-    four wavefronts per utterance, 16 rows: one), and the default (`unigrams="auto"`) follows the path's suffix as
+    four wavefronts per utterance, 65 rows: one), and the default (`unigrams="auto"`) follows the path's suffix as
     pyctcdecode's build_ctcdecoder does (beam_search_decoder.py:82-87: "either .arpa or .bin file")."""
     import shutil
     from viet_asr_amd.beam import BeamSearchDecoder

@@ -121,13 +121,13 @@ def test_fused_sub_block_form_by_batch_size():
 
 
 def test_beam_search_form_by_batch_size():
-    """Which kernel searches a batch (host arithmetic only, vasr_beam_workgroups = compute units the search occupies): below 16
-    utterances the latency form -- four wavefronts and a compute unit per utterance (csrc/beam_group.hip; the reference
-    serves batch 1, infer.py:181-192) --, from 16 on one wavefront per utterance and four utterances per unit
-    (csrc/beam_wave.hip), which is what leaves the chip to the next acoustic pass at BASELINE configs[3]."""
+    """Which kernel searches a batch (host arithmetic only, vasr_beam_workgroups = compute units the search occupies): up to 64
+    utterances four wavefronts and a compute unit per utterance (csrc/beam_group.hip; the reference serves batch 1,
+    infer.py:181-192; at BASELINE configs[3] the shorter stay in the way of the next acoustic pass is worth the wider one,
+    beam_group_width), beyond that one wavefront per utterance and four utterances per unit (csrc/beam_wave.hip)."""
     L = _lib.lib()
-    assert [L.vasr_beam_workgroups(b) for b in (0, 1, 2, 8, 15)] == [0, 1, 2, 8, 15]
-    assert [L.vasr_beam_workgroups(b) for b in (16, 17, 64, 512)] == [4, 5, 16, 128]
+    assert [L.vasr_beam_workgroups(b) for b in (0, 1, 2, 8, 15, 16, 64)] == [0, 1, 2, 8, 15, 16, 64]
+    assert [L.vasr_beam_workgroups(b) for b in (65, 66, 128, 512)] == [17, 17, 32, 128]
 
 
 @pytest.mark.parametrize("K,dil", [(33, 1), (39, 1), (51, 1), (63, 1), (75, 1), (87, 2)])

@@ -6,7 +6,7 @@
 For every case (28 / 90 / 127 labels + blank -- 128 classes is the kernels' limit --, 20-1 200 frames, width 8-128, posteriors
 CTC-like / noisy / flat, with and without the synthetic 3-gram LM, ragged per-row frame counts) the same utterances are searched
   * as batches of 1, 3 and 15 rows: an utterance on four wavefronts (beam_group.hip), `repeats` times each, and
-  * as a batch of 16 + rows: one wavefront per utterance (beam_wave.hip);
+  * as a batch of 80 rows (the 16 utterances five times; beyond 64 rows): one wavefront per utterance (beam_wave.hip);
 ids, lengths and scores must be the same bits everywhere (a race in the LDS-only barriers of the four-wavefront kernel would
 show as a run-to-run difference, a scheduling-dependent merge order as a difference between the kernels).  No oracle here:
 tests/test_beam.py and tests/test_gpu_configs.py compare both kernels with it.  Prints one JSON line."""
@@ -78,7 +78,8 @@ def _run_mode(seed, name, mode, alpha, beta, labels, arpa, decs, lp, width, ragg
         decs[key] = BeamSearchDecoder(labels, lm_path=arpa if mode != "none" else None, alpha=alpha, beta=beta,
                                       unigrams=None if mode == "binary" else "auto")
     dec = decs[key]
-    ref = [t.cpu() for t in dec.decode_ids(lp, width, frames=ragged)]            # 16 rows: beam_wave.hip
+    # the 16 utterances five times over = 80 rows: beyond 64 rows the library searches with one wavefront per utterance (beam_wave.hip)
+    ref = [t.cpu()[:lp.shape[0]] for t in dec.decode_ids(lp.repeat(5, 1, 1), width, frames=ragged.repeat(5) if ragged is not None else None)]
     stats["searches"] += 1
     stats["overflow_rows"] += int((ref[1] < 0).sum())
     for lo, hi in ((0, 1), (1, 4), (1, 16)):                                     # 1, 3, 15 rows: beam_group.hip

@@ -255,9 +255,7 @@ void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int b
       q = (int)(d / g);
     }
   }
-  static const bool generic_only = dev_env("VASR_RESAMPLE_GENERIC") && atoi(dev_env("VASR_RESAMPLE_GENERIC")) != 0;
-  static const bool no_up = dev_env("VASR_RESAMPLE_NO_UP") && atoi(dev_env("VASR_RESAMPLE_NO_UP")) != 0;   // A/B: the phase kernel
-  if (p >= 2 && p <= 16 && q == 1 && !generic_only && !no_up) {   // integer up-sampling: 8 -> 16 kHz
+  if (p >= 2 && p <= 16 && q == 1) {   // integer up-sampling: 8 -> 16 kHz
     const int wmax = nwin / num_table + 2;                              // >= taps of either wing
     const int mpad = (2 * wmax + kUpTB - 1) / kUpTB * kUpTB;
     const int tile = kUpR * p * (256 / p);
@@ -268,7 +266,7 @@ void launch_resample(const float* x, int64_t ld_in, const int64_t* len_in, int b
                        nwin, num_table, p, wmax, mpad, span, tile, y, ld_out, len_out);
     return;
   }
-  if (p > 0 && !generic_only) {
+  if (p > 0) {
     const double scale = ratio < 1.0 ? ratio : 1.0;
     const int index_step = (int)(scale * num_table);
     const int wmax = nwin / index_step + 2;

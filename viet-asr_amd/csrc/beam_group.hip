@@ -52,8 +52,7 @@
 // Results equal beam_wave.hip's bit for bit (tests/test_beam.py::test_wave_kernel_and_group_kernel_agree,
 // ::test_exact_score_ties_do_not_depend_on_the_kernel_form, every case of the randomised comparison runs both forms; soak:
 // profiles/r05_beam_soak.txt, 26 000 searches, 1 / 3 / 15 rows four times each against 16 rows).  Workgroup = 256 threads = one utterance; LDS ~136 KB, one workgroup per CU.
-// Used for batches of < 16 utterances (vasr_api.cpp); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
-#include <cstdio>
+// Used for batches of <= 64 utterances (beam_group_width below); VASR_BEAM_GROUP=0 (devtools build) pins the one-wavefront kernel.
 #include <cstdlib>
 #include <type_traits>
 
@@ -65,10 +64,7 @@ namespace {
 using namespace beam_detail;
 
 constexpr int kTab = 2048;                // merge-table slots
-#ifndef VASR_BEAM_GROUP_FILL
-#define VASR_BEAM_GROUP_FILL 716          // pairs per pass (file header; 358 = beam_wave.hip's: dev A/B builds)
-#endif
-constexpr int kFill = VASR_BEAM_GROUP_FILL;
+constexpr int kFill = 716;                // pairs per pass (file header; beam_wave.hip: 358)
 constexpr int kTbRows = 12;
 constexpr int kLpFrames = 8;
 constexpr int kLpRegs = kLpFrames * kMaxClasses / 64;
@@ -193,14 +189,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   int hd = 0;                  // radix digits histogrammed so far: digit hd uses hist[hd % 3] (uniform)
   bool all_blank = false;      // every live beam ends in blank (uniform)
   bool dirty = false;          // frames of a blank run have updated beams without a barrier (uniform)
-#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals of wavefront 0 of utterance 0 (lane k accumulates section k)
-  unsigned pacc = 0, pt = (unsigned)__builtin_readcyclecounter();
-#define GTICK(k) { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); pacc += lane == (k) ? now_ - pt : 0u; pt = now_; }
-#define GCOUNT(k, v) pacc += lane == 32 + (k) ? (unsigned)(v) : 0u;
-#else
-#define GTICK(k)
-#define GCOUNT(k, v)
-#endif
 
   // Candidate characters are a function of the frame alone, not of the beams: the four wavefronts list them for 32 frames
   // at a time IN PARALLEL (eight frames each) instead of each repeating every frame's list in the serial loop -- 1 250 of a
@@ -267,7 +255,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
 
   for (int t = 0; t < frames; ++t) {
     // ---- 1. candidate characters: from the chunk's records (pre-pass at every chunk boundary) ----
-    GTICK(15)
     if ((t & (kChunk - 1)) == 0) {
       group_sync();                        // the previous chunk's records (and frame t - 1's beams) are done with
       dirty = false;
@@ -315,7 +302,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     const int4 hdr = *reinterpret_cast<const int4*>(&S.rc_hdr[fr][0]);
     const int nc_all = __builtin_amdgcn_readfirstlane(hdr.x);
     const bool has_space = __builtin_amdgcn_readfirstlane(hdr.y) & 1, only_blank = __builtin_amdgcn_readfirstlane(hdr.y) & 2;
-    GTICK(0)
 
     // a blank-only frame met by beams that all end in blank: one beam per thread, nothing crosses wavefronts
     if (only_blank && all_blank) {
@@ -325,11 +311,9 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
       }
       dirty = true;
-      GTICK(1)
       continue;
     }
     if (dirty) { group_sync(); dirty = false; }
-    GCOUNT(0, 1)
 
     // ---- 2. ' ' is a candidate: LM cache log + commit scores, one beam per thread ----
     if (use_lm && has_space) {
@@ -364,7 +348,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       // (the commit scores are read after barrier B1)
     }
 
-    GTICK(2)
     const int cap = max(1, (int)(((float)kFill + 0.5f) * __builtin_amdgcn_rcpf((float)nb)));
     // survivors carried from the earlier passes of this frame (wavefront 0 only): ranks lane and lane + 64
     long long c_tot[2] = {ord64(-1e300), ord64(-1e300)}, c_lgt[2] = {0, 0};
@@ -459,12 +442,9 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         for (int j = 0; j < PPL; ++j) n_cl += __popcll(__ballot(claimed >> j & 1));
         if (lane == 0 && n_cl) atomicAdd(&S.red_claimed[epoch & 1], n_cl);
       }
-      GTICK(3)
       group_sync();                                                     // ---- B1
-      GTICK(4)
-      GCOUNT(1, npairs) GCOUNT(2, 1)
+       
       const bool any_merge = S.merge_epoch == epoch;                    // uniform over the workgroup
-      GTICK(5)
       // ---- 3. merged prefixes, each in the lane that claimed its slot ----
       long long tot[PPL], lgt[PPL];
       long long my_best = NC ? max(c_tot[0], c_tot[1]) : ord64(-1e300);
@@ -522,9 +502,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
         my_best = max(my_best, tot[j]);
       }
       if (my_best != ord64(-1e300)) atomicMax(&S.red_best[epoch & 1], my_best);
-      GTICK(6)
       group_sync();                                                     // ---- B4
-      GTICK(7)
       const long long best = S.red_best[epoch & 1];
       const int n_claimed_all = S.red_claimed[epoch & 1] + n_sel;       // + the carried survivors
       if (tid == 0) {   // the other set: last read a pass ago, next written after this pass's B6
@@ -572,10 +550,8 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
             if ((live >> j & 1) && (u & mask) == prefix) atomicAdd(&h[255 - (int)((u >> shift) & 255)], 1);
           }
           for (int i = tid; i < 256; i += 64 * W) hn[i] = 0;          // the next digit's buffer (last read two digits ago)
-          GTICK(8)
           group_sync();                                               // ---- R
-          GTICK(9)
-          GCOUNT(4, 1)
+          
           // lane l owns digits 255 - 4 l ... 252 - 4 l = bins 4 l ... 4 l + 3: one 16-byte read, the largest digit first
           const int4 c4 = *reinterpret_cast<const int4*>(&h[4 * lane]);
           const int cnt[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -658,7 +634,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           want = want_tied;
         }
       }
-      GTICK(10)
       // ---- selected: live and key > threshold prefix, plus the first `want` equal to it in PAIR ORDER (block = 64 pairs:
       //      index W j + w; the carried survivors follow as blocks W PPL and W PPL + 1).  Every wavefront publishes its
       //      blocks' (greater, equal) counts; after B6 each computes every block's offset itself ----
@@ -677,9 +652,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
           else if (wv == 0) { S.mb_gt[W * PPL + (j - PPL)] = ng; S.mb_eq[W * PPL + (j - PPL)] = ne; }
         }
       }
-      GTICK(11)
       group_sync();                                                     // ---- B6
-      GTICK(12)
       // (every wavefront walks all blocks' counts itself; a lane-per-block form with two DPP scans measured 160-350 cycles per
       // frame SLOWER: at one to three pairs per lane the walk is 4-14 short iterations)
       int n_out = 0, eq_seen = 0;
@@ -736,9 +709,7 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
       else if (ppl == 2) go(std::integral_constant<int, 2>{});
       else go(std::integral_constant<int, 3>{});
     }
-    GTICK(13)
     group_sync();                                                       // ---- Z: the new beams are complete
-    GTICK(14)
     all_blank = S.anychar_epoch != t;
     nb = n_sel;
     cur ^= 1;
@@ -746,20 +717,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
   // every wavefront's back-pointer and log stores have reached L2 before wavefront 0 reads them back
   __syncthreads();
   if (wv != 0) return;
-#ifdef VASR_BEAM_PROF
-  S.hist[0][lane] = (int)pacc;
-  wave_sync();
-  if (lane == 0 && b == 0 && frames > 0) {
-    const int* P = S.hist[0];
-    const int gf = max(P[32], 1);
-    printf("group prof W=%d (cycles/frame over %d frames, wavefront 0): top %d candidates %d blank-exit %d LM %d expand %d B1wait %d merge %d "
-           "score %d B4wait %d live+hist %d Rwait %d radix-search %d flags %d B6wait %d offsets+build %d Zwait %d | general frames %d pairs/gf %d "
-           "passes %d merge passes %d radix digits %d beams %d\n", W, frames, P[15] / frames, P[0] / frames, P[1] / frames, P[2] / frames,
-           P[3] / frames, P[4] / frames, P[5] / frames, P[6] / frames, P[7] / frames, P[8] / frames, P[9] / frames, P[10] / frames,
-           P[11] / frames, P[12] / frames, P[13] / frames, P[14] / frames, P[32], P[33] / gf, P[34], P[35], P[36], nb);
-  }
-  const unsigned pt_tail = (unsigned)__builtin_readcyclecounter();
-#endif
   const int n_log = S.n_log;
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best (as beam_wave.hip) ----
@@ -921,9 +878,6 @@ __global__ __launch_bounds__(64 * W) void beam_group_kernel(const float* __restr
     out_len[b] = S.overflow ? -1 : n;
     out_score[b] = (float)bs;
   }
-#ifdef VASR_BEAM_PROF
-  if (lane == 0 && b == 0) printf("group prof tail (final pass + trace-back): %u cycles\n", (unsigned)__builtin_readcyclecounter() - pt_tail);
-#endif
 }
 
 template <int W>
@@ -941,25 +895,19 @@ int launch_group(const float* logp, int batch, int frames, int V1, int space_id,
 
 }  // namespace
 
-// wavefronts an utterance of a batch gets: 4 below 16 utterances (a lone utterance, a small serving batch: latency), 1 from
-// there on (beam_wave.hip: four utterances per compute unit, the chip left to the next acoustic pass)
+// wavefronts an utterance of a batch gets: 4 up to kGroupMaxBatch = 64 utterances, 1 beyond (beam_wave.hip: four utterances per
+// compute unit).  Rounds 4-5 drew the line at 16 ("a batch leaves the chip to the next acoustic pass").  Measured in round 6 at
+// configs[3] (64 x 501 frames, beam 128 + LM, search of batch k under the acoustic pass of batch k + 1): the four-wavefront
+// form holds 64 compute units for 1.31 ms where the one-wavefront form holds 16 for 2.13 ms -- 2.5 x the CU-time, and still the
+// STEP is shorter (5.75 against 5.87 ms) and a job's last batch pays 0.70 ms instead of 1.43: every GEMM launch that meets a
+// busy compute unit loses a partial round of tiles whatever the number of busy units, so what counts is how LONG the search
+// is in the way, not how wide.  Beyond a quarter of the chip the one-wavefront form keeps the CU-time down.
+constexpr int kGroupMaxBatch = 64;
 int beam_group_width(int batch) {
-  // VASR_BEAM_GROUP (devtools build, A/B runs): 0 or 1 = never the four-wavefront form, 4 = always.  Only W = 4 is
-  // instantiated: any other value is refused loudly instead of silently falling back to the default rule (runs
-  // recorded as "W=2" and "W=8" had really been W=4).
-  static const int force = [] {
-    const char* e = dev_env("VASR_BEAM_GROUP");
-    if (!e) return -1;
-    const int v = atoi(e);
-    if (v != 0 && v != 1 && v != 4) {
-      fprintf(stderr, "vasr: VASR_BEAM_GROUP=%s is not 0, 1 or 4 -- refusing to guess\n", e);
-      abort();
-    }
-    return v;
-  }();
+  const int force = dev_switches().beam_group;   // devtools build: 0 | 1 = never the four-wavefront form, 4 = always
   if (force == 0 || force == 1) return 1;
   if (force == 4) return 4;
-  return batch < 16 ? 4 : 1;
+  return batch <= kGroupMaxBatch ? 4 : 1;
 }
 
 int launch_beam_search_group(const float* logp, int batch, int frames, int V1, int space_id, int beam_width,

@@ -143,17 +143,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
   wave_sync();
   int cur = 0, nb = 1, n_log = 0;
   bool all_blank = false;      // every live beam ends in blank (uniform)
-#ifdef VASR_BEAM_PROF   // dev build: per-section cycle totals and work counters of utterance 0 (tools/probes/beam_lat.py, ONCE=1)
-  // One VGPR holds everything -- lane k accumulates section k, lane 32 + k counter k: sixteen 64-bit totals in scalar
-  // registers made the compiler spill half the kernel's uniform state around every tick (the first profile of this kernel
-  // showed 1 000 cycles of "loop top" that were nothing but that spill code).
-  unsigned pacc = 0, pt = (unsigned)__builtin_readcyclecounter();
-#define WTICK(k) { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); pacc += lane == (k) ? now_ - pt : 0u; pt = now_; }
-#define WCOUNT(k, v) pacc += lane == 32 + (k) ? (unsigned)(v) : 0u;
-#else
-#define WTICK(k)
-#define WCOUNT(k, v)
-#endif
 
   // Log-probs reach the frames through LDS, kLpFrames frames per batch (a contiguous run of kLpFrames * V1 floats), and
   // the batch after the current one is already on its way in registers.  Two things measured on the way: (1) a per-frame
@@ -226,7 +215,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     // ---- 1. candidate characters.  pyctcdecode works on log(clip(p, 1e-15, 1)) = clip(x, log 1e-15, 0); for every class
     //         that can be a candidate (x >= token_min_logp, or the arg-max) that is min(x, 0), a float: no fp64 here ----
     const int c0 = lane, c1 = lane + 64;
-    WTICK(9)
     if ((t & (kLpFrames - 1)) == 0) {                        // batch boundary: land the batch in LDS, request the next one
 #pragma unroll
       for (int k = 0; k < kLpRegs; ++k) if (64 * k + lane < lp_batch) S.lpq[64 * k + lane] = q[k];
@@ -254,7 +242,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     const bool has_space = space_id < 64 ? (m0 >> space_id & 1) : (space_id < 128 ? (m1 >> (space_id - 64) & 1) : false);
     const bool only_blank = nc_all == 1 && (V < 64 ? (m0 >> V & 1) : (m1 >> (V - 64) & 1));
     wave_sync();
-    WTICK(0)
 
     // A frame whose only candidate is blank, met by beams that all end in blank already, changes nothing but the
     // scores, and those by the same amount: prefixes and last characters stay distinct (no merge), the LM parts and
@@ -268,10 +255,8 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         bp[(int64_t)t * kMaxBeams + i] = (unsigned)i << 8;
       }
       wave_sync();
-      WTICK(1)
       continue;
     }
-    WCOUNT(0, 1)
 
     // ---- 2. ' ' is a candidate: "text + pending word" of every live beam enters pyctcdecode's LM score cache (eoslog), and
     //         every pending word gets the LM score a commit would add -- once per (text, word): children that keep both
@@ -280,9 +265,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       for (int i0 = 0; i0 < nb; i0 += 64) {
         const int i = i0 + lane;
         bool put = false;
-#ifdef VASR_BEAM_PROF
-        bool did_lm = false;
-#endif
         unsigned long long h = 0;
         if (i < nb) {
           const unsigned m = S.meta[cur][i];
@@ -297,16 +279,12 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
               S.commit_lmd[cur][i] = lm_word_score(lm, ctx, S.whash[cur][i], false, &w);
               S.commit_wid[cur][i] = w;
               S.meta[cur][i] = m | kMetaCommit;
-#ifdef VASR_BEAM_PROF
-              did_lm = true;
-#endif
             }
           }
         }
         const unsigned long long pm = __ballot(put);
         if (put) eoslog[n_log + rank_in(pm)] = h;
         n_log += __popcll(pm);
-        WCOUNT(5, __popcll(__ballot(did_lm)))
       }
       wave_sync();
     }
@@ -319,7 +297,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     int c_src[2] = {0, 0};
     int n_sel = 0;
     bool any_char = false;
-    WTICK(2)
 
     // table key of pair (beam bi, character c) = src -- (prefix text, last character), as the expand step forms it
     auto pair_key = [&](int sr) __attribute__((always_inline)) -> unsigned long long {
@@ -338,7 +315,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       constexpr int PPL = decltype(ppl_tag)::value;
       const int npairs = nb * nc;
       const float inv_nc = __builtin_amdgcn_rcpf((float)nc);
-      WCOUNT(1, npairs) WCOUNT(3, 1)
       int slot[PPL], src[PPL];
       double score[PPL];
       unsigned claimed = 0, act = 0;
@@ -419,7 +395,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       }
       const bool any_merge = __ballot((act & ~claimed) != 0u) != 0ull;      // uniform
       wave_sync();
-      WTICK(3)
       // ---- ... a merged slot's max becomes max(claimer, contributors), the contributors add exp(score - max): hardware 2^x
       //      on a float (1 ulp), as a 2^-44 fixed-point integer -- associative, hence deterministic ----
       unsigned merged = 0;             // bit j: the slot this lane claimed for pair j has further contributors
@@ -441,13 +416,9 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         }
         wave_sync();
       }
-      WTICK(4)
       // ---- 3. merged prefixes, each in the lane that claimed its slot: combined score; the slot goes back to empty ----
       long long tot[PPL], lgt[PPL];
       long long my_best = max(c_tot[0], c_tot[1]);
-#ifdef VASR_BEAM_PROF
-      int n_claimed = 0;
-#endif
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         // (reads unconditional -- every lane has a valid slot and parent for every j -- so that the PPL chains overlap;
@@ -483,14 +454,9 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         tot[j] = mine ? ord64(logit + (double)lmt) : ord64(-1e300);
         lgt[j] = __double_as_longlong(logit);
         my_best = max(my_best, tot[j]);
-#ifdef VASR_BEAM_PROF
-        n_claimed += __popcll(__ballot(mine));
-#endif
       }
-      WCOUNT(2, n_claimed)
       const long long best = wave_max_i64(my_best);
       wave_sync();
-      WTICK(5)
       // ---- 4. prune (max + beam_prune_logp), then the top beam_width by combined score ----
       const long long thr_prune = ord64(unord64(best) + (double)beam_prune_logp);
       const unsigned long long ubest = (unsigned long long)best ^ 0x8000000000000000ull;
@@ -507,7 +473,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
       int want = beam_width;
       bool tie = false;                 // (uniform) the digits ran out on a bucket with more entries than wanted
       if (tot_live > beam_width) {
-        WCOUNT(6, 1)
         // every live key lies between the prune threshold and the best score: the leading BITS those two have in common
         // (sign, exponent, the top of the mantissa) are common to all of them and cost no pass -- the first digit starts at the
         // first bit in which they differ (round 5: byte-aligned digits wasted most of the first one, 3.1 -> 2.4 digits per select
@@ -520,7 +485,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         tie = lead == 64;                       // (a prune threshold AT the best score: whatever is live is tied)
 #pragma unroll 1
         for (int shift = max(0, 56 - lead); lead < 64; shift = max(0, shift - 8)) {
-          WCOUNT(4, 1)
           for (int i = lane; i < 256; i += 64) S.hist[i] = 0;
           wave_sync();
 #pragma unroll
@@ -599,7 +563,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
           want = want_tied;
         }
       }
-      WTICK(6)
       // selected: live and key > threshold prefix, plus the first `want` (pairs in order, then the carried survivors by
       // rank) equal to it.  A selected entry's record (pair, merged logit) goes to the sel_* rows at its rank: after the
       // last pass the new beams are built from them, otherwise they come back as carried survivors (rank = lane, lane + 64).
@@ -636,7 +599,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
         }
         wave_sync();
       }
-      WTICK(7)
     };
 
 #pragma unroll 1
@@ -663,22 +625,7 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     nb = n_sel;
     cur ^= 1;
     wave_sync();
-    WTICK(8)
   }
-#ifdef VASR_BEAM_PROF
-  S.hist[lane] = (int)pacc;
-  wave_sync();
-  if (lane == 0 && b == 0 && frames > 0) {
-    const int* P = S.hist;
-    const int gf = max(P[32], 1);
-    printf("wave prof (cycles/frame over %d frames): top %d candidates %d blank-exit %d LM+eoslog %d expand1 %d expand2 %d score %d "
-           "select %d publish %d build %d | general frames %d pairs/gf %d entries/gf %d passes %d radix digit passes %d LM scorings %d "
-           "select frames %d live beams %d\n", frames, P[9] / frames, P[0] / frames, P[1] / frames, P[2] / frames, P[3] / frames,
-           P[4] / frames, P[5] / frames, P[6] / frames, P[7] / frames, P[8] / frames, P[32], P[33] / gf, P[34] / gf, P[35], P[36],
-           P[37], P[38], nb);
-  }
-  const unsigned pt_tail = (unsigned)__builtin_readcyclecounter();
-#endif
 
   // ---- final: commit pending words (LM score with </s>), merge identical texts, pick the best ----
   // Is "text + pending word" in pyctcdecode's LM cache (then its cached score, WITHOUT </s>, is what the final pass
@@ -856,9 +803,6 @@ __global__ __launch_bounds__(256) void beam_wave_kernel(const float* __restrict_
     out_len[b] = n;
     out_score[b] = (float)bs;
   }
-#ifdef VASR_BEAM_PROF
-  if (lane == 0 && b == 0) printf("wave prof tail (final pass + trace-back): %u cycles total\n", (unsigned)__builtin_readcyclecounter() - pt_tail);
-#endif
 }
 
 }  // namespace
@@ -868,8 +812,6 @@ size_t beam_wave_lds_bytes() { return sizeof(WaveLds); }
 // utterances per workgroup (= per compute unit): a lone utterance gets a workgroup of its own; a batch is packed four to a
 // compute unit so that the search of batch k leaves the rest of the chip to the acoustic pass of batch k + 1
 int beam_wave_utts_per_workgroup(int batch) {
-  static const int force = dev_env("VASR_BEAM_UPW") ? atoi(dev_env("VASR_BEAM_UPW")) : 0;   // 1 | 2 | 4 (dev: A/B runs)
-  if (force == 1 || force == 2 || force == 4) return force;
   return batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
 }
 

@@ -439,13 +439,11 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
 template <int K, int DIL>
 void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* li, const int32_t* lo, int batch,
                     int channels, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
-  static const int lds_pad = dev_env("VASR_DW_LDSPAD") ? atoi(dev_env("VASR_DW_LDSPAD")) : 0;   // occupancy experiments
-  static const bool tail = !(dev_env("VASR_DW_TAIL") && atoi(dev_env("VASR_DW_TAIL")) == 0);   // A/B switch
   const int n_pairs = (batch + 1) / 2;
   // full 512-frame tiles, then a tail of 128 or 256 columns (the pitch is a multiple of 128; 384 runs as a full tile)
   int nt_main = (int)(ldy / kTile);
   int rest = (int)(ldy - (int64_t)nt_main * kTile);
-  if (!tail || rest > 256) { nt_main += rest ? 1 : 0; rest = 0; }
+  if (rest > 256) { nt_main += 1; rest = 0; }
   const int tiles_total = nt_main + (rest ? 1 : 0);
   if (amax) amax->n = channels * tiles_total;
   unsigned* ap = amax ? amax->p : nullptr;
@@ -456,7 +454,7 @@ void launch_dw_pair(const float* x, int64_t ldx, const float* w, const int32_t* 
   else if (rest == 256)
     VASR_LAUNCH((dw_pair_kernel<K, DIL, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
   else
-    VASR_LAUNCH((dw_pair_kernel<K, DIL, 1>), grid, dim3(256), lds_pad, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
+    VASR_LAUNCH((dw_pair_kernel<K, DIL, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, batch, y, ldy, ap, as, nt_main);
 }
 
 // Any kernel / stride / dilation / row pitch: one thread per output, taps straight from L1/L2.
@@ -529,24 +527,10 @@ void launch_dw_t(const float* x, int64_t ldx, const float* w, const int32_t* li,
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
   unsigned* ap = amax ? amax->p : nullptr;
   const int as = amax ? amax->stride : 0;
-  static const int rows_env = dev_env("VASR_DW_ROWS") ? atoi(dev_env("VASR_DW_ROWS")) : 1;
-  if (channels % 32 == 0 && rows_env == 8) {
-    dim3 grid(channels / 32, batch, tiles);
-    if (amax) amax->n = grid.x * 4 * tiles;
-    VASR_LAUNCH((dw_conv_kernel<K, 8>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
-  } else if (channels % 8 == 0 && rows_env == 2) {
-    dim3 grid(channels / 8, batch, tiles);
-    if (amax) amax->n = grid.x * 4 * tiles;
-    VASR_LAUNCH((dw_conv_kernel<K, 2>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
-  } else if (channels % 16 == 0 && rows_env != 1) {
-    dim3 grid(channels / 16, batch, tiles);
-    if (amax) amax->n = grid.x * 4 * tiles;
-    VASR_LAUNCH((dw_conv_kernel<K, 4>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
-  } else {
-    dim3 grid(channels / 4, batch, tiles);
-    if (amax) amax->n = grid.x * 4 * tiles;
-    VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
-  }
+  // (one channel per wavefront; 2 / 4 / 8 channels per wavefront were measured slower and are no longer instantiated)
+  dim3 grid(channels / 4, batch, tiles);
+  if (amax) amax->n = grid.x * 4 * tiles;
+  VASR_LAUNCH((dw_conv_kernel<K, 1>), grid, dim3(256), 0, st, x, ldx, w, li, lo, channels, y, ldy, ap, as);
 }
 
 }  // namespace
@@ -573,7 +557,7 @@ static int launch_depthwise_impl(const float* x, int64_t ldx, int frames_in, con
                                  int pad, float* y, int64_t ldy, hipStream_t st, AmaxTab* amax) {
   const bool aligned = channels % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-  static const bool pair = !(dev_env("VASR_DW_PAIR") && atoi(dev_env("VASR_DW_PAIR")) == 0);
+  const bool pair = dev_switches().dw_pair;   // devtools build: VASR_DW_PAIR=0 sends every shape to the generic kernel
   if (pair && aligned && stride == 1) {
     if (dilation == 2 && kernel == 87 && pad == 86)
       { launch_dw_pair<87, 2>(x, ldx, w, lens_in, lens_out, batch, channels, y, ldy, st, amax); return 0; }

@@ -24,7 +24,8 @@
 // CONSECUTIVE frames per lane, so one lane rotation (4 ds_bpermute_b32, no LDS storage, no barrier) makes every store
 // instruction write 1 KB of one row.
 //
-//   grid (C / 4, ceil(B / utterances per wave), ceil(ldy / 512)), block 256 = 4 wavefronts = 4 channels; a wavefront builds
+//   grid: 1-D over (C / 4) x ceil(B / utterances per wave) x ceil(ldy / 512) (XCD-aware order, see the kernel), block 256 =
+//   4 wavefronts = 4 channels; a wavefront builds
 //   its channel's A fragments once (from a [hi | lo] fp16 tap table packed at vasr_finalize()) and walks up to eight
 //   utterances with them, 512 frames (two MFMA groups sharing one staged row) per utterance, the next utterance's row in
 //   flight while the current one is multiplied.  The walk is fully unrolled: what depends on the utterance (row
@@ -52,19 +53,12 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((vector_size(16))) unsigned int;
 
-#ifndef VASR_TZ_ABLATE
-#define VASR_TZ_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no MFMAs, 2 no global stores, 4 no conversion /
-#endif                     // LDS staging, 8 no row loads, 16 no lane rotation, 32 no maxima publishing
 constexpr int kTile = 512;          // output frames per task: 2 groups of 16 windows x 16 outputs
 constexpr int kGroup = 256;
 constexpr int kUttPerWave = 8;      // upper bound; the launch passes the count in use
-#ifndef VASR_TZ_LDAUX
-#define VASR_TZ_LDAUX 0   // cache-policy bits of the row loads (dev)
-#endif
-#ifndef VASR_TZ_STAGES
-#define VASR_TZ_STAGES 1   // rows in flight per wavefront beyond the one being multiplied: 1 and 2 measure the same at 512
-                           // channels (23.2 us at K = 75), 1 is 5-10 % faster at 256; 3 and 4 are 25-30 % SLOWER (31 us)
-#endif
+// rows in flight per wavefront beyond the one being multiplied: 1 and 2 measure the same at 512 channels (23.2 us at K = 75),
+// 1 is 5-10 % faster at 256; 3 and 4 are 25-30 % SLOWER (31 us)
+constexpr int kRowStages = 1;
 
 template <int K, int DIL>
 struct TzGeom {
@@ -73,7 +67,7 @@ struct TzGeom {
   static constexpr int OFF = PADL - PAD;
   static constexpr int SPAN = 15 + DIL * (K - 1) + OFF + 1;         // window samples one 16-output window touches
   static constexpr int NS = (SPAN + 31) / 32;                       // k-steps
-  static constexpr int STAGES = VASR_TZ_STAGES;                     // register stages of NLD float4 each
+  static constexpr int STAGES = kRowStages;                         // register stages of NLD float4 each
   static constexpr int TSZ = 32 * NS + 16;                          // tap-table entries: entry i = dense tap i - (15 + OFF)
   static constexpr int ROWS = kTile - 16 + 32 * NS;                 // samples staged per task
   static constexpr int NLD = (ROWS / 4 + 63) / 64;                  // float4 loads per lane and task
@@ -105,10 +99,22 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
                                                           const unsigned* __restrict__ amax_x, int amax_x_stride,
                                                           int amax_x_n, int channels, int batch,
                                                           float* __restrict__ y, int64_t ldy,
-                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int upw_nt) {
+                                                          unsigned* __restrict__ amax_y, int amax_y_stride, int upw_nt,
+                                                          int tiles, int n_rest) {
   using G = TzGeom<K, DIL>;
-  const int upw = upw_nt & 0xff;           // utterances one wavefront walks
-  const bool nt = (upw_nt & 0x100) != 0;   // non-temporal output stores
+  // 1-D grid -> (channel group, utterance group, time tile).  Workgroup i runs on XCD i % 8 (each with an L2 of its own).
+  // A row longer than one 512-frame tile is cut into time tiles whose staged rows OVERLAP by the window overhang (80 of 592
+  // samples): dealt to the XCDs round-robin -- rounds 2-5: grid (C / 4, B / upw, tiles), a row's neighbouring tiles 8 192
+  // workgroups apart -- that overhang came from HBM a second time (profiles/r06_c5_pmc_traffic_summary.json, the 512 x 30 s
+  // shard: FETCH_SIZE 1.10-1.18 x the tensor, WRITE_SIZE 1.00 x).  Here the tiles of one (channel group, utterance group) get
+  // consecutive slots of ONE XCD, so that the neighbour's overhang is in that L2 when it is asked for.  With a single tile
+  // per row (the 10 s headline) this is the old order: channel group fastest.
+  const int bid = (int)blockIdx.x;
+  const int rest = ((bid >> 3) / tiles) * 8 + (bid & 7);      // (channel group, utterance group) index, channel group fastest
+  if (rest >= n_rest) return;                                 // (the grid is padded to whole rounds of the 8 XCDs)
+  const int ncg = channels >> 2;
+  const int bx = rest % ncg, by = rest / ncg, bz = (bid >> 3) % tiles;
+  const int upw = upw_nt;                  // utterances one wavefront walks
   constexpr int NS = G::NS, NLD = G::NLD, kStages = G::STAGES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -116,10 +122,10 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   unsigned char* base = lds_raw + wave * G::LDS_WAVE;
   unsigned char* dat = base;                                               // [plane][PLANE]
   unsigned* tab = reinterpret_cast<unsigned*>(base + G::LDS_DATA);
-  const int c = blockIdx.x * 4 + wave;
-  const int t_tile = blockIdx.z * kTile;
+  const int c = bx * 4 + wave;
+  const int t_tile = bz * kTile;
   const int n16 = lane & 15, kg = lane >> 4;
-  const int b_lo = blockIdx.y * upw;
+  const int b_lo = by * upw;
   const int b_hi = min(b_lo + upw, batch);
   if (b_lo >= b_hi) return;
   const bool two = t_tile + kGroup < ldy;   // the second group has columns to write (wave-uniform)
@@ -170,8 +176,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const auto d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xrow0 + u * row_stride), 0, rng[u], 0x00020000);
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      if (!(VASR_TZ_ABLATE & 8)) sg.r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d, voff[j], 0, VASR_TZ_LDAUX));
-      else sg.r[j] = v4f{(float)voff[j], 1.f, 2.f, 3.f};
+      sg.r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d, voff[j], 0, 0));
     }
   };
   // scale by the utterance's power of two, split into fp16 hi / lo, 8 + 8 bytes into the two planes: sample tau at byte
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   // D fragment: lane n + 16 g holds frames 16 n + 4 g .. + 3; lane L pulls the registers of lane (L >> 2) + 16 (L & 3) and
   // then holds frames 4 L .. 4 L + 3
   const int pull = 4 * ((lane >> 2) + 16 * (lane & 3));
-  const int slot = c * gridDim.z + blockIdx.z;
+  const int slot = c * tiles + bz;
 
   float sxu[kUttPerWave], ixu[kUttPerWave];   // (scale, 1 / scale) per utterance, set below
   unsigned mxu[kUttPerWave];                  // per-lane maxima of the outputs, per utterance
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   //      also halves the number of registers -- a lane keeps the utterances whose index agrees with its lane bit and
   //      hands the others to its partner -- until lane L holds utterance L & 7; one store writes all of them ----
   auto publish = [&]() {
-    if (!amax_y || (VASR_TZ_ABLATE & 32)) return;
+    if (!amax_y) return;
 #define VASR_DPP(xx, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(xx), (ctrl), 0xF, 0xF, false))
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
     unsigned r[4], q[2];
@@ -239,8 +244,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
   };
   auto do_task = [&](auto u_tag, Stage& sg) {
     constexpr int u = decltype(u_tag)::value;
-    if (!(VASR_TZ_ABLATE & 4)) sstore(sg, sxu[u]);
-    else asm volatile("" :: "v"(sg.r[0]), "v"(sg.r[NLD - 1]));
+    sstore(sg, sxu[u]);
     // The utterance kStages ahead, in flight while this one and the next ones are multiplied and stored: issued whether
     // or not it exists (see rng[]), so that on the straight-line path the compiler knows how many vector-memory
     // operations are younger than the rows it waits for (s_waitcnt vmcnt counts, it does not name).
@@ -250,10 +254,7 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     // All B fragments of the task are requested before the first multiply (one exposed LDS round trip per task instead of
     // one per k-step), and the two groups' accumulation chains alternate on the matrix pipe.
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#ifndef VASR_TZ_ALLB
-#define VASR_TZ_ALLB 1
-#endif
-    constexpr bool kAllB = VASR_TZ_ALLB && NS <= 3;   // 16 NS registers of B fragments for both groups
+    constexpr bool kAllB = NS <= 3;   // 16 NS registers of B fragments for both groups
     auto load_b = [&](int q, uint4 (&bh)[NS], uint4 (&bl)[NS]) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -262,13 +263,9 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
       }
     };
     auto step = [&](f32x4 acc, int s, const uint4 (&bh)[NS], const uint4 (&bl)[NS]) {
-      if (!(VASR_TZ_ABLATE & 1)) {
-        acc = mma(al[s], bh[s], acc);
-        acc = mma(ah[s], bl[s], acc);
-        acc = mma(ah[s], bh[s], acc);
-      } else {
-        acc[s & 3] += __uint_as_float(bh[s].x ^ bl[s].y ^ al[s].x ^ ah[s].y);
-      }
+      acc = mma(al[s], bh[s], acc);
+      acc = mma(ah[s], bl[s], acc);
+      acc = mma(ah[s], bh[s], acc);
       return acc;
     };
     {
@@ -300,10 +297,9 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
     const auto dy = __builtin_amdgcn_make_buffer_rsrc(yr, 0, 4 * (int)ldy, 0x00020000);
     v4f o0 = {acc0[0] * os, acc0[1] * os, acc0[2] * os, acc0[3] * os};
     v4f o1 = {acc1[0] * os, acc1[1] * os, acc1[2] * os, acc1[3] * os};
-    if (!(VASR_TZ_ABLATE & 16)) {   // all eight pulls in flight together
-      o0.x = lane_pull(pull, o0.x); o0.y = lane_pull(pull, o0.y); o0.z = lane_pull(pull, o0.z); o0.w = lane_pull(pull, o0.w);
-      o1.x = lane_pull(pull, o1.x); o1.y = lane_pull(pull, o1.y); o1.z = lane_pull(pull, o1.z); o1.w = lane_pull(pull, o1.w);
-    }
+    // all eight pulls in flight together
+    o0.x = lane_pull(pull, o0.x); o0.y = lane_pull(pull, o0.y); o0.z = lane_pull(pull, o0.z); o0.w = lane_pull(pull, o0.w);
+    o1.x = lane_pull(pull, o1.x); o1.y = lane_pull(pull, o1.y); o1.z = lane_pull(pull, o1.z); o1.w = lane_pull(pull, o1.w);
     float mx = 0.f;
     auto finish = [&](v4f o, int q) {
       const int tq = t_tile + kGroup * q;
@@ -315,12 +311,8 @@ __global__ __launch_bounds__(256) void dw_toeplitz_kernel(const float* __restric
         o.w = nv > 3 ? o.w : 0.f;
       }
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-      if (!(VASR_TZ_ABLATE & 2)) {
-        // (wave-uniform) non-temporal when the layer's output cannot stay in the Infinity Cache: vasr_internal.h stream_stores
-        if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 2);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 0);
-      } else
-        asm volatile("" :: "v"(o));
+      // (non-temporal stores for outputs beyond the Infinity Cache were measured in rounds 1-3: no gain in the pipeline)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dy, 4 * (tq + 4 * lane), 0, 0);
     };
     finish(o0, 0);
     finish(o1, 1);
@@ -401,19 +393,20 @@ int launch_tz(const float* x, int64_t ldx, const unsigned* taps, const float* ta
   constexpr int lds = 4 * G::LDS_WAVE;
   const unsigned tiles = (unsigned)((ldy + kTile - 1) / kTile);
   // utterances one wavefront walks with its channel's A fragments: as many as leave >= 4096 wavefronts (4 per SIMD)
-  static const int upw_env = dev_env("VASR_DW_UPW") ? atoi(dev_env("VASR_DW_UPW")) : 0;
+  const int upw_env = dev_switches().dw_upw;   // devtools build: pins it
   int upw = kUttPerWave;
   if (upw_env >= 1 && upw_env <= kUttPerWave) upw = upw_env;
   else
     while (upw > 2 && (int64_t)channels * ((batch + upw - 1) / upw) * tiles < 4096) upw /= 2;
-  dim3 grid(channels / 4, (batch + upw - 1) / upw, tiles);
+  const int n_rest = (channels / 4) * ((batch + upw - 1) / upw);
+  dim3 grid((unsigned)(((n_rest + 7) / 8) * 8) * tiles);      // 1-D: the kernel deals it to (channel group, utterance group, tile)
   if (amax_y) {
-    amax_y->n = channels * grid.z;
+    amax_y->n = channels * (int)tiles;
     if (amax_y->n > amax_y->stride) return -1;
   }
   VASR_LAUNCH(kern, grid, dim3(256), lds, st, x, ldx, taps, tap_inv, li, lo, amax_x.p, amax_x.stride, amax_x.n, channels, batch,
               y, ldy, amax_y ? amax_y->p : nullptr, amax_y ? amax_y->stride : 0,
-              upw | (stream_stores((size_t)batch * channels * ldy * 4) ? 0x100 : 0));
+              upw, (int)tiles, n_rest);
   return 0;
 }
 

@@ -69,24 +69,6 @@ struct FTile {
   static constexpr int kSegBytes = FPS * 8 + 16;           // a lane's segment of its pair's window row incl. its pad: 144 / 80
 };
 
-#ifndef VASR_FUSED_PLAINFMA
-#define VASR_FUSED_PLAINFMA 0   // 1: v_fma_f32 pairs instead of v_pk_fma_f32 (compile with -fno-slp-vectorize)
-#endif
-#ifndef VASR_FUSED_PRIO_P
-#define VASR_FUSED_PRIO_P 0     // s_setprio of the producer wavefronts
-#endif
-#ifndef VASR_FUSED_PRIO_C
-#define VASR_FUSED_PRIO_C 0     // ... of the consumer wavefronts
-#endif
-#ifndef VASR_FUSED_SWAP
-#define VASR_FUSED_SWAP 0       // 1: wavefronts 0..3 produce (older), 4..7 consume
-#endif
-#ifndef VASR_FUSED_ABLATE
-#define VASR_FUSED_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no MFMAs, 2 no depthwise FMAs, 4 no epilogue stores,
-                              // 8 no epilogue at all, 16 no tap-table copy, 32 no conversion / B-image writes, 64 no row loads,
-                              // 128 no window staging (LDS writes + reads)
-#endif
-
 template <int K, int BN>
 struct FGeom {
   using TL = FTile<BN>;
@@ -139,7 +121,6 @@ struct FusedArgs {
   const int32_t* lens2;
   AmaxTab amax_x2;
   int32_t batch;
-  int32_t nt_store;
 };
 
 // LDS-only workgroup barrier: __syncthreads() would also drain the vector-memory counter, i.e. make the producers wait
@@ -181,7 +162,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   const int tile = bid % tiles_t;
   const int t0 = tile * BN;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (VASR_FUSED_SWAP ? 4 : 0)) & 7;   // role index: < 4 consumes
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // role index: < 4 consumes
   const int len_in = a.lens_in[b], len_out = a.lens_out[b];
   const int len2 = DUAL ? a.lens2[b] : 0;
   constexpr int NCH = (DUAL ? 2 : 1) * (FC / FCH);
@@ -202,7 +183,6 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   // those round trips instead of in front of them (1.6 us of a 31 us kernel when it came first).
   constexpr int kTapV4 = G::kTapBytes / 16, kTapIt = (kTapV4 + FNT - 1) / FNT;
   auto tap_copy = [&]() {
-    if (VASR_FUSED_ABLATE & 16) return;
     v4f tv[kTapIt];
 #pragma unroll
     for (int i = 0; i < kTapIt; ++i) {
@@ -218,7 +198,6 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
 
   if (wave < 4) {
     // =========================================== consumers =========================================================
-    if (VASR_FUSED_PRIO_C) __builtin_amdgcn_s_setprio(VASR_FUSED_PRIO_C);
     const int kh = lane >> 5, l31 = lane & 31;
     const int wm = wave * 64;
     constexpr int ksteps = NCH * 4;
@@ -285,23 +264,20 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
                   bf[nxt_f][p] = *reinterpret_cast<const uint4*>(bimg + bimg_off<BN>(cc, p, (g + 2) / NT) + boff[(g + 2) % NT]);
               }
               __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to two MFMAs before their use)
-              if (!(VASR_FUSED_ABLATE & 1)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][1]), __builtin_bit_cast(f16x8, bf[cur_f][0]), acc[i][j], 0, 0, 0);
+              for (int i = 0; i < 2; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][1]), __builtin_bit_cast(f16x8, bf[cur_f][0]), acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][0]), __builtin_bit_cast(f16x8, bf[cur_f][1]), acc[i][j], 0, 0, 0);
+              for (int i = 0; i < 2; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][0]), __builtin_bit_cast(f16x8, bf[cur_f][1]), acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][0]), __builtin_bit_cast(f16x8, bf[cur_f][0]), acc[i][j], 0, 0, 0);
-              }
+              for (int i = 0; i < 2; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cw[i][0]), __builtin_bit_cast(f16x8, bf[cur_f][0]), acc[i][j], 0, 0, 0);
             }
           }
         }
       }
     }
-    if (VASR_FUSED_ABLATE & 8) return;
     // ---- epilogue: BN affine + ReLU, rows transposed through the (now idle) producer windows into float4 stores ----
     const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
     unsigned ymax = 0;
@@ -344,7 +320,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           const int f = lane + 64 * k, row = f / (BN / 4), c4 = f % (BN / 4);
           const int m = mq + row, t = t0 + 4 * c4;
           const v4f v = __builtin_elementwise_max(pv[k], v4f{relu_floor, relu_floor, relu_floor, relu_floor});
-          if (!(VASR_FUSED_ABLATE & 4)) *reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t) = v;
+          *reinterpret_cast<v4f*>(a.y + ((int64_t)b * FC + m) * a.ldy + t) = v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned u = abs_bits(v[e]);
@@ -359,7 +335,6 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
 
   // ============================================= producers ===========================================================
   if (!live) return;
-  if (VASR_FUSED_PRIO_P) __builtin_amdgcn_s_setprio(VASR_FUSED_PRIO_P);
   const int pw = wave - 4;                    // k-step of the chunk this wavefront produces
   const int p = lane >> 3, s = lane & 7;      // channel pair, segment of FPS frames
   unsigned char* win = wins + pw * kWWave;
@@ -376,7 +351,6 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
       int t = t0 - G::PADL + 4 * q;
       t = t < 0 ? 0 : (t > (int)a.ldx - 4 ? (int)a.ldx - 4 : t);
       const float* r0 = xb + (int64_t)(2 * sp) * a.ldx + t;
-      if (VASR_FUSED_ABLATE & 64) { st[j][0] = v4f{1.f, 2.f, 3.f, (float)t}; st[j][1] = st[j][0]; continue; }
       st[j][0] = *reinterpret_cast<const v4f*>(r0);
       st[j][1] = *reinterpret_cast<const v4f*>(r0 + a.ldx);
     }
@@ -409,10 +383,6 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
   const int sx = (((FPS * s) & 15) ^ (((FPS * s) >> 4) | (kh << TL::KHS))) << 4;
   // converts the FPS (pair, frame) results of this lane and writes them into B image `buf`, k-step pw
   auto emit = [&](int buf, const v2f (&d)[FPS], int nvalid) {
-    if (VASR_FUSED_ABLATE & 32) {
-      if (d[0].x == 12345.678f) *reinterpret_cast<unsigned*>(bimg + wbase) = 1u;
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < FPS; ++j) {
       const float sj = j < nvalid ? xs : 0.f;              // MaskedConv1d: the pointwise conv sees zeros past lens_out
@@ -446,8 +416,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           u[e] = ok ? u[e] : 0.f;
           w[e] = ok ? w[e] : 0.f;
         }
-        if ((VASR_FUSED_ABLATE & 128) && u.x + w.y == 12345.678f) *reinterpret_cast<v4f*>(win) = u;
-        if (sp < 8 && !(VASR_FUSED_ABLATE & 128)) {
+        if (sp < 8) {
           unsigned char* dst = win + sp * kWPitch + (4 * q) * 8 + ((4 * q) / FPS) * 16;   // 16 bytes of pad per FPS frames
           *reinterpret_cast<v4f*>(dst) = v4f{u.x, w.x, u.y, w.y};
           *reinterpret_cast<v4f*>(dst + 16) = v4f{u.z, w.z, u.w, w.w};
@@ -463,8 +432,7 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
       auto load_units = [&](int qa, int qb) {
 #pragma unroll
         for (int qq = qa; qq < qb; ++qq) {
-          const v4f v = (VASR_FUSED_ABLATE & 128) ? v4f{st[0][0].x, st[0][1].y, (float)qq, 1.f}
-                                                   : *reinterpret_cast<const v4f*>(rd + qq * 16 + (qq / (FPS / 2)) * 16);   // frames 2 qq, 2 qq + 1
+          const v4f v = *reinterpret_cast<const v4f*>(rd + qq * 16 + (qq / (FPS / 2)) * 16);   // frames 2 qq, 2 qq + 1
           xw[2 * qq] = v.xy;
           xw[2 * qq + 1] = v.zw;
         }
@@ -494,23 +462,14 @@ __global__ __launch_bounds__(FNT, 1) void dwpw_fused_kernel(FusedArgs a, int til
           load_taps(blk + 1);
           load_units(G::qend(blk), G::qend(blk + 1));
         }
-        if (!(VASR_FUSED_ABLATE & 2)) {
 #pragma unroll
-          for (int k = G::TB * blk; k < G::TB * (blk + 1) && k < K; ++k) {
+        for (int k = G::TB * blk; k < G::TB * (blk + 1) && k < K; ++k) {
 #pragma unroll
-            for (int j = 0; j < FPS; ++j) {
-#if VASR_FUSED_PLAINFMA
-              acc[j].x = __builtin_fmaf(wt[k - G::TB * blk].x, xw[G::OFF + j + k].x, acc[j].x);
-              acc[j].y = __builtin_fmaf(wt[k - G::TB * blk].y, xw[G::OFF + j + k].y, acc[j].y);
-#else
-              acc[j] = __builtin_elementwise_fma(wt[k - G::TB * blk], xw[G::OFF + j + k], acc[j]);
-#endif
-            }
-            // one tap at a time over all FPS accumulators: left alone, the scheduler turns the loops inside out (one output
-            // at a time, its taps as a dependent chain with a wait state between links) to save registers
+          for (int j = 0; j < FPS; ++j) acc[j] = __builtin_elementwise_fma(wt[k - G::TB * blk], xw[G::OFF + j + k], acc[j]);
+          // one tap at a time over all FPS accumulators: left alone, the scheduler turns the loops inside out (one output
+          // at a time, its taps as a dependent chain with a wait state between links) to save registers
 #pragma unroll
-            for (int j = 0; j < FPS; ++j) asm volatile("" : "+v"(acc[j]));
-          }
+          for (int j = 0; j < FPS; ++j) asm volatile("" : "+v"(acc[j]));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -585,7 +544,6 @@ int launch_fused_dwpw(const FusedLaunch& f, hipStream_t st, int* amax_n) {
   a.amax_x = f.amax_x; a.wt = reinterpret_cast<const uint4*>(f.wt); a.w_inv_scale = f.w_inv_scale; a.scale = f.scale;
   a.shift = f.shift; a.y = f.y; a.ldy = f.ldy; a.frames = f.frames; a.relu = f.relu; a.amax_y = f.amax_y;
   a.lens_y = f.lens_y; a.x2 = f.x2; a.ldx2 = f.ldx2; a.lens2 = f.lens2; a.amax_x2 = f.amax_x2; a.batch = f.batch;
-  a.nt_store = f.nt_store;
   const bool dual = f.x2 != nullptr;
   if (f.tile_cols == 64) {
     if (f.kernel == 33) return dual ? launch_fused_t<33, true, 64>(a, st, amax_n) : launch_fused_t<33, false, 64>(a, st, amax_n);

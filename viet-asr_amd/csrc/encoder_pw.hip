@@ -207,11 +207,10 @@ void launch_pointwise(const PwArgs& a, hipStream_t st) {
   // round 2: it only runs when the pitch allows it, and no caller can reach it with K % 64 != 0 any more.
   // Tile choice: cover all of M with one workgroup where possible (each activation fetched once), and keep
   // >= 2 workgroups per CU in flight: 512 ch -> 512x64 tiles, 256 ch -> 256x64 (one m-tile per wave), else 128x128.
-  static const int force = dev_env("VASR_PW_TILE") ? atoi(dev_env("VASR_PW_TILE")) : 0;
   const int kq = a.x2 ? a.K1 : a.K;   // dual source: both parts must be whole chunks of the K depth per LDS buffer
   const bool k128 = a.K % 128 == 0 && kq % 128 == 0, k64 = a.K % 64 == 0 && kq % 64 == 0;
-  if (a.M % 512 == 0 && k128 && force != 42) launch_t<8, 2>(a, st);
-  else if (a.M % 256 == 0 && k128 && force != 42) launch_t<8, 1>(a, st);
+  if (a.M % 512 == 0 && k128) launch_t<8, 2>(a, st);
+  else if (a.M % 256 == 0 && k128) launch_t<8, 1>(a, st);
   else if (a.M % 256 == 0 && k64) launch_t<4, 2>(a, st);
   else if (k64) launch_t<4, 1>(a, st);
   else launch_t<2, 2>(a, st);   // K % 32 shapes on a 256-frame pitch only (unreachable through the C ABI today)

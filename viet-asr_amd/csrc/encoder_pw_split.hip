@@ -52,9 +52,6 @@ enum { kBf16x3 = 0, kBf16x2 = 1, kF16x2 = 2 };
 
 constexpr int BKC = 64;   // K rows per LDS buffer
 
-#ifndef VASR_ABLATE
-#define VASR_ABLATE 0   // dev-only timing ablations (results are wrong): 1 no weight reloads, 2 no LDS fragment reads,
-#endif                  // 4 no activation staging, 8 no per-chunk barrier
 constexpr int STEPS = BKC / 16;
 
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
@@ -128,26 +125,9 @@ struct Geom {
   static_assert(PATCHES % NT == 0 && PPT >= 1, "staging patches must divide evenly over the threads");
 };
 
-// Dev experiment of round 5 (profiles/r05_fused512_probe.txt): VASR_PW_XWAVES extra wavefronts join the 512 x 64 tile's
-// workgroup, take part in its barriers and execute VASR_PW_XFILL packed FMAs per K chunk each -- the vector work the
-// depthwise PRODUCER wavefronts of a fused 512-channel kernel would issue next to this GEMM stream (8 K per lane and
-// chunk for 16 channels x 64 frames per wavefront: 408 at K = 51, 504 at 63, 600 at 75).  Results stay correct.
-#ifndef VASR_PW_XWAVES
-#define VASR_PW_XWAVES 0
-#endif
-#ifndef VASR_PW_XFILL
-#define VASR_PW_XFILL 408
-#endif
-#ifndef VASR_PW_XPLAIN
-#define VASR_PW_XPLAIN 0   // 1: two v_fma_f32 instead of one v_pk_fma_f32
-#endif
-template <int NW, int TM, int TN>
-constexpr int extra_waves() { return (NW == 8 && TM == 2 && TN == 2) ? VASR_PW_XWAVES : 0; }
-
 template <int NW, int TM, int TN, bool MASK, bool RES, bool DUAL, int ARITH>
-__global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_waves<NW, TM, TN>() ? 1 : 2)) void pw_gemm_split_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
+__global__ __launch_bounds__(64 * NW, 2) void pw_gemm_split_kernel(PwArgs a, int blocks_m, int tiles_t, int n_blocks) {
   using G = Geom<NW, TM, TN, ARITH>;
-  constexpr int XW = extra_waves<NW, TM, TN>();
   constexpr int BM = G::BM, BN = G::BN, NT = G::NT, PPT = G::PPT, PL = G::PL, PLW = G::PLW;
   extern __shared__ __attribute__((aligned(16))) uint4 Bs[];   // [2][PL][STEPS][2][BN]
   auto bs = [&](int buf, int plane, int s, int kb, int n) -> uint4& {
@@ -167,9 +147,6 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef VASR_PW_PRIO
-  if (VASR_PW_PRIO == 2 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   const int wm = wave * 32 * TM;
   const int kh = lane >> 5, l31 = lane & 31;
   const int len = MASK ? a.lens[b] : 0;
@@ -203,13 +180,7 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
   // quarter per k-step, out of registers that were requested during chunk c - 1: an HBM round trip has a whole chunk
   // (~5 us) to complete, and the conversion's VALU work is spread under the MFMAs instead of sitting behind the last
   // one (measured on the one-chunk-ahead form: staging cost 7.5 of 42 us of a 512-channel layer's main loop).
-#ifndef VASR_PW_PAIRS
-#define VASR_PW_PAIRS 1
-#endif
-#ifndef VASR_PW_CVT_AT
-#define VASR_PW_CVT_AT 0   // n-tile of a k-step after which the step's share of the conversion is placed
-#endif
-  constexpr bool PAIRS = VASR_PW_PAIRS && PPT % 2 == 0;
+  constexpr bool PAIRS = PPT % 2 == 0;
   auto patch_of = [&](int p, int& n, int& g) {
     if constexpr (PAIRS) {
       const int pi = tid + (p >> 1) * NT;
@@ -223,11 +194,10 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
   };
   // requests chunk k0 (clamped to the last chunk: past the end the last chunk is simply requested again, so that the
   // number of loads in flight is the same on every path -- s_waitcnt vmcnt counts, it does not name)
-#ifndef VASR_PW_STAGE_SETS
-#define VASR_PW_STAGE_SETS 2   // 2 = rows requested two chunks ahead and converted a quarter per k-step; 1 = requested at the
-#endif                         // start of the previous chunk and converted during its last k-step (16 registers less)
-  constexpr int SSETS = VASR_PW_STAGE_SETS;
-  float rr[SSETS][PPT][8];   // stage register sets: one being converted, one being filled (indexed by compile-time constants only)
+  // two stage register sets: rows are requested two chunks ahead and converted a quarter per k-step (one set -- requested at the
+  // start of the previous chunk, converted during its last k-step -- saved 16 registers and measured slower: DESIGN_HISTORY.md)
+  constexpr int SSETS = 2;
+  float rr[SSETS][PPT][8];   // one set being converted, one being filled (indexed by compile-time constants only)
   auto gload = [&](int k0, auto set_tag) {
     auto& r = rr[decltype(set_tag)::value % SSETS];
     k0 = k0 < a.K - BKC ? k0 : a.K - BKC;
@@ -300,12 +270,8 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
   };
 
   // weights: the next k-step's fragments are in flight while the current ones are multiplied
-#ifndef VASR_PW_WSETS
-#define VASR_PW_WSETS 2   // weight fragment sets in rotation: 2 = one k-step ahead, 4 = three k-steps ahead (STEPS % sets == 0)
-#endif
-  constexpr int WSETS = PL == 2 && TM * TN >= 8 ? VASR_PW_WSETS : 2;   // (3 planes / the small tiles: no registers or no need)
-  static_assert(STEPS % WSETS == 0 || WSETS == 2, "weight sets must divide the k-steps of a chunk");
-  uint4 aw[WSETS][TM][PL];            // aw[s % WSETS] holds the fragments of global k-step s
+  // two fragment sets in rotation: `af` is multiplied while `an` is filled (four sets, three k-steps ahead, measured the same)
+  uint4 aw[2][TM][PL];
   uint4 (&af)[TM][PL] = aw[0];
   uint4 (&an)[TM][PL] = aw[1];
   auto aload = [&](int s, uint4 (&dst)[TM][PL]) {
@@ -329,35 +295,6 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
   // (A separate tail for the odd chunk was tried first: a second conditional copy of the chunk body next to the
   // final-pair block makes the register allocator spill ~160 registers around the merge of the 128 accumulators.)
   const int odd = nchunks & 1;
-  if constexpr (XW > 0) {
-    if (wave >= NW) {
-      v2f fa[8], fx[8], fw[4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { fa[j] = v2f{0.f, 0.f}; fx[j] = v2f{(float)(tid + j), 1e-3f * lane}; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) fw[k] = v2f{1e-3f * (k + 1), 1e-4f * tid};
-      __syncthreads();
-      for (int c = 0; c < nchunks + (nchunks ? odd : 0); ++c) {
-        for (int it = 0; it < VASR_PW_XFILL / 8; ++it) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (VASR_PW_XPLAIN) {
-              asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fa[j].x) : "v"(fw[j & 3].x), "v"(fx[j].x));
-              asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fa[j].y) : "v"(fw[j & 3].y), "v"(fx[j].y));
-            } else {
-              asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(fa[j]) : "v"(fw[j & 3]), "v"(fx[j]));
-            }
-          }
-        }
-        __syncthreads();
-      }
-      float fsum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fsum += fa[j].x + fa[j].y;
-      if (fsum == 12345.678f) a.y[0] = fsum;
-      return;
-    }
-  }
   unsigned amv[8], amv2[8];
   if (nchunks) {
     if constexpr (ARITH == kF16x2) {
@@ -366,11 +303,6 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
     }
     gload(0, S0{});
     aload(0, af);
-    if constexpr (WSETS > 2) {
-      // chunk "-1" (odd counts) starts at global step -STEPS: its steps clamp to fragment 0, which is what aw[*] then holds
-#pragma unroll
-      for (int w = 1; w < WSETS - 1; ++w) aload(odd ? 0 : w, aw[w]);
-    }
     if constexpr (ARITH == kF16x2) {
       // every wavefront reduces the producers' per-wavefront maxima of its utterance itself (a few KB from L2, no barrier);
       // a tile without chunks multiplies nothing and needs no scale
@@ -394,32 +326,11 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
         sstore_half(0, 0, S0{}, p, 0);
         sstore_half(0, 0, S0{}, p, 1);
       }
-      if constexpr (SSETS == 2) gload(BKC, S0{});   // chunk 1: converted during chunk 0
-    }
-  }
-  // Dev experiment (VASR_PW3_TILE=6 VASR_PW_PHASE=ticks): two 4-wavefront workgroups share a compute unit (the hardware's
-  // TG_ID tells them apart: tools/probes/place_probe.hip -- blockIdx i and i + 256 land on one unit, TG_ID 0 and 1); the
-  // second one holds back for `phase_delay` ticks of the 100 MHz clock so that its store-only epilogue runs under the
-  // other's MFMAs and vice versa.  Measured null: a delay of 2-6 us neither costs nor gains anything,
-  // i.e. one wavefront per SIMD runs its latency-bound stream no faster when it has the matrix pipe to itself.
-  if (NW == 4 && a.phase_delay > 0 && wave == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if ((hw >> 16) & 1u) {
-      const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-      while (__builtin_amdgcn_s_memrealtime() - t_start < (uint64_t)a.phase_delay) __builtin_amdgcn_s_sleep(16);
+      gload(BKC, S0{});   // chunk 1: converted during chunk 0
     }
   }
   __syncthreads();
 
-#ifndef VASR_PW_FILLER
-#define VASR_PW_FILLER 0
-#endif
-#if VASR_PW_FILLER
-  float fill[8], fill_a = 1.0f + 1e-7f * tid, fill_b = 1e-9f * lane;
-#pragma unroll
-  for (int f = 0; f < 8; ++f) fill[f] = (float)(tid + f);
-#endif
   // One K chunk c.  `cur` holds the rows of chunk c + 1 (requested one chunk ago), `nxt` receives those of chunk c + 2.
   // LAST = false: request, convert a share of `cur` per k-step into the idle LDS buffer -- unconditionally, no branch
   // anywhere in this body (with one the compiler merges the paths' load counters and waits for everything, vmcnt(0),
@@ -430,55 +341,28 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
     const int cn = c + 1;
     // activation fragments: the n-tile being multiplied and the next one being read; the rotation runs across the
     // k-steps of the chunk, so that a step's first fragments are already in flight when the step starts
-#ifndef VASR_PW_BDEPTH
-#define VASR_PW_BDEPTH 1   // n-tiles a B fragment is requested ahead of its MFMAs (2: three fragment sets, reads pinned per n-tile)
-#endif
-    constexpr int BD = (VASR_PW_BDEPTH == 2 && PL == 2 && TN == 4) ? 2 : 1;
-    uint4 bf[BD + 1][PL];
+    uint4 bf[2][PL];
 #pragma unroll
     for (int p = 0; p < PL; ++p) bf[0][p] = bs(c & 1, p, 0, kh, l31);
-    if constexpr (BD == 2) {
-#pragma unroll
-      for (int p = 0; p < PL; ++p) bf[1][p] = bs(c & 1, p, 0, kh, 32 + l31);
-    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if constexpr (WSETS == 2) {
-        if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + 1, an);
-      } else {
-        if (!(VASR_ABLATE & 1)) aload(c * STEPS + s + WSETS - 1, aw[(s + WSETS - 1) % WSETS]);
-      }
-      if (!LAST && s == 0 && !(VASR_ABLATE & 4)) gload((c + SSETS) * BKC, nxt);   // one set: `nxt` and `cur` are the same registers
+      aload(c * STEPS + s + 1, an);
+      if (!LAST && s == 0) gload((c + SSETS) * BKC, nxt);
       // Pins the loads at the top of the step.  Left alone, the scheduler sinks them towards their first use to save
       // registers: the weight prefetch then runs ~8 MFMAs ahead instead of a whole step.
       __builtin_amdgcn_sched_barrier(0);
-      uint4 (&cw)[TM][PL] = aw[WSETS == 2 ? 0 : s % WSETS];   // this k-step's weight fragments
+      uint4 (&cw)[TM][PL] = af;   // this k-step's weight fragments
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int g = s * TN + j;
-        const int cur_f = BD == 2 ? g % 3 : (g & 1), nxt_f = BD == 2 ? (g + 2) % 3 : (cur_f ^ 1);
-        if constexpr (BD == 2) {
-          if (g + 2 < STEPS * TN) {
+        const int cur_f = g & 1, nxt_f = cur_f ^ 1;
+        if (j + 1 < TN) {
 #pragma unroll
-            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, (g + 2) / TN, kh, ((g + 2) % TN) * 32 + l31);
-          }
-          __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads to two MFMAs before their use)
-        } else if (!(VASR_ABLATE & 2)) {
-          if (j + 1 < TN) {
+          for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
+        } else if (s + 1 < STEPS) {
 #pragma unroll
-            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s, kh, (j + 1) * 32 + l31);
-          } else if (s + 1 < STEPS) {
-#pragma unroll
-            for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s + 1, kh, l31);
-          }
-        } else {
-#pragma unroll
-          for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bf[cur_f][p];
+          for (int p = 0; p < PL; ++p) bf[nxt_f][p] = bs(c & 1, p, s + 1, kh, l31);
         }
-#ifndef VASR_PW_PRIO
-#define VASR_PW_PRIO 0   // 1: s_setprio 1 around every n-tile's MFMA cluster; 2: static s_setprio 1 for wavefronts 4-7 (dev experiments)
-#endif
-        if (VASR_PW_PRIO == 1) __builtin_amdgcn_s_setprio(1);
         // cross terms, smallest first; the m-tiles alternate so that consecutive MFMAs never chain on one accumulator
         if constexpr (ARITH == kBf16x3) {
 #pragma unroll
@@ -494,35 +378,20 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][1], acc[i][j]);   // hi  * mid (lo)
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = mma<ARITH>(cw[i][0], bf[cur_f][0], acc[i][j]);   // hi  * hi
-        if (VASR_PW_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-#if VASR_PW_FILLER
-        // dev-only experiment (dw -> pw fusion budget): VASR_PW_FILLER independent v_fma_f32 per MFMA of this n-tile group,
-        // the VALU work a fused depthwise would have to co-issue (8.5 per MFMA at K = 51, 12.5 at K = 75 for kF16x2)
-#pragma unroll
-        for (int f = 0; f < VASR_PW_FILLER * TM * (ARITH == kBf16x3 ? 6 : 3); ++f)
-          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fill[f & 7]) : "v"(fill_a), "v"(fill_b));
-#endif
         // this k-step's share of the next chunk's conversion, after the step's first n-tile: the scheduler spreads
         // it under the MFMAs that follow
-        if (!LAST && !(VASR_ABLATE & 4) && j == (VASR_PW_CVT_AT < TN ? VASR_PW_CVT_AT : TN - 1)) {
-          // two sets: a share per k-step; one set: everything in the last k-step (the rows were requested in the first)
-          const int h0 = SSETS == 2 ? s * HALVES / STEPS : (s == STEPS - 1 ? 0 : HALVES);
-          const int h1 = SSETS == 2 ? (s + 1) * HALVES / STEPS : HALVES;
+        if (!LAST && j == 0) {
+          const int h0 = s * HALVES / STEPS, h1 = (s + 1) * HALVES / STEPS;
 #pragma unroll
           for (int hv = h0; hv < h1; ++hv) sstore_half(cn & 1, cn * BKC, cur, hv >> 1, hv & 1);
-#ifdef VASR_PW_CVT_FENCE
-          __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       }
-      if constexpr (WSETS == 2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
-      }
+        for (int p = 0; p < PL; ++p) af[i][p] = an[i][p];
     }
-    if (!(VASR_ABLATE & 8)) __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
+    __syncthreads();   // after the last chunk: the epilogue reuses the LDS buffers
   };
   {
     int c = -odd;
@@ -536,21 +405,7 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
     }
   }
 
-#if VASR_PW_FILLER
-  {
-    float fsum = 0.f;
-#pragma unroll
-    for (int f = 0; f < 8; ++f) fsum += fill[f];
-    if (fsum == 12345.678f) acc[0][0][0] += fsum;   // keeps the filler registers alive
-  }
-#endif
   // ---- epilogue (as encoder_pw.hip): BN affine (+ residual) + ReLU, 128-byte row segments per half-wave ----
-  if (a.relu & 2) return;  // debug: skip the epilogue (tools/kscan.py ablation)
-  if (a.relu & 4) {        // debug: the second workgroup of a compute unit skips it (is the epilogue bandwidth- or latency-bound?)
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if ((hw >> 16) & 1u) return;
-  }
   // max |y| over the utterance's VALID output frames, for the split of the next kF16x2 consumer of y
   const int ylen = a.amax_y.p ? (a.lens_y ? a.lens_y[b] : a.frames) : 0;
   unsigned ymax = 0;
@@ -572,27 +427,21 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
     // retires in order: a load issued between two passes made its consumer wait -- vmcnt(0) -- for every store of the
     // passes before it, i.e. the 4 TM passes ran as 4 TM store round trips in series (round 2's "12 us store-bound
     // epilogue" of a 512-channel layer).
-#ifndef VASR_PW_EPI_PRELOAD
-#define VASR_PW_EPI_PRELOAD 1
-#endif
     v4f scv[TM][4], shv[TM][4];
-    if (VASR_PW_EPI_PRELOAD) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          scv[i][q] = *reinterpret_cast<const v4f*>(a.scale + m0 + wm + i * 32 + 8 * q + 4 * kh);
-          shv[i][q] = *reinterpret_cast<const v4f*>(a.shift + m0 + wm + i * 32 + 8 * q + 4 * kh);
-        }
-    }
+      for (int q = 0; q < 4; ++q) {
+        scv[i][q] = *reinterpret_cast<const v4f*>(a.scale + m0 + wm + i * 32 + 8 * q + 4 * kh);
+        shv[i][q] = *reinterpret_cast<const v4f*>(a.shift + m0 + wm + i * 32 + 8 * q + 4 * kh);
+      }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float* buf = stage + ((i * 4 + q) & 1) * (8 * BN);
         const int mq = m0 + wm + i * 32 + 8 * q;
-        const v4f sc = VASR_PW_EPI_PRELOAD ? scv[i][q] : *reinterpret_cast<const v4f*>(a.scale + mq + 4 * kh);
-        const v4f sh = VASR_PW_EPI_PRELOAD ? shv[i][q] : *reinterpret_cast<const v4f*>(a.shift + mq + 4 * kh);
+        const v4f sc = scv[i][q], sh = shv[i][q];
         wave_fence();   // LDS executes one wavefront's accesses in order: pass p+2's writes follow pass p's reads
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
@@ -607,9 +456,6 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
         // maximum with a uniform floor and the maxima are tracked unconditionally (ylen = 0 without a table).  With a
         // uniform BRANCH per piece (relu / table / store kind) every piece was its own basic block -- LDS read, wait,
         // arithmetic, store, branch -- and the pass paid one LDS round trip per piece in series.
-#ifndef VASR_PW_NT
-#define VASR_PW_NT 0   // dev: honour PwArgs::nt_store (measured: no gain -- off)
-#endif
         v4f pv[F4], rv[F4];
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
@@ -625,8 +471,7 @@ __global__ __launch_bounds__((64 * (NW + extra_waves<NW, TM, TN>())), (extra_wav
           if (RES) v += rv[k];
           v = __builtin_elementwise_max(v, v4f{relu_floor, relu_floor, relu_floor, relu_floor});
           v4f* dstp = reinterpret_cast<v4f*>(a.y + ((int64_t)b * a.m_store + m) * a.ldy + t);
-          if (VASR_PW_NT && a.nt_store) __builtin_nontemporal_store(v, dstp);   // (uniform) stream_stores
-          else *dstp = v;
+          *dstp = v;   // (non-temporal stores for outputs beyond the Infinity Cache: measured, no gain)
 #pragma unroll
           for (int e = 0; e < 4; ++e) track(v[e], t + e);
         }
@@ -678,7 +523,7 @@ int launch_k(const PwArgs& a, hipStream_t st, int* amax_n) {
   static std::atomic<uint64_t> lds_opted{0};   // per device (dyn_lds_opt_in)
   const hipError_t attr = dyn_lds_opt_in(reinterpret_cast<const void*>(kern), (int)G::LDS, lds_opted);
   if (attr != hipSuccess) return (int)attr;
-  VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT + 64 * extra_waves<NW, TM, TN>()), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
+  VASR_LAUNCH(kern, dim3(n_blocks), dim3(G::NT), G::LDS, st, a, blocks_m, tiles_t, n_blocks);
   return 0;
 }
 
@@ -720,14 +565,12 @@ bool pointwise_split_supported(int M, int K, int K1) {
 int pointwise_amax_slots(int M, int64_t ld) { return (int)((int64_t)(M / 64) * ((ld + 31) / 32) * 2); }
 
 int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* amax_n) {
-  static const int force = dev_env("VASR_PW3_TILE") ? atoi(dev_env("VASR_PW3_TILE")) : 0;   // 1..5 pins a tile shape
-  static const bool no_skip = dev_env("VASR_NO_TILE_SKIP") && atoi(dev_env("VASR_NO_TILE_SKIP")) != 0;   // A/B switch
-  PwArgs a = args;
-  if (no_skip) a.zero_from = nullptr;
+  const int force = dev_switches().pw3_tile;   // devtools build: 1..5 pins a tile shape (tests of the alternate tiles)
+  const PwArgs& a = args;
   // the largest tile that divides M and still gives (almost) every one of the 256 CUs a workgroup:
   // 512x128, 256x128, 128x64, 64x32 (the CTC head, 29 or 91 rows padded to 128, runs 128x64 tiles)
   auto blocks = [&](int bm, int bn) { return (int64_t)(a.M / bm) * ((a.ldx + bn - 1) / bn) * a.batch; };
-  const int rows[10] = {0, 512, 256, 128, 64, 256, 256, 32, 512, 1024};
+  const int rows[6] = {0, 512, 256, 128, 64, 256};
   int tile = 4;
   if (a.M % 512 == 0 && blocks(512, 128) >= 192) tile = 1;
   else if (a.M % 256 == 0 && blocks(256, 128) >= 192) tile = 2;
@@ -751,32 +594,20 @@ int launch_pointwise_split(const PwArgs& args, int arith, hipStream_t st, int* a
     const int64_t n1 = blocks(512, 128), rounds = (n1 + cus - 1) / cus;
     if ((double)n1 < 0.85 * (double)(rounds * cus)) tile = 5;
   }
-  if (force >= 1 && force <= 9 && a.M % rows[force] == 0) tile = force;
+  if (force >= 1 && force <= 5 && a.M % rows[force] == 0) tile = force;
   // Small batches (the 64 x 32 tile's territory: <= 5 utterances of 10 s at 512 channels): the whole K range in ONE trip to
-  // memory instead of K / 64 dependent chunk steps -- encoder_pw_lat.hip, same bits.  VASR_PW_LAT=0 keeps the chunked kernel,
-  // =2 extends the latency kernel to the 128 x 64 tile's batches (dev: A/B runs).
-  static const int lat = dev_env("VASR_PW_LAT") ? atoi(dev_env("VASR_PW_LAT")) : 1;
-  if (arith == kF16x2 && !force && lat > 0 && (tile == 4 || (lat >= 2 && tile == 3)) &&
-      pointwise_latency_supported(a.M, a.K, a.x2 ? a.K1 : 0)) {
+  // memory instead of K / 64 dependent chunk steps -- encoder_pw_lat.hip, same bits.  (Devtools: VASR_PW_LAT=0 keeps the chunked
+  // kernel.)
+  if (arith == kF16x2 && !force && dev_switches().pw_lat > 0 && tile == 4 && pointwise_latency_supported(a.M, a.K, a.x2 ? a.K1 : 0)) {
     const int e = launch_pointwise_latency(a, st, amax_n);
     if (e >= 0) return e;
   }
-  static const int phase_delay = dev_env("VASR_PW_PHASE") ? atoi(dev_env("VASR_PW_PHASE")) : 0;   // 10 ns ticks (dev)
-  a.phase_delay = phase_delay;
+  // (tiles measured and dropped, DESIGN_HISTORY.md section 4: 256 x 128 on four wavefronts with two workgroups per CU, 512 x 64,
+  // 1024 x 64 -- the tile a CTC head folded into the last GEMM would need --, 128 x 32 for the head, 32 x 32 on one wavefront)
   switch (tile) {
     case 1: return launch_t<8, 2, 4>(a, arith, st, amax_n);
     case 2: return launch_t<8, 1, 4>(a, arith, st, amax_n);
     case 5: return launch_t<8, 1, 2>(a, arith, st, amax_n);
-    case 6: return launch_t<4, 2, 4>(a, arith, st, amax_n);   // 256 x 128 on four wavefronts, two workgroups per CU (dev)
-    // (256 x 128 on FOUR wavefronts, two workgroups per CU -- possible with the 64 KB of the two-plane arithmetics -- measured
-    // slower than one 512 x 128 workgroup: 57.5 vs 54.6 us on a 512-channel layer; one wavefront per SIMD and workgroup does
-    // not cover its own waits, and every workgroup converts the whole activation tile again)
-    case 8: return launch_t<8, 2, 2>(a, arith, st, amax_n);   // 512 x 64 (dev: half-filled chips, configs[1])
-#ifdef VASR_DEVTOOLS
-    // (128 x 32 tiles for the CTC head -- four workgroups per CU -- measured 39.9 us against 35.4 for the 128 x 64 tile: not kept)
-    case 9: return launch_t<8, 4, 2>(a, arith, st, amax_n);   // 1024 x 64 (dev, round 5: the tile a CTC head folded into the last GEMM would need)
-#endif
-    case 7: return launch_t<1, 1, 1>(a, arith, st, amax_n);   // 32 x 32 on one wavefront (dev: batch-1 experiment)
     case 3: return launch_t<4, 1, 2>(a, arith, st, amax_n);
     default: return launch_t<2, 1, 1>(a, arith, st, amax_n);
   }

@@ -262,8 +262,7 @@ void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, i
                        frames);
   };
   // fewer 32-frame workgroups than half the chip's compute units: the one-frame-per-wavefront form
-  static const int force = dev_env("VASR_STFT_FPB") ? atoi(dev_env("VASR_STFT_FPB")) : 0;   // 8 | 32 (dev: A/B runs)
-  const bool small = force ? force == 8 : (int64_t)((frames + 31) / 32) * batch < 128;
+  const bool small = (int64_t)((frames + 31) / 32) * batch < 128;
   if (small) go(stft_logmel_kernel<8>, 8);
   else go(stft_logmel_kernel<32>, 32);
 }

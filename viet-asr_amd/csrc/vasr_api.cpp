@@ -119,6 +119,7 @@ struct vasr_handle {
   bool slice_ready = false;
   bool row_independent = false;   // vasr_set_row_independent
   int busy_cus = 0;               // vasr_set_busy_cus
+  DevSwitches sw = dev_switches();   // kernel-selection switches of the devtools build (vasr_internal.h); defaults in the product
   int n_cu = 256;                 // compute units of the device the handle was finalized on (tile-fill decisions)
   hipStream_t slice_stream[kMaxSlices] = {};
   hipEvent_t slice_done[kMaxSlices] = {}, slice_fork{};
@@ -131,6 +132,36 @@ struct vasr_handle {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
 };
+
+#ifdef VASR_DEVTOOLS
+// The devtools build's kernel-selection switches (vasr_internal.h DevSwitches): the environment is read HERE, once per
+// process, and nowhere else; a value outside a switch's documented set aborts instead of silently meaning "default".
+const vasr::DevSwitches& vasr::dev_switches() {
+  static const DevSwitches sw = [] {
+    DevSwitches s;
+    auto num = [](const char* name, int dflt, std::initializer_list<int> allowed) {
+      const char* e = getenv(name);
+      if (!e) return dflt;
+      const int v = atoi(e);
+      for (int a : allowed) if (a == v) return v;
+      fprintf(stderr, "vasr (devtools build): %s=%s is not a documented value -- refusing to guess\n", name, e);
+      abort();
+    };
+    s.pw3_tile = num("VASR_PW3_TILE", 0, {0, 1, 2, 3, 4, 5});
+    s.pw_lat = num("VASR_PW_LAT", 1, {0, 1});
+    s.dw_pair = num("VASR_DW_PAIR", 1, {0, 1}) != 0;
+    s.dw_mfma = num("VASR_DW_MFMA", 1, {0, 1}) != 0;
+    s.dw_upw = num("VASR_DW_UPW", 0, {0, 1, 2, 3, 4, 5, 6, 7, 8});
+    s.fused = num("VASR_FUSED", 1, {0, 1}) != 0;
+    s.fused_min_tiles = getenv("VASR_FUSED_MIN_TILES") ? atoi(getenv("VASR_FUSED_MIN_TILES")) : 0;
+    s.fused_tile = num("VASR_FUSED_TILE", 0, {0, 64, 128});
+    s.fused_residual = num("VASR_NO_FUSED_RESIDUAL", 0, {0, 1}) == 0;
+    s.beam_group = num("VASR_BEAM_GROUP", -1, {-1, 0, 1, 4});
+    return s;
+  }();
+  return sw;
+}
+#endif
 
 struct vasr_lm {
   BeamLm view{};
@@ -376,7 +407,7 @@ int build_encoder(vasr_handle* h) {
       const SubBlock& last = B.subs.back();
       const int k1 = last.pw.cin, k2 = cin;
       const int chunk = d.filters % 512 == 0 ? 128 : (d.filters % 256 == 0 ? 64 : 32);
-      if (d.stride == 1 && k1 % chunk == 0 && k2 % chunk == 0 && !dev_env("VASR_NO_FUSED_RESIDUAL")) {
+      if (d.stride == 1 && k1 % chunk == 0 && k2 % chunk == 0 && h->sw.fused_residual) {
         char w1[160], bn1[160], w2[160], bn2[160];
         const int jl = j - (last.separable ? 3 : 2);
         snprintf(w1, sizeof w1, "encoder.%zu.mconv.%d.conv.weight", i, jl + (last.separable ? 1 : 0));
@@ -504,12 +535,6 @@ struct ProfScope {
 };
 enum { kProfFrontend = 0, kProfDepthwise = 1, kProfPointwise = 2, kProfHead = 3, kProfFused = 4 };
 
-}  // namespace
-bool vasr::stream_stores(size_t out_bytes) {
-  static const long mb = dev_env("VASR_NT_MB") ? atol(dev_env("VASR_NT_MB")) : 0;   // off: measured, no gain in the pipeline
-  return mb > 0 && out_bytes >= (size_t)mb * 1000000u;
-}
-namespace {
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -610,7 +635,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // ---- fused depthwise -> pointwise kernel (encoder_fused.hip): 256-channel sub-blocks in the fp16-split arithmetic, when
       //      there are enough 128-frame tiles to fill the chip (one workgroup per tile, all channels); VASR_FUSED=0 is the
       //      A/B switch ----
-      static const bool fused_on = !(dev_env("VASR_FUSED") && atoi(dev_env("VASR_FUSED")) == 0);
+      const bool fused_on = h->sw.fused;
       // One workgroup per CU (159 KB of LDS), one 128-frame tile each: it pays when the tiles fill whole rounds of the chip
       // (measured, fused vs two kernels: 64 x 10 s = 256 tiles -3.4 % per step, 512 x 30 s = 6144 tiles -4 %; but 32 x 10 s = 128
       // tiles +2.6 %, 64 x 10.3 s = 320 tiles = 1.25 rounds +3 %, 16 x 10 s = 64 tiles +4.6 %).  Smaller batches take the kernel's
@@ -618,8 +643,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // 10 s; measured against two kernels, ms per step: 15x5 B = 12 / 16 / 20 / 24 / 32: -3.8 / -4.8 / -8.3 / -7.7 / -6.7 %, 12x1
       // (BASELINE configs[1]) B = 16 / 20 / 24 / 32: -3.1 / -5.1 / -5.0 / -4.3 %; B = 8: +-0; B = 1-4: +5 ... +9 % (one tile is 14 us
       // of latency against 4 + 7 us for the two kernels spread over the chip); 36-44 utterances (1.1-1.4 rounds): +0.8 ... +1.6 %.
-      static const int fused_min_tiles = dev_env("VASR_FUSED_MIN_TILES") ? atoi(dev_env("VASR_FUSED_MIN_TILES")) : 0;
-      static const int fused_tile = dev_env("VASR_FUSED_TILE") ? atoi(dev_env("VASR_FUSED_TILE")) : 0;
+      const int fused_min_tiles = h->sw.fused_min_tiles, fused_tile = h->sw.fused_tile;
       const int n_cu = h->n_cu;
       // (units a concurrent kernel of the caller's holds -- the overlapped beam search -- take no workgroups: 256 tiles on the
       // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
@@ -648,7 +672,6 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         f.amax_y = free_tab(cur_amax); f.lens_y = lens(S.pw.step + 1);
         if (fuse_res) { f.x2 = blk_in; f.ldx2 = blk_ld; f.lens2 = lens(B.first_step); f.amax_x2 = blk_amax; }
         f.batch = batch; f.kernel = S.dw.kernel;
-        f.nt_store = stream_stores((size_t)batch * WF.cout * cur_ld * 4);
         f.tile_cols = f_cols;
         int e;
         {
@@ -674,7 +697,7 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         // 512-channel layer: 22.8 / 23.7 / 23.8 / 28.1 us at K = 51 / 63 / 75 / 87 x 2 against 25.6 / 28.4 / 31.0 / 35.5 us
         // of packed FMAs; 256 channels, K = 33 / 39: 12.8 / 12.6 against 13.3 / 13.4), else packed FMAs.
         // VASR_DW_MFMA=0 keeps the packed-FMA kernels.
-        static const bool dw_mfma = !(dev_env("VASR_DW_MFMA") && atoi(dev_env("VASR_DW_MFMA")) == 0);
+        const bool dw_mfma = h->sw.dw_mfma;
         int e = -1;
         if (want_amax && dw_mfma && cur_amax.p && S.dw.d_taps)
           e = launch_depthwise_mfma(cur, cur_ld, S.dw.d_taps, S.dw.d_tap_inv, lens(S.dw.step), lens(S.dw.step + 1), cur_amax,
@@ -707,7 +730,6 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
         return fail(VASR_ERR_UNSUPPORTED, "block %zu: residual across a strided block", i);
       a.amax_x = gx_amax;
       a.amax_x2 = fuse ? blk_amax : AmaxTab{};
-      a.nt_store = !(last_block && last_sub) && stream_stores((size_t)batch * W.m_pad * dst_ld * 4);
       // this GEMM's output is masked at lens(S.pw.step + 1) by whatever reads it next
       // (the encoder output's maxima are only wanted by the fused path's CTC head, which reads every column < T')
       if (want_amax && (!(last_block && last_sub) || enc_amax)) {
@@ -1079,8 +1101,7 @@ int vasr_get_gemm_mode(const vasr_handle* h) { return h ? h->gemm_mode : -1; }
 
 int vasr_set_busy_cus(vasr_handle* h, int cus) {
   if (!h || cus < 0) return fail(VASR_ERR_INVALID, "busy compute units must be >= 0");
-  static const bool off = dev_env("VASR_NO_BUSY_CUS") && atoi(dev_env("VASR_NO_BUSY_CUS")) != 0;   // A/B switch
-  h->busy_cus = off ? 0 : cus;
+  h->busy_cus = cus;
   return 0;
 }
 
@@ -1127,7 +1148,8 @@ int vasr_beam_search_rows_f32(const float* d_logp, const int32_t* d_row_frames, 
   if (space_id < -1 || space_id >= num_classes - 1) return fail(VASR_ERR_INVALID, "space_id out of range");
   const size_t need_bytes = vasr_beam_workspace_bytes(batch, frames);
   if (ws_bytes < need_bytes) return fail(VASR_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need_bytes);
-  // < 16 utterances: an utterance on four wavefronts of a compute unit (beam_group.hip, the serving latency); from there on
+  // <= 64 utterances: an utterance on four wavefronts of a compute unit (beam_group.hip: the serving latency, and the shorter
+  // stay in the way of an overlapped acoustic pass); beyond that
   // one wavefront per utterance, four utterances per compute unit (beam_wave.hip).  Same bits either way; VASR_BEAM_GROUP
   // (devtools build: 0 | 1 = never, 4 = always the four-wavefront form; anything else aborts) pins the form for A/B runs.
   const int e = launch_beam_search_group(
@@ -1278,17 +1300,11 @@ int vasr_bench_depthwise_mfma(const float* d_x, const uint32_t* d_taps, const fl
   if (amax_stride < 256 || amax_stride < depthwise_amax_slots(channels, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   AmaxTab ax{d_amax, amax_stride, 0}, ay{d_amax + (size_t)batch * amax_stride, amax_stride, 0};
-  // timing runs (tools/bench_dw.py): VASR_BENCH_KEEP_AMAX=1 reuses the input maxima a previous call left in d_amax
-  static const bool keep = dev_env("VASR_BENCH_KEEP_AMAX") != nullptr;
-  static int kept_n = 0;
-  if (keep && kept_n) ax.n = kept_n;
-  else launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
-  kept_n = ax.n;
+  launch_amax(d_x, ld, channels, (int)frames, d_lens, batch, &ax, st);
   const int e = launch_depthwise_mfma(d_x, ld, d_taps, d_tap_inv, d_lens, d_lens, ax, batch, channels, kernel, dilation,
                                       d_y, ld, &ay, st);
   if (e > 0) return fail(VASR_ERR_HIP, "depthwise (MFMA): %s", hipGetErrorString((hipError_t)e));
   if (e < 0) return fail(VASR_ERR_UNSUPPORTED, "no Toeplitz instantiation for kernel %d dilation %d", kernel, dilation);
-  if (keep) return check_launch("bench_depthwise_mfma");
   if (ay.n < amax_stride)
     HIP_TRY(hipMemset2DAsync(d_amax + (size_t)batch * amax_stride + ay.n, (size_t)amax_stride * 4, 0,
                              (size_t)(amax_stride - ay.n) * 4, batch, st));
@@ -1312,7 +1328,7 @@ int vasr_bench_pointwise(const float* d_x, const float* d_wt, const float* d_sca
   PwArgs a{};
   a.wt = d_wt; a.x = d_x; a.lens = nullptr; a.scale = d_scale; a.shift = d_shift; a.res = nullptr; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.ldr = 0; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
   launch_pointwise(a, static_cast<hipStream_t>(stream));
   return check_launch("bench_pointwise");
 }
@@ -1346,21 +1362,16 @@ int vasr_bench_pointwise_f16x2(const float* d_x, const uint16_t* d_w16, float w_
   if (amax_stride < 256 || amax_stride < pointwise_amax_slots(cout, ld)) return fail(VASR_ERR_INVALID, "maxima table too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   AmaxTab ax{d_amax, amax_stride, 0};
-  static const bool keep = dev_env("VASR_BENCH_KEEP_AMAX") != nullptr;   // timing runs: see vasr_bench_depthwise_mfma
-  static int kept_n = 0;
-  if (keep && kept_n) ax.n = kept_n;
-  else launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, &ax, st);
-  kept_n = ax.n;
+  launch_amax(d_x, ld, cin, (int)frames, nullptr, batch, &ax, st);
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w16); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
   a.amax_x = ax; a.w_inv_scale = w_inv_scale;
   a.amax_y = AmaxTab{d_amax + (size_t)batch * amax_stride, amax_stride, 0};   // second table: maxima of y
   int n_y = 0;
   const int e = launch_pointwise_split(a, 2, st, &n_y);
   if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
-  if (keep) return check_launch("bench_pointwise_f16x2");
   // slots past the ones the launch used read as zero for the caller
   if (n_y < amax_stride)
     HIP_TRY(hipMemset2DAsync(d_amax + (size_t)batch * amax_stride + n_y, (size_t)amax_stride * 4, 0,
@@ -1378,8 +1389,8 @@ int vasr_bench_pointwise_bf16x3(const float* d_x, const uint16_t* d_w3, const fl
   PwArgs a{};
   a.wt = reinterpret_cast<const float*>(d_w3); a.x = d_x; a.scale = d_scale; a.shift = d_shift; a.y = d_y;
   a.M = cout; a.K = cin; a.batch = batch; a.ldx = ld; a.ldy = ld; a.frames = (int)frames;
-  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1 | (dev_env("VASR_DEBUG_NO_EPILOGUE") ? (atoi(dev_env("VASR_DEBUG_NO_EPILOGUE")) == 2 ? 4 : 2) : 0);
-  const int e = launch_pointwise_split(a, dev_env("VASR_BENCH_BF16X2") ? 1 : 0, static_cast<hipStream_t>(stream));
+  a.store_cols = (int)ld; a.m_store = cout; a.relu = 1;
+  const int e = launch_pointwise_split(a, 0, static_cast<hipStream_t>(stream));
   if (e) return fail(VASR_ERR_HIP, "pointwise GEMM: %s", hipGetErrorString((hipError_t)e));
   return check_launch("bench_pointwise_bf16x3");
 }

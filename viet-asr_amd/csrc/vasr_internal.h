@@ -8,13 +8,30 @@
 
 namespace vasr {
 
-// Kernel-selection / A-B switches (VASR_DW_*, VASR_PW3_TILE, VASR_FUSED*, VASR_NO_*, ...) are read from the environment by
-// the DEVTOOLS build only (libvasr_hip_dev.so: tests of the alternate kernel paths, tools/); the product library never
-// looks at them.  VASR_GEMM and VASR_SLICES -- documented modes with API equivalents -- stay plain getenv in vasr_api.cpp.
+// Kernel-SELECTION switches: every product path that the default rules do not reach at a given shape (the packed-FMA
+// depthwise, the two-kernel form of a fused sub-block, a pinned GEMM tile, the one-wavefront beam search ...) can be forced,
+// so that the tests can hold it to the same goldens.  They exist in the DEVTOOLS build only (libvasr_hip_dev.so), are read
+// from the environment ONCE per process (dev_switches(), vasr_api.cpp) and copied into every handle at vasr_create(); in the
+// product library the struct is a compile-time constant of defaults and nothing looks at the environment.  (Rounds 1-5 also
+// kept timing ablations and one-off experiments behind ~40 more switches and macros inside the kernels; their results are in
+// DESIGN_HISTORY.md, their code is in the history -- `git show a54b0b9:viet-asr_amd/csrc`.)  VASR_GEMM and VASR_SLICES --
+// documented modes with API equivalents -- are plain getenv at vasr_create().
+struct DevSwitches {
+  int pw3_tile = 0;             // VASR_PW3_TILE=1..5: pins the split GEMM's tile (512x128, 256x128, 128x64, 64x32, 256x64)
+  int pw_lat = 1;               // VASR_PW_LAT=0: small batches stay on the chunked GEMM instead of the latency kernel
+  bool dw_pair = true;          // VASR_DW_PAIR=0: the generic depthwise kernel instead of the pair kernel
+  bool dw_mfma = true;          // VASR_DW_MFMA=0: packed-FMA depthwise kernels instead of the Toeplitz form
+  int dw_upw = 0;               // VASR_DW_UPW=1..8: utterances one wavefront of the Toeplitz kernel walks
+  bool fused = true;            // VASR_FUSED=0: depthwise and GEMM of a 256-channel sub-block as two kernels
+  int fused_min_tiles = 0;      // VASR_FUSED_MIN_TILES=n: fuse from n tiles on, whatever the round-filling rule says
+  int fused_tile = 0;           // VASR_FUSED_TILE=64|128: pins the fused kernel's tile width
+  bool fused_residual = true;   // VASR_NO_FUSED_RESIDUAL=1: a block's residual branch as its own GEMM, not as a second K range
+  int beam_group = -1;          // VASR_BEAM_GROUP=0|1: always one wavefront per utterance, 4: always four
+};
 #ifdef VASR_DEVTOOLS
-inline const char* dev_env(const char* name) { return getenv(name); }
+const DevSwitches& dev_switches();
 #else
-inline const char* dev_env(const char*) { return nullptr; }
+inline const DevSwitches& dev_switches() { static constexpr DevSwitches k{}; return k; }
 #endif
 
 // Kernel-duration probe for vasr_profile_begin/end.  When armed, the next VASR_LAUNCH goes out through
@@ -68,12 +85,6 @@ inline hipError_t dyn_lds_opt_in(const void* kernel, int bytes, std::atomic<uint
 constexpr int kTimeTile = 128;
 static inline int64_t pad_frames(int64_t t) { return (t + kTimeTile - 1) / kTimeTile * kTimeTile; }
 
-// Non-temporal ("nt") stores for a layer's output: right when the tensor cannot stay in the 256 MiB Infinity Cache anyway.
-// Measured (tools/probes/hbm_probe.py, read + write of the same size): at 403 MB -- one 512-channel layer of 512 x 30 s --
-// a copy runs at 5.9 TB/s with plain stores and 6.9-7.3 TB/s with nt stores; at 134 MB (64 x 10 s) both run at 6.5-6.7 TB/s
-// and the NEXT kernel finds a plainly stored tensor in the cache (round 1: nt stores there cost +0.16 / +0.26 ms per step).
-// VASR_NT_MB overrides the threshold (0 = never).
-bool stream_stores(size_t out_bytes);
 
 // Per-utterance maxima for the fp16-split arithmetic (encoder_pw_split.hip kF16x2, encoder_dw_mfma.hip): every kernel
 // that produces a tensor such a kernel will read publishes max |y| over each utterance's valid frames, one plain store
@@ -163,12 +174,10 @@ struct PwArgs {
   // Ragged batches only -- full-length clips never hit it.  Honoured by the split-bf16 kernel.
   const int32_t* zero_from;
   int32_t busy_cus;       // compute units held by a concurrent kernel of the caller's (vasr_set_busy_cus); tile choice only
-  int32_t phase_delay;    // 4-wavefront tiles: ticks (10 ns) the second workgroup of a compute unit holds back (0 = off)
   // kF16x2 only: maxima tables of x / x2 (inputs) and 1 / (weight scale) of the fp16 pack
   AmaxTab amax_x;
   AmaxTab amax_x2;
   float w_inv_scale;
-  int32_t nt_store;       // output stored with non-temporal hints (stream_stores)
   // any split arithmetic: publish max |y| over columns < lens_y[b] (nullptr: < frames) into amax_y (p == nullptr: off);
   // launch_pointwise_split reports the slots it used through its amax_n argument
   AmaxTab amax_y;
@@ -206,7 +215,6 @@ struct FusedLaunch {
   AmaxTab amax_y; const int32_t* lens_y;
   const float* x2; int64_t ldx2; const int32_t* lens2; AmaxTab amax_x2;   // residual source (nullptr = none)
   int32_t batch, kernel;
-  int32_t nt_store;                            // output stored with non-temporal hints (stream_stores)
   int32_t tile_cols;                           // frames per workgroup: 128 (0 = default) or 64
 };
 bool fused_dwpw_supported(int channels, int cout, int kernel, int stride, int dilation);

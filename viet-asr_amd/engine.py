@@ -148,9 +148,9 @@ class QuartzNetCTC:
     def forward_beam(self, wav, length, beam_decoder, beam_width, frames=None, overlap=True):
         """Acoustic pass + beam search (+ LM) of one device-resident batch: the batched form of infer.py:146-160.
 
-        overlap=True runs the search on a side stream: it occupies one wavefront per utterance, four utterances per compute
-        unit (16 of the 256 CUs at B = 64) for about as long as the acoustic pass of the NEXT batch takes on the rest of the
-        chip, so queued behind the log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
+        overlap=True runs the search on a side stream: it occupies a compute unit per utterance up to 64 utterances (four
+        wavefronts each, 1.3 ms at B = 64 x 501 frames, beam 128), a compute unit per four utterances beyond, so queued behind the
+        log-probs of batch k it runs under the kernels of batch k + 1 instead of after them.  Returns dict(ids, id_len,
         score, done): ``done`` is an event on the side stream (None when overlap is off); wait for it -- or
         synchronise the device -- before reading the results from another stream."""
         # a search of the previous batch that is still queued or running holds a compute unit per four utterances while this
