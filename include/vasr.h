@@ -35,7 +35,8 @@ extern "C" {
  * a signature or struct layout changes (4: vasr_profile_end reports five kernel classes with flops / bytes per class --
  * a caller built against the four-class form would be written past its arrays; 5: vasr_lm_create takes 16-byte table
  * entries with power-of-two capacities; 6: vasr_lm_create takes the character trie of pyctcdecode's unigram set, the
- * vocabulary entries carry a set-membership flag, vasr_resample_f32 emits ceil(len * ratio) samples). */
+ * vocabulary entries carry a set-membership flag, vasr_resample_f32 emits ceil(len * ratio) samples,
+ * vasr_frontend_desc ends in log_guard_clamp and knows normalize = 2). */
 #define VASR_ABI_VERSION 6
 
 typedef struct vasr_handle vasr_handle;
@@ -63,8 +64,8 @@ typedef struct {
 } vasr_block_desc;
 
 /* Front end = FilterbankFeatures.__init__ (parts/features.py:113-236) with the knobs the
- * path uses: dither 0, pad_to 0 (infer.py:89-90), stft_conv false, mag_power 2, log guard
- * "add", per_feature normalisation, frame_splicing 1. */
+ * path uses: dither 0, pad_to 0 (infer.py:89-90), stft_conv false, mag_power 2, frame_splicing 1; log guard "add" or
+ * "clamp" (:269-274), normalisation per_feature, all_features or none (:17-46). */
 typedef struct {
   int32_t sample_rate;  /* 16000 */
   int32_t n_fft;        /* 512 (only 512 is implemented) */
@@ -73,9 +74,12 @@ typedef struct {
   int32_t n_mels;       /* 64 (only 64 is implemented) */
   float preemph;        /* 0.97; <0 disables */
   float log_guard;      /* 2^-24 */
-  int32_t normalize;    /* 1 = per_feature, 0 = none */
+  int32_t normalize;    /* 1 = per_feature (per utterance and mel bin), 2 = all_features (one mean / std per utterance over
+                           every bin and frame, features.py:31-39), 0 = none */
   const float* h_window;     /* [win_length] or NULL -> symmetric hann */
   const float* h_filterbank; /* [n_mels][n_fft/2+1] row-major, REQUIRED */
+  int32_t log_guard_clamp;   /* 0 = log(x + log_guard) (log_zero_guard_type "add", the shipped configs), 1 = log(max(x,
+                                log_guard)) ("clamp", features.py:272-273).  (ABI 6: appended) */
 } vasr_frontend_desc;
 
 typedef struct {

@@ -100,6 +100,17 @@ def normalize_batch_per_feature(x, seq_len):
     return (x - x_mean.unsqueeze(2)) / x_std.unsqueeze(2)
 
 
+def normalize_batch_all_features(x, seq_len):
+    """parts/features.py:31-39 -- per utterance: mean / unbiased std over every bin and every frame < seq_len[b]."""
+    x_mean = torch.zeros(seq_len.shape, dtype=x.dtype)
+    x_std = torch.zeros(seq_len.shape, dtype=x.dtype)
+    for i in range(x.shape[0]):
+        x_mean[i] = x[i, :, : seq_len[i].item()].mean()
+        x_std[i] = x[i, :, : seq_len[i].item()].std()
+    x_std += CONSTANT
+    return (x - x_mean.view(-1, 1, 1)) / x_std.view(-1, 1, 1)
+
+
 def torch_stft_magnitude(x, n_fft, hop, win_length, window="hann"):
     """``torch_stft.STFT(n_fft, hop, win_length, window).transform(x)[0]`` -- PARITY UNPINNED: the package is
     third-party (pseeth/torch-stft, requirements.txt, unpinned), absent from /root/reference and from this image;
@@ -124,7 +135,7 @@ def torch_stft_magnitude(x, n_fft, hop, win_length, window="hann"):
 
 def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_stride=160, n_fft=512,
                     preemph=0.97, nfilt=64, lowfreq=0, highfreq=None, log_zero_guard_value=2 ** -24,
-                    normalize="per_feature", pad_value=0.0, fb=None, stft_conv=False):
+                    normalize="per_feature", pad_value=0.0, fb=None, stft_conv=False, log_zero_guard_type="add"):
     """FilterbankFeatures.forward (parts/features.py:245-301) with dither=0, pad_to=0
     (infer.py:89-90; quirk Q1: the featurizer is never put in eval mode, so no pad-to-16),
     mag_power=2, log guard "add", frame_splicing=1.  stft_conv=True (unpinned, see
@@ -150,9 +161,16 @@ def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_st
         fb = slaney_mel_filterbank(sample_rate, n_fft, nfilt, lowfreq, highfreq or sample_rate / 2)
     fb = torch.as_tensor(fb, dtype=torch.float32).unsqueeze(0)
     m = torch.matmul(fb, p)                                                    # :266
-    m = torch.log(m + log_zero_guard_value)                                    # :269-271
+    if log_zero_guard_type == "add":                                           # :269-271
+        m = torch.log(m + log_zero_guard_value)
+    elif log_zero_guard_type == "clamp":                                       # :272-273
+        m = torch.log(torch.clamp(m, min=log_zero_guard_value))
+    else:
+        raise ValueError("log_zero_guard_type was not understood")             # :274-275
     if normalize == "per_feature":                                             # :282-283
         m = normalize_batch_per_feature(m, seq_len)
+    elif normalize == "all_features":
+        m = normalize_batch_all_features(m, seq_len)
     max_len = m.size(-1)                                                       # :287-291
     mask = torch.arange(max_len).expand(m.size(0), max_len) >= seq_len.unsqueeze(1)
     m = m.masked_fill(mask.unsqueeze(1), pad_value)

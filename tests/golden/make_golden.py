@@ -127,7 +127,7 @@ def install_shims():
     torch.stft = stft_legacy
 
 
-def build_reference(cfg, labels):
+def build_reference(cfg, labels, pre_overrides=None):
     import nemo
     import nemo.collections.asr as nemo_asr
     nf = nemo.core.NeuralModuleFactory(placement=nemo.core.DeviceType.CPU)
@@ -136,6 +136,7 @@ def build_reference(cfg, labels):
     pre_cfg["pad_to"] = 0          # infer.py:90
     pre_cfg["stft_conv"] = False   # 15x5 yaml says true (torch_stft, absent); run like the vi config
     pre_cfg.pop("feat_type", None)
+    pre_cfg.update(pre_overrides or {})   # constructor options no shipped YAML uses (round 6: log guard "clamp", all_features)
     pre = nemo_asr.AudioToMelSpectrogramPreprocessor(**pre_cfg)
     enc = nemo_asr.JasperEncoder(feat_in=pre_cfg["features"], **cfg["JasperEncoder"])
     dec = nemo_asr.JasperDecoderForCTC(feat_in=cfg["JasperEncoder"]["jasper"][-1]["filters"],
@@ -144,13 +145,13 @@ def build_reference(cfg, labels):
     return nf, pre, enc, dec, greedy
 
 
-def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, band_hz=0):
+def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, band_hz=0, pre_overrides=None):
     pkg = _load_pkg()
     synth = pkg.synth
     from nemo.collections.asr.helpers import post_process_predictions
     cfg = yaml.safe_load(open(os.path.join(REF, "configs", cfg_file), encoding="utf-8"))
     labels = cfg["labels"]
-    nf, pre, enc, dec, greedy = build_reference(cfg, labels)
+    nf, pre, enc, dec, greedy = build_reference(cfg, labels, pre_overrides)
     jas = cfg["JasperEncoder"]["jasper"]
     enc_sd = synth.encoder_state_dict(jas, 64, seed)
     if real_decoder:
@@ -182,6 +183,9 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, ba
         min_margin=np.float32(margin.min().item()),
         fb=pre.filter_banks[0].numpy(),
     )
+    if pre_overrides:
+        import json
+        out["pre_overrides"] = json.dumps(pre_overrides, sort_keys=True)
     if band_hz:   # (only the round-5 cases carry these keys: the older fixtures regenerate bit-identically without them)
         out["band_hz"] = band_hz
         out["sig_abs_sum"] = np.float64(np.abs(sig.astype(np.float64)).sum())
@@ -282,6 +286,11 @@ if __name__ == "__main__":
     # round 5: the band-limited regime of 8 kHz-sourced audio, batched and ragged
     run_case("vi12x1_b4_band4k_ragged", "quartznet12x1_vi.yaml", 4, 40000, 9, True, real_decoder=VI_DEC, band_hz=4000)
     run_case("en15x5_b2_band4k", "quartznet15x5.yaml", 2, 30000, 10, False, band_hz=4000)
+    # round 6: front-end constructor options the reference accepts and no shipped YAML uses (parts/features.py:31-39, 272-273)
+    run_case("vi12x1_b3_clamp_allfeat", "quartznet12x1_vi.yaml", 3, 24000, 12, True,
+             pre_overrides={"log_zero_guard_type": "clamp", "normalize": "all_features"})
+    run_case("vi12x1_b2_clamp_1e5", "quartznet12x1_vi.yaml", 2, 16000, 13, True,
+             pre_overrides={"log_zero_guard_type": "clamp", "log_zero_guard_value": 1e-5})
     # BASELINE config 1 plumbing: real recordings of the reference's audio_samples/ (16 kHz broadcast, 8 kHz call centre)
     run_real_audio_case("real16k_thoisu_5", "V1 1 11 12H00 THOI SU 2019_5.wav", 7)
     run_real_audio_case("real8k_external_2", "external_1202_771_20191118_093137_1574044304_22681_2.wav", 8)

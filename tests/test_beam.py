@@ -101,6 +101,14 @@ def test_arpa_round_trip_and_backoff(tmp_path):
         d = BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "x.binary"), allow_missing_lm=True)
     assert d.lm_path is None
     assert BeamSearchDecoder(LABELS, lm_path=path).lm_path == path
+    # the reference's shipped call site (infer.py:184 passes a `.binary`): with the ARPA source NEXT to it under the same stem the
+    # unmodified path works, and keeps the behaviour the binary has in pyctcdecode (no unigram list)
+    import shutil
+    shutil.copy(path, os.path.join(str(tmp_path), "x.arpa"))
+    with pytest.warns(UserWarning, match="reading its ARPA source"):
+        d = BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "x.binary"))
+    assert d.lm_path == os.path.join(str(tmp_path), "x.arpa") and d.unigrams is None
+    assert BeamSearchDecoder(LABELS, lm_path=os.path.join(str(tmp_path), "x.arpa")).unigrams == "auto"
 
 
 def test_lm_changes_the_ranking(tmp_path):

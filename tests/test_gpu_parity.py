@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BAND_CASES, GOLDEN_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden
+from conftest import BAND_CASES, GOLDEN_CASES, OPTION_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden, oracle_pre_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +38,7 @@ def _engine(cfg, enc_sd, dec_sd, gemm=None):
 
 
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + OPTION_CASES)
 def test_fused_path_matches_reference_goldens(gpu, name, gemm):
     """The three fp32-equivalent GEMM arithmetics (2 x fp16 scaled split operands, 3 x bf16 split operands, exact-fp32
     MFMA) against the reference goldens, same tolerance for all."""
@@ -139,6 +139,31 @@ def test_neural_module_dag_matches_goldens(gpu, name):
     assert np.abs(lp_v.numpy() - g["logp"]).max() <= LOGP_TOL
     assert pred_v.dtype == torch.int64 and (pred_v.numpy() == g["pred"]).all()
     assert post_process_predictions([pred_v], cfg["labels"]) == [str(s) for s in g["hyp"]]
+
+
+@pytest.mark.parametrize("name", OPTION_CASES)
+def test_front_end_options_no_shipped_config_uses(gpu, name):
+    """log_zero_guard_type="clamp" (parts/features.py:272-273) and normalize="all_features" (:31-39): fixtures generated by the
+    imported reference with those constructor arguments; the NeuralModule built from the same kwargs (the reference's
+    `AudioToMelSpectrogramPreprocessor(**cfg)`, infer.py:102-103) against the reference's features, frame by frame, and
+    against the oracle with the same options."""
+    from viet_asr_amd import asr as nemo_asr
+    from viet_asr_amd.core import DeviceType, NeuralModuleFactory
+    from oracle import quartznet_oracle as O
+    g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
+    NeuralModuleFactory(placement=DeviceType.GPU)
+    pre_cfg = dict(cfg["AudioToMelSpectrogramPreprocessor"], dither=0, pad_to=0)
+    pre_cfg.pop("feat_type", None)
+    pre = nemo_asr.AudioToMelSpectrogramPreprocessor(**pre_cfg)
+    mel, seq = pre(force_pt=True, input_signal=torch.from_numpy(sig).to(gpu), length=torch.from_numpy(lens).to(gpu))
+    assert (seq.cpu().numpy() == g["seq"]).all()
+    err = float(np.abs(mel.cpu().numpy() - g["mel"]).max())
+    ref_mel, _ = O.melspec_forward(sig, lens, **oracle_pre_kwargs(cfg))
+    _record("front_end_options", name=name, err=err, err_vs_oracle=float((mel.cpu() - ref_mel).abs().max()))
+    assert err <= MEL_TOL, err
+    assert (mel.cpu().numpy()[g["mel"] == 0] == 0).all()
+    with pytest.raises(ValueError):
+        nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(pre_cfg, log_zero_guard_type="floor"))
 
 
 def test_stage_entry_points_against_oracle(gpu):

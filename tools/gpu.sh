@@ -45,7 +45,8 @@ print('step %.3f ms = %.0fx | gemm %.3f ms frac %.3f (of measured %s) | dw %.3f 
 #      -> <tag>/kernel_stats.csv, <tag>/pmc_traffic_summary.json, <tag>/bench_under_rocprof.json
 #      (gpurun refuses --pmc together with the hip / hsa / memory-copy traces: counters get runs of their own)
 task_prof() {
-O=$R/gpurun_out/${1:-prof}; mkdir -p $O
+local O=$R/gpurun_out/${1:-prof}; mkdir -p $O   # (local: task_final calls this twice and keeps its own $O)
+local ARGS PARGS f
 ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu-baseline --no-other-gemm --no-side-configs}
 PARGS=${PMC_BENCH_ARGS:-$ARGS}
 cd /tmp && export TMPDIR=/tmp

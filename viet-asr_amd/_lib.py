@@ -31,7 +31,8 @@ class FrontendDesc(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32),
                 ("hop_length", C.c_int32), ("n_mels", C.c_int32), ("preemph", C.c_float),
                 ("log_guard", C.c_float), ("normalize", C.c_int32),
-                ("h_window", C.POINTER(C.c_float)), ("h_filterbank", C.POINTER(C.c_float))]
+                ("h_window", C.POINTER(C.c_float)), ("h_filterbank", C.POINTER(C.c_float)),
+                ("log_guard_clamp", C.c_int32)]
 
 
 class ModelDesc(C.Structure):
@@ -176,7 +177,8 @@ class Handle:
             pre = frontend.get("preemph", 0.97)
             fe.preemph = -1.0 if pre is None else float(pre)
             fe.log_guard = float(frontend.get("log_guard", 2 ** -24))
-            fe.normalize = 1 if frontend.get("normalize", "per_feature") == "per_feature" else 0
+            fe.normalize = {"per_feature": 1, "all_features": 2}.get(frontend.get("normalize", "per_feature"), 0)
+            fe.log_guard_clamp = 1 if frontend.get("log_guard_type", "add") == "clamp" else 0
             if win.shape != (fe.win_length,) or fb.shape != (fe.n_mels, fe.n_fft // 2 + 1):
                 raise ValueError(f"window {win.shape} / filterbank {fb.shape} do not match the description")
             fe.h_window, fe.h_filterbank = _fptr(win), _fptr(fb)

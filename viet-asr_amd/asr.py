@@ -287,14 +287,18 @@ class BeamSearchDecoderWithLM(NonTrainableNM):
         return {"predictions": NeuralType(("B", "T"), PredictionsType())}
 
     def __init__(self, lm_path, vocab, beam_width, alpha, beta, num_cpus=1, cutoff_prob=1.0, cutoff_top_n=40,
-                 input_tensor=True, allow_missing_lm=False):
+                 input_tensor=True, allow_missing_lm=False, unigrams="auto"):
+        """unigrams (net-new): "auto" = what build_ctcdecoder does for lm_path's suffix -- the ARPA's own unigram list + character
+        trie for "*.arpa", none otherwise --, None = no unigram list on any file (the behaviour the reference got from its
+        `.binary`), or a list of words (viet_asr_amd/beam.py)."""
         super().__init__()
         if self._factory is not None and self._factory.world_size > 1:
             raise ValueError("BeamSearchDecoderWithLM does not run in distributed mode")   # :79-80
         from .beam import BeamSearchDecoder
         self.vocab, self.beam_width = list(vocab), beam_width
         # an lm_path that cannot be read (KenLM binaries, a missing file) raises unless allow_missing_lm (beam.LM_HELP)
-        self.decoder = BeamSearchDecoder(self.vocab, lm_path=lm_path, alpha=alpha, beta=beta, allow_missing_lm=allow_missing_lm)
+        self.decoder = BeamSearchDecoder(self.vocab, lm_path=lm_path, alpha=alpha, beta=beta, allow_missing_lm=allow_missing_lm,
+                                         unigrams=unigrams)
         self.num_cpus, self.cutoff_prob, self.cutoff_top_n, self.input_tensor = num_cpus, cutoff_prob, cutoff_top_n, \
             input_tensor
 

@@ -265,7 +265,8 @@ def lm_file_usable(path):
     return True, ""
 
 
-LM_HELP = ("this library reads n-gram models as ARPA text only.  The reference's default `models/language_model/3-gram-lm.binary` "
+LM_HELP = ("this library reads n-gram models as ARPA text only (or put `<same stem>.arpa` next to the `.binary`: it is then read "
+           "instead, with the binary's no-unigram behaviour).  The reference's default `models/language_model/3-gram-lm.binary` "
            "(infer.py:184, app.py:20) is a KenLM binary, a third-party layout that cannot be turned back into ARPA: keep (or "
            "rebuild) the ARPA file it was compiled from -- `lmplz -o 3 < corpus.txt > 3-gram-lm.arpa` -- and pass that path.  "
            "Pass allow_missing_lm=True to search without a language model instead.")
@@ -284,6 +285,20 @@ class BeamSearchDecoder:
         # reference's own fall-back (infer.py:117-128: kenlm not importable -> lm_path = None, search without an LM).
         if lm_path:
             ok, why = lm_file_usable(lm_path)
+            if not ok:
+                # The reference's shipped paths name KenLM binaries (`models/language_model/3-gram-lm.binary`, infer.py:184,
+                # app.py:20).  When the ARPA text such a binary was compiled from sits NEXT to it under the same stem, read that
+                # -- with the behaviour the BINARY has in pyctcdecode (no unigram list), so that an unmodified call site gets the
+                # rankings it would get from the reference.
+                import os
+                sibling = lm_path.rsplit(".", 1)[0] + ".arpa" if lm_path.endswith((".binary", ".bin")) else None
+                if sibling and os.path.exists(sibling) and lm_file_usable(sibling)[0]:
+                    import warnings
+                    warnings.warn(f"language model {lm_path!r} not usable ({why}); reading its ARPA source {sibling!r} instead, with the "
+                                  "behaviour a KenLM binary has in pyctcdecode (no unigram list)")
+                    lm_path, ok = sibling, True
+                    if isinstance(unigrams, str) and unigrams == "auto":
+                        unigrams = None
             if not ok:
                 if not allow_missing_lm:
                     raise ValueError(f"language model {lm_path!r} not usable ({why}); {LM_HELP}")

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < kMelTaps; ++i) acc = fmaf(mw[i], P[mlo + i], acc);
-    tile[lane * (kFramesPerBlock + 1) + fl] = logf(acc + log_guard);
+    // (uniform) log_zero_guard_type: "add" log(x + guard), "clamp" log(max(x, guard))
+    tile[lane * (kFramesPerBlock + 1) + fl] = tb.guard_clamp ? logf(fmaxf(acc, log_guard)) : logf(acc + log_guard);
     wave_fence();
   }
   __syncthreads();
@@ -229,6 +230,36 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ mel,
   normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red);
 }
 
+// normalize_batch("all_features") (features.py:31-39): ONE mean and one unbiased std per utterance over every mel bin and
+// every valid frame, x[b, :, :seq[b]].mean() / .std() + 1e-5.  One workgroup per utterance, after the row kernel has masked the
+// padded frames (launched with normalize = 0); statistics in double as above.  No shipped configuration uses it.
+__global__ __launch_bounds__(256) void normalize_all_kernel(float* __restrict__ mel, int64_t ld, const int64_t* __restrict__ seq,
+                                                            int n_mels, int frames) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* x = mel + (int64_t)blockIdx.x * n_mels * ld;
+  const int64_t n64 = seq[blockIdx.x];
+  const int n = (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64));
+  const double cnt = (double)n * (double)n_mels;
+  double s = 0.0;
+  for (int f = 0; f < n_mels; ++f)
+    for (int t = tid; t < n; t += 256) s += (double)x[(int64_t)f * ld + t];
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const double mu = (((red[0] + red[1]) + red[2]) + red[3]) / cnt;       // no valid frame -> NaN, like torch .mean() of an empty slice
+  double q = 0.0;
+  for (int f = 0; f < n_mels; ++f)
+    for (int t = tid; t < n; t += 256) { const double d = (double)x[(int64_t)f * ld + t] - mu; q += d * d; }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wv] = q;
+  __syncthreads();
+  const float mean = (float)mu;
+  const float stdv = (float)sqrt((((red[4] + red[5]) + red[6]) + red[7]) / (cnt - 1.0)) + 1e-5f;   // features.py:37-38 CONSTANT
+  for (int f = 0; f < n_mels; ++f)
+    for (int t = tid; t < n; t += 256) x[(int64_t)f * ld + t] = (x[(int64_t)f * ld + t] - mean) / stdv;
+}
+
 __global__ __launch_bounds__(256) void normalize_chain_kernel(float* __restrict__ mel, int64_t ld,
                                                               const int64_t* __restrict__ len, int hop, int batch, int n_mels,
                                                               int frames, int normalize, int64_t* __restrict__ seq,
@@ -269,6 +300,10 @@ void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, i
 
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st) {
   hipLaunchKernelGGL(seq_len_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, len, batch, hop, seq);
+}
+
+void launch_normalize_all(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames, hipStream_t st) {
+  hipLaunchKernelGGL(normalize_all_kernel, dim3(batch), dim3(256), 0, st, mel, mel_ld, seq, n_mels, frames);
 }
 
 void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,

@@ -146,6 +146,7 @@ const vasr::DevSwitches& vasr::dev_switches() {
       for (int a : allowed) if (a == v) return v;
       fprintf(stderr, "vasr (devtools build): %s=%s is not a documented value -- refusing to guess\n", name, e);
       abort();
+      return dflt;   // (not reached)
     };
     s.pw3_tile = num("VASR_PW3_TILE", 0, {0, 1, 2, 3, 4, 5});
     s.pw_lat = num("VASR_PW_LAT", 1, {0, 1});
@@ -332,7 +333,7 @@ int build_frontend(vasr_handle* h) {
   if ((rc = upload(h, win, &d_win)) || (rc = upload(h, tw256, &d_t256)) || (rc = upload(h, tw512, &d_t512)) ||
       (rc = upload(h, mw, &d_mw)) || (rc = upload(h, lo, &d_lo)))
     return rc;
-  h->ft = FrontendTables{d_win, d_t256, d_t512, d_mw, d_lo};
+  h->ft = FrontendTables{d_win, d_t256, d_t512, d_mw, d_lo, h->fe.log_guard_clamp ? 1 : 0};
   return 0;
 }
 
@@ -913,7 +914,8 @@ int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, i
   launch_seq_len(d_len, batch, h->fe.hop_length, d_seq, st);
   launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
                      h->fe.preemph, h->fe.log_guard, d_mel, T, T, st);
-  launch_normalize(d_mel, T, d_seq, batch, h->fe.n_mels, T, h->fe.normalize, st);
+  launch_normalize(d_mel, T, d_seq, batch, h->fe.n_mels, T, h->fe.normalize == 1, st);
+  if (h->fe.normalize == 2) launch_normalize_all(d_mel, T, d_seq, batch, h->fe.n_mels, T, st);
   return check_launch("melspec");
 }
 
@@ -981,9 +983,10 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
     ProfScope ps(h, kProfFrontend, st);
     launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
                        h->fe.preemph, h->fe.log_guard, melp, p.Tp0, (int)T, st);
-    launch_normalize_chain(melp, p.Tp0, d_len, h->fe.hop_length, batch, h->fe.n_mels, (int)T, h->fe.normalize, seq,
+    launch_normalize_chain(melp, p.Tp0, d_len, h->fe.hop_length, batch, h->fe.n_mels, (int)T, h->fe.normalize == 1, seq,
                            h->d_steps, (int)h->steps.size(), reinterpret_cast<int32_t*>(ws + p.lens_tab), d_enc_len,
                            h->row_independent ? d_len : nullptr, (int)p.T1, st);
+    if (h->fe.normalize == 2) launch_normalize_all(melp, p.Tp0, seq, batch, h->fe.n_mels, (int)T, st);
   }
   AmaxTab enc_amax{};
   const int32_t* own_frames = nullptr;

@@ -104,6 +104,7 @@ struct FrontendTables {
   const float* tw512;    // [257][2] e^{-2 pi i k/512}
   const float* mel_w;    // [64][kMelTaps] packed non-zero filter weights
   const int32_t* mel_lo; // [64] first fft bin of each filter
+  int32_t guard_clamp;   // log(max(x, guard)) instead of log(x + guard)  (features.py:269-274)
 };
 constexpr int kMelTaps = 32;  // >= max non-zeros per Slaney filter at 64 mels / 512 fft (23)
 
@@ -113,6 +114,8 @@ void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, i
                         int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st);
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st);
+// normalize: 1 = per (utterance, mel bin) row, 0 = mask only; "all_features" = mask only, then launch_normalize_all
+void launch_normalize_all(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames, hipStream_t st);
 void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,
                       int normalize, hipStream_t st);
 

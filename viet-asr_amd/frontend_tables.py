@@ -75,8 +75,12 @@ def frontend_description(pre_cfg):
     # symmetric one (features.py:178) -- and returned as a magnitude that features.py:260-261 squares again.  The kernels
     # therefore run the same transform with the periodic window (power = re^2 + im^2 instead of sqrt(.)^2: <= 1 ulp).
     periodic = bool(c.get("stft_conv", False))
-    if c.get("log", True) is not True or c.get("log_zero_guard_type", "add") != "add":
-        raise NotImplementedError("only log=True with log_zero_guard_type='add' is implemented")
+    guard_type = c.get("log_zero_guard_type", "add")
+    if guard_type not in ("add", "clamp"):
+        raise ValueError(f"{type(c).__name__} received {guard_type} for the log_zero_guard_type parameter. "
+                         "It must be either 'add' or 'clamp'.")                       # features.py:215-220
+    if c.get("log", True) is not True:
+        raise NotImplementedError("only log=True is implemented")
     if float(c.get("mag_power", 2.0)) != 2.0 or int(c.get("frame_splicing", 1)) != 1:
         raise NotImplementedError("only mag_power=2, frame_splicing=1 are implemented")
     guard = c.get("log_zero_guard_value", 2 ** -24)
@@ -91,10 +95,11 @@ def frontend_description(pre_cfg):
     n_mels = int(c.get("features", 64))
     fb = mel_filterbank(sr, n_fft, n_mels, c.get("lowfreq", 0) or 0.0, c.get("highfreq") or sr / 2)
     norm = c.get("normalize", "per_feature")
-    if norm not in ("per_feature", None, False, ""):
-        raise NotImplementedError(f"normalize={norm!r} is not implemented (per_feature or none)")
+    if norm not in ("per_feature", "all_features", None, False, ""):
+        raise NotImplementedError(f"normalize={norm!r} is not implemented (per_feature, all_features or none)")
     if float(c.get("pad_value", 0)) != 0.0:
         raise NotImplementedError("pad_value other than 0 is not implemented")
     return dict(sample_rate=sr, n_fft=int(n_fft), win_length=nws, hop_length=nwst, n_mels=n_mels,
                 preemph=c.get("preemph", 0.97), log_guard=float(guard),
-                normalize="per_feature" if norm == "per_feature" else "none", window=win, filterbank=fb)
+                log_guard_type=guard_type, normalize=norm if norm in ("per_feature", "all_features") else "none", window=win,
+                filterbank=fb)

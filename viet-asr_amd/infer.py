@@ -22,7 +22,7 @@ from .helpers import post_process_predictions
 
 class VietASR:
     def __init__(self, config_file, encoder_checkpoint, decoder_checkpoint, device="gpu", lm_path=None,
-                 beam_width=20, lm_alpha=0.5, lm_beta=1.5, decoder="beam", allow_missing_lm=False):
+                 beam_width=20, lm_alpha=0.5, lm_beta=1.5, decoder="beam", allow_missing_lm=False, lm_unigrams="auto"):
         if os.path.exists(str(config_file)):
             model_definition = configs.load_model_definition(config_file)
         else:
@@ -57,6 +57,7 @@ class VietASR:
             # a given lm_path that is missing or not ARPA text is an error unless allow_missing_lm (round 5; beam.LM_HELP)
             self.beam = nemo_asr.BeamSearchDecoderWithLM(vocab=labels, beam_width=beam_width, alpha=lm_alpha,
                                                          beta=lm_beta, lm_path=lm_path, allow_missing_lm=allow_missing_lm,
+                                                         unigrams=lm_unigrams,   # "auto": pyctcdecode's rule for the path's suffix
                                                          num_cpus=max(1, os.cpu_count()))
             self.infer_tensors = [self.beam(log_probs=log_probs, log_probs_length=encoded_len)]
         else:
