@@ -135,8 +135,8 @@ def torch_stft_magnitude(x, n_fft, hop, win_length, window="hann"):
 
 def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_stride=160, n_fft=512,
                     preemph=0.97, nfilt=64, lowfreq=0, highfreq=None, log_zero_guard_value=2 ** -24,
-                    normalize="per_feature", pad_value=0.0, fb=None, stft_conv=False, log_zero_guard_type="add"):
-    """FilterbankFeatures.forward (parts/features.py:245-301) with dither=0, pad_to=0
+                    normalize="per_feature", pad_value=0.0, fb=None, stft_conv=False, log_zero_guard_type="add", dither=0.0):
+    """FilterbankFeatures.forward (parts/features.py:245-301) with dither=0 (default), pad_to=0
     (infer.py:89-90; quirk Q1: the featurizer is never put in eval mode, so no pad-to-16),
     mag_power=2, log guard "add", frame_splicing=1.  stft_conv=True (unpinned, see
     torch_stft_magnitude) squares the package's magnitude and skips the re/im sum (:260-263).
@@ -146,6 +146,8 @@ def melspec_forward(x, length, sample_rate=16000, n_window_size=320, n_window_st
     x = torch.as_tensor(x, dtype=torch.float32)
     length = torch.as_tensor(length, dtype=torch.int64)
     seq_len = featurizer_seq_len(length, n_window_stride)                      # :246
+    if dither > 0:                                                             # :250-251 (the caller seeds torch; not in place here)
+        x = x + dither * torch.randn_like(x)
     if preemph is not None:                                                    # :254-255
         x = torch.cat((x[:, 0].unsqueeze(1), x[:, 1:] - preemph * x[:, :-1]), dim=1)
     if stft_conv:

@@ -166,6 +166,9 @@ def run_case(name, cfg_file, batch, samples, seed, ragged, real_decoder=None, ba
     # the executor's call convention: pmodule(force_pt=True, **ports)  (actions.py:419-428)
     enc.eval(); dec.eval(); greedy.eval()                      # actions.py:412-415 (nn.Modules only: Q1)
     with torch.no_grad():
+        if pre_overrides and pre_overrides.get("dither"):
+            torch.manual_seed(seed)     # features.py:250-251 draws torch.randn_like(x) from the global CPU generator
+            sig = sig.copy()            # ... and adds it IN PLACE to the tensor that shares the array's memory
         mel, seq = pre(force_pt=True, input_signal=torch.as_tensor(sig), length=torch.as_tensor(lens))
         e, elen = enc(force_pt=True, audio_signal=mel, length=seq)
         logp = dec(force_pt=True, encoder_output=e)
@@ -291,6 +294,8 @@ if __name__ == "__main__":
              pre_overrides={"log_zero_guard_type": "clamp", "normalize": "all_features"})
     run_case("vi12x1_b2_clamp_1e5", "quartznet12x1_vi.yaml", 2, 16000, 13, True,
              pre_overrides={"log_zero_guard_type": "clamp", "log_zero_guard_value": 1e-5})
+    # dither (parts/features.py:250-251): noise of 1e-3 from torch's CPU generator seeded with the case's seed
+    run_case("vi12x1_b2_dither_1e3", "quartznet12x1_vi.yaml", 2, 16000, 14, True, pre_overrides={"dither": 1e-3})
     # BASELINE config 1 plumbing: real recordings of the reference's audio_samples/ (16 kHz broadcast, 8 kHz call centre)
     run_real_audio_case("real16k_thoisu_5", "V1 1 11 12H00 THOI SU 2019_5.wav", 7)
     run_real_audio_case("real8k_external_2", "external_1202_771_20191118_093137_1574044304_22681_2.wav", 8)

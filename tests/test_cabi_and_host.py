@@ -273,19 +273,17 @@ def test_constructor_errors_mirror_the_reference():
     with pytest.raises(ValueError):     # parts/jasper.py:61-62
         nemo_asr.JasperEncoder(jasper=[dict(filters=256, repeat=1, kernel=[33], stride=[2], dilation=[2], dropout=0.0,
                                             residual=False, separable=True)], activation="relu", feat_in=64)
-    # the reference's own defaults (dither=1e-5, pad_to=16) and the 15x5 YAML's stft_conv=true must construct: the
-    # training-time dither level is announced and not applied, stft_conv selects torch_stft's periodic window
-    with pytest.warns(UserWarning, match="dither"):
-        pre = nemo_asr.AudioToMelSpectrogramPreprocessor()
-    assert pre.pad_to == 16
+    # the reference's own defaults (dither=1e-5, pad_to=16) and the 15x5 YAML's stft_conv=true must construct;
+    # stft_conv selects torch_stft's periodic window
+    pre = nemo_asr.AudioToMelSpectrogramPreprocessor()
+    assert pre.pad_to == 16 and pre.dither == 1e-5
     sym = nemo_asr.AudioToMelSpectrogramPreprocessor(dither=0)._desc["window"]
     per = nemo_asr.AudioToMelSpectrogramPreprocessor(dither=0, stft_conv=True)._desc["window"]
     from scipy.signal import get_window
     assert np.abs(per - get_window("hann", 320, fftbins=True)).max() < 1e-6
     assert np.abs(sym - get_window("hann", 320, fftbins=False)).max() < 1e-6 and np.abs(sym - per).max() > 1e-3
-    with pytest.raises(NotImplementedError):      # audible noise is not generated on the inference path
-        nemo_asr.AudioToMelSpectrogramPreprocessor(dither=1e-2)
-    with pytest.raises(NotImplementedError):      # features.py:295-296, training-time option
+    assert nemo_asr.AudioToMelSpectrogramPreprocessor(dither=1e-2).dither == 1e-2     # applied in forward (features.py:250-251)
+    with pytest.raises(TypeError):      # features.py:209: the reference's own constructor fails on the advertised "max"
         nemo_asr.AudioToMelSpectrogramPreprocessor(dither=0, pad_to="max")
     if not torch.cuda.is_available():
         with pytest.raises(ValueError):     # neural_factory.py:320-330

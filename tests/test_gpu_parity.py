@@ -166,6 +166,38 @@ def test_front_end_options_no_shipped_config_uses(gpu, name):
         nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(pre_cfg, log_zero_guard_type="floor"))
 
 
+def test_dither_is_the_reference_torch_call_on_the_device(gpu):
+    """dither (parts/features.py:250-251: `x += dither * torch.randn_like(x)`): the module makes the SAME torch call on the same
+    device tensor, in place like the reference, so under one torch.manual_seed it is bit-for-bit the dither = 0 module fed with
+    signal + noise; the features of that dithered signal against the oracle.  (The reference-generated fixture of this case
+    draws from the CPU generator: tests/test_oracle_golden.py replays it with the oracle.)"""
+    from viet_asr_amd import asr as nemo_asr
+    from viet_asr_amd.core import DeviceType, NeuralModuleFactory
+    from oracle import quartznet_oracle as O
+    g, cfg, sig, lens, enc_sd, dec_sd = load_golden("vi12x1_b2_dither_1e3")
+    NeuralModuleFactory(placement=DeviceType.GPU)
+    pre_cfg = dict(cfg["AudioToMelSpectrogramPreprocessor"], pad_to=0)
+    pre_cfg.pop("feat_type", None)
+    assert pre_cfg["dither"] == 1e-3
+    pre_d = nemo_asr.AudioToMelSpectrogramPreprocessor(**pre_cfg)
+    pre_0 = nemo_asr.AudioToMelSpectrogramPreprocessor(**dict(pre_cfg, dither=0))
+    x, n = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    torch.manual_seed(7)
+    xa = x.clone()
+    mel_d, seq = pre_d(force_pt=True, input_signal=xa, length=n)
+    torch.manual_seed(7)
+    xb = x.clone()
+    xb += 1e-3 * torch.randn_like(xb)
+    mel_0, _ = pre_0(force_pt=True, input_signal=xb, length=n)
+    assert torch.equal(xa, xb) and not torch.equal(xa, x)          # in place, like the reference
+    assert torch.equal(mel_d, mel_0) and (seq.cpu().numpy() == g["seq"]).all()
+    assert 0.9e-3 < float((xa - x).std()) < 1.1e-3
+    ref_mel, _ = O.melspec_forward(xa.cpu().numpy(), lens)
+    err = float((mel_d.cpu() - ref_mel).abs().max())
+    _record("front_end_dither", err_vs_oracle=err)
+    assert err <= MEL_TOL, err
+
+
 def test_stage_entry_points_against_oracle(gpu):
     """Each C-ABI stage fed with the ORACLE's input for that stage (errors do not compound)."""
     from viet_asr_amd import _lib, configs, stages, synth

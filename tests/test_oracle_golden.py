@@ -2,15 +2,18 @@
 import numpy as np
 import pytest
 
-from conftest import BAND_CASES, GOLDEN_CASES, OPTION_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden, oracle_pre_kwargs
+from conftest import BAND_CASES, DITHER_CASES, GOLDEN_CASES, OPTION_CASES, REAL_AUDIO_CASES, load_golden, load_real_audio_golden, oracle_pre_kwargs
 from oracle import audio_oracle as AO
 from oracle import quartznet_oracle as O
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES + BAND_CASES + OPTION_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + BAND_CASES + OPTION_CASES + DITHER_CASES)
 def test_oracle_matches_reference_outputs(name):
     g, cfg, sig, lens, enc_sd, dec_sd = load_golden(name)
     assert (lens == g["lens"]).all()
+    if name in DITHER_CASES:
+        import torch
+        torch.manual_seed(int(g["seed"]))      # make_golden.py: the reference drew its noise from the CPU generator under this seed
     r = O.forward_all(sig, lens, enc_sd, dec_sd, cfg["JasperEncoder"]["jasper"], **oracle_pre_kwargs(cfg))
     # same ATen primitives as the reference -> bit-exact on the same host; 2e-6 leaves room for
     # a different CPU dispatch (AVX2 vs AVX512 kernels) on another box

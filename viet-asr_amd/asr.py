@@ -57,27 +57,22 @@ class AudioToMelSpectrogramPreprocessor(NonTrainableNM):
             n_fft=n_fft, preemph=preemph, features=features, lowfreq=lowfreq, highfreq=highfreq, log=log,
             log_zero_guard_type=log_zero_guard_type, log_zero_guard_value=log_zero_guard_value,
             frame_splicing=frame_splicing, stft_conv=stft_conv, pad_value=pad_value, mag_power=mag_power))
-        # dither adds random noise to the signal (features.py:250-251): not reproducible, and infer.py:89 forces it to 0.
-        # The constructor default and every shipped YAML say 1e-5, so a module built with the reference's defaults or
-        # from **cfg must construct: a training-time level (<= 1e-4, i.e. <= -80 dB re full scale) is accepted, NOT
-        # applied (the features are the dither=0 ones) and announced once; anything louder is a request for noise this
-        # inference path does not generate and raises.  pad_to: FilterbankFeatures zero-pads T up to
-        # a multiple of self.pad_to in training mode -- the mode the executor leaves this NonTrainableNM in, quirk Q1 --
-        # and of 16 in eval mode (features.py:292-300); infer.py:90 sets 0 = no padding.  A non-zero pad_to is applied
-        # here the way the reference's (training-mode) branch does it: extra all-zero frames appended on the device.
-        if dither and dither > 1e-4:
-            raise NotImplementedError(f"dither={dither!r}: random noise on the input is not generated on this inference "
-                                      "path; pass dither=0 as infer.py:89 does (levels <= 1e-4 are accepted and ignored)")
-        if dither:
-            import warnings
-            warnings.warn(f"AudioToMelSpectrogramPreprocessor: dither={dither!r} is not applied (inference path, "
-                          "infer.py:89 sets it to 0); features are those of dither=0", stacklevel=2)
+        # dither (features.py:250-251): `x += dither * torch.randn_like(x)` -- the SAME torch call on the same device tensor, in
+        # place like the reference (SURVEY section 8b "ownership"), so that under one torch.manual_seed this module and the
+        # reference's draw the same noise on the same device; infer.py:89 forces 0.  pad_to: FilterbankFeatures zero-pads T up
+        # to a multiple of self.pad_to in training mode -- the mode the executor leaves this NonTrainableNM in, quirk Q1 -- and
+        # of 16 in eval mode (features.py:292-300); infer.py:90 sets 0 = no padding.  A non-zero pad_to is applied here the way
+        # the reference's (training-mode) branch does it: extra all-zero frames appended on the device.
+        if dither is not None and dither < 0:
+            raise ValueError(f"dither must be >= 0, got {dither!r}")
         if pad_to == "max":
-            raise NotImplementedError("pad_to='max' (pad every batch to max_duration, a training-time option, "
-                                      "features.py:295-296) is not implemented; infer.py:90 uses pad_to=0")
+            # features.py:209 evaluates `pad_to > 0` in the constructor: with the string the docstring advertises
+            # (audio_preprocessing.py:261-262, features.py:295-296) the reference itself raises this TypeError
+            raise TypeError("'>' not supported between instances of 'str' and 'int' (pad_to='max': the reference's own "
+                            "constructor fails at parts/features.py:209)")
         if pad_to is not None and (int(pad_to) != pad_to or pad_to < 0):
             raise ValueError(f"pad_to must be a non-negative integer, got {pad_to!r}")
-        self.dither, self.pad_to = dither, int(pad_to or 0)
+        self.dither, self.pad_to = float(dither or 0.0), int(pad_to or 0)
         self.win_length, self.hop_length = self._desc["win_length"], self._desc["hop_length"]
         self._handle = None
 
@@ -97,6 +92,8 @@ class AudioToMelSpectrogramPreprocessor(NonTrainableNM):
         return torch.ceil(seq_len.float() / self.hop_length).to(dtype=torch.long)
 
     def forward(self, input_signal, length):
+        if self.dither > 0:
+            input_signal += self.dither * torch.randn_like(input_signal)      # features.py:250-251
         mel, seq = stages.melspec(self._get_handle(), input_signal, length)
         if self.pad_to > 0 and mel.shape[-1] % self.pad_to:
             mel = torch.nn.functional.pad(mel, (0, self.pad_to - mel.shape[-1] % self.pad_to), value=self._desc.get("pad_value", 0.0))
