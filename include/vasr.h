@@ -36,8 +36,8 @@ extern "C" {
  * a caller built against the four-class form would be written past its arrays; 5: vasr_lm_create takes 16-byte table
  * entries with power-of-two capacities; 6: vasr_lm_create takes the character trie of pyctcdecode's unigram set, the
  * vocabulary entries carry a set-membership flag, vasr_resample_f32 emits ceil(len * ratio) samples,
- * vasr_frontend_desc ends in log_guard_clamp and knows normalize = 2). */
-#define VASR_ABI_VERSION 6
+ * vasr_frontend_desc ends in log_guard_clamp and knows normalize = 2; 7: + vasr_transcribe_greedy_pcm16). */
+#define VASR_ABI_VERSION 7
 
 typedef struct vasr_handle vasr_handle;
 typedef void* vasr_stream; /* hipStream_t */
@@ -158,6 +158,16 @@ VASR_API int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, cons
                                int64_t samples, int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len,
                                float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
                                vasr_stream stream);
+
+/* The same call on int16 PCM as it sits in a wav file (AudioSegment._convert_samples_to_float32, parts/segment.py:61-74:
+ * samples.astype('float32') * 2^-15): the front end's staging load converts and scales each sample as it reads it (SURVEY
+ * section 8 f1) -- an exact conversion times an exact power of two, so every output equals, bit for bit, what
+ * vasr_pcm16_to_f32 followed by vasr_transcribe_greedy_f32 returns; half the bytes over PCIe and into the first kernel, one
+ * launch and one [B][L] float buffer fewer.  d_pcm [B][L] int16 (rows zero padded).  (ABI 7) */
+VASR_API int vasr_transcribe_greedy_pcm16(vasr_handle* h, const int16_t* d_pcm, const int64_t* d_len, int batch,
+                                 int64_t samples, int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len,
+                                 float* d_logp, float* d_enc_len, void* d_workspace, size_t workspace_bytes,
+                                 vasr_stream stream);
 
 /* GEMM arithmetic of the 1x1 convolutions of the encoder:
  *   0            v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain;

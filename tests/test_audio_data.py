@@ -106,6 +106,43 @@ def test_pcm16_to_float_on_device(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch,samples", [(3, 20000), (40, 32000)])   # the one-frame-per-wavefront STFT form / the 32-frame one
+def test_int16_pcm_straight_into_the_front_end(gpu, batch, samples):
+    """int16 -> float32 (parts/segment.py:61-74, samples * 2^-15) fused into the front end's staging load
+    (vasr_transcribe_greedy_pcm16).  The conversion and the power-of-two product are exact, so every output -- log-probs
+    included -- equals the float path's on the converted samples bit for bit; ragged rows, both STFT kernel forms, and the
+    host-side batch API (engine.launch) fed with int16 arrays."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 21), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 21), device=gpu)
+    sig, lens = synth.audio_batch(batch, samples, 21, ragged=True)
+    pcm = np.clip(np.round(sig * 32768.0 * 4), -32768, 32767).astype(np.int16)
+    for b in range(batch):
+        pcm[b, lens[b]:] = 0
+    d_pcm, d_len = torch.from_numpy(pcm).to(gpu), torch.from_numpy(lens).to(gpu)
+    a = eng.forward(d_pcm, d_len, want_logp=True)
+    b_ = eng.forward(audio.pcm16_to_float(d_pcm), d_len, want_logp=True)
+    def same_ids(p, q):      # (ids past id_len are unwritten)
+        n = p["id_len"].cpu().numpy()
+        return torch.equal(p["id_len"], q["id_len"]) and all(torch.equal(p["ids"][r, : n[r]], q["ids"][r, : n[r]]) for r in range(batch))
+    for k in ("pred", "enc_len", "logp"):
+        assert torch.equal(a[k], b_[k]), k
+    assert same_ids(a, b_) and int(a["id_len"].max()) > 0
+    for ri in (False, True):
+        a = eng.forward(d_pcm, d_len, row_independent=ri)
+        b_ = eng.forward(audio.pcm16_to_float(d_pcm), d_len, row_independent=ri)
+        assert same_ids(a, b_)
+    eng.forward(d_pcm, d_len)      # (leave the handle in the batched mode)
+    got = eng.launch([pcm[i, : lens[i]] for i in range(batch)]).texts()
+    want = eng.launch([(pcm[i, : lens[i]].astype(np.float32) / 32768.0) for i in range(batch)]).texts()
+    assert got == want and any(got)
+    with pytest.raises(ValueError):
+        eng.forward(d_pcm.to(torch.int32), d_len)
+
+
+@pytest.mark.gpu
 def test_randomised_resampler_and_greedy_tail_cases(gpu):
     """Forty cases each of tests/devtools/fuzz_audio.py: random rate pairs / batch shapes / ragged lengths through the
     resampler, random shapes and class counts (with exact ties) through argmax + CTC collapse."""

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vasr_ctc_collapse": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "vasr_transcribe_greedy_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
                                              C.c_size_t, _P]),
+    "vasr_transcribe_greedy_pcm16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P,
+                                               C.c_size_t, _P]),
     "vasr_pcm16_to_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
     "vasr_resample_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, C.c_int64, _P, _P]),
     "vasr_set_gemm_mode": (C.c_int, [_P, C.c_int]),
@@ -102,7 +104,7 @@ DEV_SIGNATURES = {
     "vasr_bench_pointwise": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
-ABI_VERSION = 6          # VASR_ABI_VERSION of the include/vasr.h these signatures were written against
+ABI_VERSION = 7          # VASR_ABI_VERSION of the include/vasr.h these signatures were written against
 
 _lib = None
 _dev = None

@@ -39,8 +39,14 @@ __device__ __forceinline__ void wave_fence() {
 // the throughput form, 62.5 % of the staged samples shared) or 8 (one frame per wavefront: a small batch's few workgroups
 // -- 21 for a 6.6 s clip -- are a chain of four dependent FFTs each, 16.5 us at batch 1; four times as many workgroups
 // of a quarter of the length fill more of the idle chip).  A frame's arithmetic does not depend on the block it is in.
-template <int kFramesPerBlock>
-__global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables tb, const float* __restrict__ wav,
+// S = float (the reference's float32 signal) or short: int16 PCM straight from the file, scaled by 2^-15 on the way into LDS
+// (AudioSegment._convert_samples_to_float32, parts/segment.py:61-74: an exact conversion and an exact power-of-two product,
+// i.e. the bits of converting first -- SURVEY section 8 f1: "int16 -> fp32 fused into the pre-emphasis load").
+__device__ __forceinline__ float sample_f32(const float* x, int64_t n) { return x[n]; }
+__device__ __forceinline__ float sample_f32(const short* x, int64_t n) { return (float)x[n] * 0x1p-15f; }
+
+template <int kFramesPerBlock, typename S>
+__global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables tb, const S* __restrict__ wav,
                                                           int64_t samples, const int64_t* __restrict__ row_len,
                                                           int hop, float preemph,
                                                           float log_guard, float* __restrict__ mel,
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFramesPerBlock;
-  const float* x = wav + (int64_t)b * samples;
+  const S* x = wav + (int64_t)b * samples;
   // row-independent mode (vasr_set_row_independent): the row ends at its own length, as if it were alone in the batch
   const int64_t ns = row_len ? min(row_len[b], samples) : samples;
 
@@ -85,9 +91,9 @@ __global__ __launch_bounds__(kThreads, 4) void stft_logmel_kernel(FrontendTables
     if (n >= ns) n = 2 * (ns - 1) - n;
     float v = 0.f;
     if (n >= 0 && n < ns) {
-      v = x[n];
+      v = sample_f32(x, n);
       // features.py:254-255  x[:,1:] - preemph * x[:,:-1]  (two roundings, no fma contraction)
-      if (preemph >= 0.f && n > 0) v = __fsub_rn(v, __fmul_rn(preemph, x[n - 1]));
+      if (preemph >= 0.f && n > 0) v = __fsub_rn(v, __fmul_rn(preemph, sample_f32(x, n - 1)));
     }
     seg[i] = v;
   }
@@ -282,10 +288,10 @@ __global__ __launch_bounds__(256) void normalize_chain_kernel(float* __restrict_
 
 }  // namespace
 
-void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, const int64_t* row_len,
-                        int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
+void launch_stft_logmel(const FrontendTables& tb, const void* wav, bool pcm16, int batch, int64_t samples,
+                        const int64_t* row_len, int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st) {
-  auto go = [&](auto kern, int fpb) {
+  auto go = [&](auto kern, auto* wav, int fpb) {
     const int seg_len = (fpb - 1) * hop + kNfft;
     const size_t lds = (size_t)((seg_len + 3) & ~3) * 4 + kWaves * 256 * 8 + kWaves * (260 + kMelTaps) * 4 + 64 * (fpb + 1) * 4;
     dim3 grid((frames + fpb - 1) / fpb, batch);
@@ -294,8 +300,13 @@ void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, i
   };
   // fewer 32-frame workgroups than half the chip's compute units: the one-frame-per-wavefront form
   const bool small = (int64_t)((frames + 31) / 32) * batch < 128;
-  if (small) go(stft_logmel_kernel<8>, 8);
-  else go(stft_logmel_kernel<32>, 32);
+  if (pcm16) {
+    if (small) go(stft_logmel_kernel<8, short>, static_cast<const short*>(wav), 8);
+    else go(stft_logmel_kernel<32, short>, static_cast<const short*>(wav), 32);
+  } else {
+    if (small) go(stft_logmel_kernel<8, float>, static_cast<const float*>(wav), 8);
+    else go(stft_logmel_kernel<32, float>, static_cast<const float*>(wav), 32);
+  }
 }
 
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st) {

@@ -912,7 +912,7 @@ int vasr_melspec_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T = (int)vasr_mel_frames(h, samples);
   launch_seq_len(d_len, batch, h->fe.hop_length, d_seq, st);
-  launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
+  launch_stft_logmel(h->ft, d_wav, false, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
                      h->fe.preemph, h->fe.log_guard, d_mel, T, T, st);
   launch_normalize(d_mel, T, d_seq, batch, h->fe.n_mels, T, h->fe.normalize == 1, st);
   if (h->fe.normalize == 2) launch_normalize_all(d_mel, T, d_seq, batch, h->fe.n_mels, T, st);
@@ -966,7 +966,7 @@ int vasr_ctc_collapse(const int64_t* d_pred, int batch, int64_t frames, int blan
 }
 
 // One contiguous slice of the batch through the whole path on one stream.
-static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+static int transcribe_part(vasr_handle* h, const void* d_wav, bool pcm16, const int64_t* d_len, int batch, int64_t samples,
                            int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
                            char* ws, hipStream_t st) {
   const int64_t T = vasr_mel_frames(h, samples);
@@ -981,7 +981,7 @@ static int transcribe_part(vasr_handle* h, const float* d_wav, const int64_t* d_
     // workgroups) seq = ceil(len / hop) and the encoder's length chain -- three launches fewer on the critical path of a
     // batch-1 call than seq_len + stft + normalize + len_chain
     ProfScope ps(h, kProfFrontend, st);
-    launch_stft_logmel(h->ft, d_wav, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
+    launch_stft_logmel(h->ft, d_wav, pcm16, batch, samples, h->row_independent ? d_len : nullptr, h->fe.hop_length,
                        h->fe.preemph, h->fe.log_guard, melp, p.Tp0, (int)T, st);
     launch_normalize_chain(melp, p.Tp0, d_len, h->fe.hop_length, batch, h->fe.n_mels, (int)T, h->fe.normalize == 1, seq,
                            h->d_steps, (int)h->steps.size(), reinterpret_cast<int32_t*>(ws + p.lens_tab), d_enc_len,
@@ -1024,9 +1024,9 @@ static size_t sliced_workspace_bytes(const vasr_handle* h, int batch, int64_t T)
   return total;
 }
 
-int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
-                               int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
-                               void* d_ws, size_t ws_bytes, vasr_stream stream) {
+static int transcribe_any(vasr_handle* h, const void* d_wav, bool pcm16, const int64_t* d_len, int batch, int64_t samples,
+                          int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                          void* d_ws, size_t ws_bytes, vasr_stream stream) {
   if (!h || !h->finalized || !h->has_frontend || !h->has_encoder || !h->has_decoder)
     return fail(VASR_ERR_STATE, "handle needs a finalized front end, encoder and decoder");
   if (batch <= 0 || !d_wav || !d_len || !d_ws) return fail(VASR_ERR_INVALID, "bad argument");
@@ -1041,7 +1041,7 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
   const int n = n_slices(h, batch);
   const int64_t T1 = vasr_encoded_frames(h, T);
   if (n == 1) {
-    int rc = transcribe_part(h, d_wav, d_len, batch, samples, d_pred, d_ids, d_id_len, d_logp, d_enc_len, ws, user);
+    int rc = transcribe_part(h, d_wav, pcm16, d_len, batch, samples, d_pred, d_ids, d_id_len, d_logp, d_enc_len, ws, user);
     return rc ? rc : check_launch("transcribe");
   }
   if (!h->slice_ready) {
@@ -1058,7 +1058,7 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
     const int lo = (int)((int64_t)batch * i / n), hi = (int)((int64_t)batch * (i + 1) / n);
     hipStream_t st = h->slice_stream[i];
     HIP_TRY(hipStreamWaitEvent(st, h->slice_fork, 0));
-    int rc = transcribe_part(h, d_wav + (int64_t)lo * samples, d_len + lo, hi - lo, samples,
+    int rc = transcribe_part(h, static_cast<const char*>(d_wav) + (int64_t)lo * samples * (pcm16 ? 2 : 4), pcm16, d_len + lo, hi - lo, samples,
                              d_pred ? d_pred + (int64_t)lo * T1 : nullptr, d_ids ? d_ids + (int64_t)lo * T1 : nullptr,
                              d_id_len ? d_id_len + lo : nullptr,
                              d_logp ? d_logp + (int64_t)lo * T1 * h->num_classes : nullptr,
@@ -1069,6 +1069,18 @@ int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t
     HIP_TRY(hipStreamWaitEvent(user, h->slice_done[i], 0));
   }
   return check_launch("transcribe");
+}
+
+int vasr_transcribe_greedy_f32(vasr_handle* h, const float* d_wav, const int64_t* d_len, int batch, int64_t samples,
+                               int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                               void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  return transcribe_any(h, d_wav, false, d_len, batch, samples, d_pred, d_ids, d_id_len, d_logp, d_enc_len, d_ws, ws_bytes, stream);
+}
+
+int vasr_transcribe_greedy_pcm16(vasr_handle* h, const int16_t* d_pcm, const int64_t* d_len, int batch, int64_t samples,
+                                 int64_t* d_pred, int32_t* d_ids, int32_t* d_id_len, float* d_logp, float* d_enc_len,
+                                 void* d_ws, size_t ws_bytes, vasr_stream stream) {
+  return transcribe_any(h, d_pcm, true, d_len, batch, samples, d_pred, d_ids, d_id_len, d_logp, d_enc_len, d_ws, ws_bytes, stream);
 }
 
 int vasr_pcm16_to_f32(const int16_t* d_pcm, int64_t n, float* d_out, vasr_stream stream) {

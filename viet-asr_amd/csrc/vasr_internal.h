@@ -110,8 +110,9 @@ constexpr int kMelTaps = 32;  // >= max non-zeros per Slaney filter at 64 mels /
 
 // row_len: nullptr = the reference's batched semantics (every row is `samples` long, reflect padding at the padded
 // end, quirk Q5); else each row ends at row_len[b] like an unbatched call
-void launch_stft_logmel(const FrontendTables& tb, const float* wav, int batch, int64_t samples, const int64_t* row_len,
-                        int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
+// wav: [batch][samples] float, or (pcm16) int16 PCM scaled by 2^-15 as it is read
+void launch_stft_logmel(const FrontendTables& tb, const void* wav, bool pcm16, int batch, int64_t samples,
+                        const int64_t* row_len, int hop, float preemph, float log_guard, float* mel, int64_t mel_ld, int frames,
                         hipStream_t st);
 void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStream_t st);
 // normalize: 1 = per (utterance, mel bin) row, 0 = mask only; "all_features" = mask only, then launch_normalize_all

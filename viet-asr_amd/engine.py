@@ -83,7 +83,8 @@ class QuartzNetCTC:
         return self._ws
 
     def forward(self, wav, length, want_logp=False, want_pred=True, row_independent=False):
-        """wav [B, L] f32 cuda (rows zero padded), length [B] i64 cuda.
+        """wav [B, L] f32 cuda (rows zero padded) -- or int16 PCM as it sits in a wav file: the front end scales it by 2^-15 as
+        it reads it (vasr_transcribe_greedy_pcm16; the same bits as converting first) --, length [B] i64 cuda.
 
         Returns dict(ids [B,T'] i32, id_len [B] i32, pred [B,T'] i64, enc_len [B] f32, logp or None).
         Everything is enqueued on the current stream; nothing synchronises.
@@ -93,8 +94,8 @@ class QuartzNetCTC:
         that row alone returns, bit for bit (vasr_set_row_independent in include/vasr.h); every length must then
         exceed n_fft / 2, which the caller checks (the lengths live on the device here).
         """
-        if wav.device.type != "cuda" or wav.dtype != torch.float32 or not wav.is_contiguous():
-            raise ValueError("wav must be a contiguous float32 cuda tensor")
+        if wav.device.type != "cuda" or wav.dtype not in (torch.float32, torch.int16) or not wav.is_contiguous():
+            raise ValueError("wav must be a contiguous float32 (or int16 PCM) cuda tensor")
         if length.dtype != torch.int64 or length.device != wav.device:
             raise ValueError("length must be an int64 tensor on the same device")
         B, L = wav.shape
@@ -109,7 +110,8 @@ class QuartzNetCTC:
         if bool(row_independent) != self._row_independent:
             self.handle.set_row_independent(row_independent)
             self._row_independent = bool(row_independent)
-        _lib.check(_lib.lib().vasr_transcribe_greedy_f32(
+        entry = _lib.lib().vasr_transcribe_greedy_pcm16 if wav.dtype == torch.int16 else _lib.lib().vasr_transcribe_greedy_f32
+        _lib.check(entry(
             self.handle.h, wav.data_ptr(), length.data_ptr(), B, L,
             pred.data_ptr() if pred is not None else None, ids.data_ptr(), id_len.data_ptr(),
             logp.data_ptr() if logp is not None else None, enc_len.data_ptr(),
@@ -308,7 +310,7 @@ class _Slot:
 
     def __init__(self, eng):
         self.eng = eng
-        self.pin = self.dev = self.dev_f32 = None
+        self.pin = self.dev = None
         self.pin_len = self.dev_len = None
         self.pin_ids = self.pin_idlen = None
         self.out = None               # device outputs of the batch in flight (kept alive until its results are read)
@@ -321,8 +323,6 @@ class _Slot:
         if self.pin is None or self.pin.numel() < nbytes:
             self.pin = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
             self.dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        if pcm16 and (self.dev_f32 is None or self.dev_f32.numel() < nbytes // 2):
-            self.dev_f32 = torch.empty(nbytes // 2, dtype=torch.float32, device=dev)
         if self.pin_len is None or self.pin_len.numel() < B:
             self.pin_len = torch.empty(B, dtype=torch.int64, pin_memory=True)
             self.dev_len = torch.empty(B, dtype=torch.int64, device=dev)
@@ -361,10 +361,7 @@ class _Slot:
                 self.ev_h2d.record(eng._copy_stream)
             comp.wait_event(self.ev_h2d)
             wav = self.dev[:nbytes].view(dtype).view(B, L)
-            if pcm16:
-                f32 = self.dev_f32[: B * L].view(B, L)
-                _lib.check(_lib.lib().vasr_pcm16_to_f32(wav.data_ptr(), B * L, f32.data_ptr(), comp.cuda_stream))
-                wav = f32
+            # (int16 PCM goes into the front end as it is: scaled by 2^-15 in the STFT kernel's staging load)
             self.out = eng.forward(wav, self.dev_len[:B], want_pred=False, row_independent=row_independent)
             self.pin_ids[: B * t1].copy_(self.out["ids"].view(-1), non_blocking=True)
             self.pin_idlen[:B].copy_(self.out["id_len"], non_blocking=True)
