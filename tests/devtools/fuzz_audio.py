@@ -55,11 +55,18 @@ def greedy_case(case):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    t0, bad = time.time(), 0
+    S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9      # seconds per fuzzer: stop early, still print the summary
+    t00, bad, done = time.time(), 0, []
     for fn in (resample_case, greedy_case):
-        for case in range(N):
+        t0, k = time.time(), 0
+        for case in range(S0, S0 + N):
+            if time.time() - t0 > LIMIT:
+                break
             msg = fn(case)
+            k += 1
             if msg:
                 bad += 1
                 print("MISMATCH", msg, flush=True)
-    print(f"{N} cases each, {bad} mismatches, {time.time() - t0:.0f} s")
+        done.append(k)
+    print(f"{done} cases (resample, greedy) from {S0}, {bad} mismatches, {time.time() - t00:.0f} s")

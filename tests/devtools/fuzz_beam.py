@@ -103,8 +103,12 @@ def _run_mode(case, kind, Tn, bw, lm_kind, alpha, beta, lp, x, path, mode, texts
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9      # seconds: stop early, still print the summary
     t0, bad = time.time(), 0
     for case in range(S0, S0 + N):
+        if time.time() - t0 > LIMIT:
+            N = case - S0
+            break
         msg = run_case(case)
         if msg:
             bad += 1

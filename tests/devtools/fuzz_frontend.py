@@ -72,10 +72,15 @@ def frontend_case(case, tol=2e-4):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    t0, bad = time.time(), 0
-    for case in range(N):
+    S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9      # seconds: stop early, still print the summary
+    t0, bad, done = time.time(), 0, 0
+    for case in range(S0, S0 + N):
+        if time.time() - t0 > LIMIT:
+            break
         msg = frontend_case(case)
+        done += 1
         if msg:
             bad += 1
             print("MISMATCH", msg, flush=True)
-    print(f"{N} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+    print(f"{done} cases from {S0}, {bad} mismatches, {time.time() - t0:.0f} s")
