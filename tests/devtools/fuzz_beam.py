@@ -35,7 +35,61 @@ abc = os.path.join(tmp, "abc.arpa")
 BO.write_arpa(abc, 3, ng, no_backoff=no_bo)
 
 
-STATS = {"cases": 0, "near_tie_excuses": 0, "arpa_mode_cases": 0, "modes_differ": 0}
+STATS = {"cases": 0, "near_tie_excuses": 0, "cut_near_tie_excuses": 0, "arpa_mode_cases": 0, "modes_differ": 0}
+
+
+def oracle_trace(lp, labels, beam_width, lm, flips=()):
+    """beam_oracle.decode_beams' loop, statement for statement, with two additions for the analysis of a disagreement: it records
+    the score gap between the last beam kept and the first beam dropped at every frame's cut, and -- for the frames in `flips` --
+    breaks that cut the OTHER way.  -> (final beams as decode_beams returns them, [(gap, frame, score at the cut)])."""
+    probs = np.exp(np.asarray(lp, dtype=np.float64))
+    logits = np.log(np.clip(probs, BO.MIN_TOKEN_CLIP_P, 1))
+    idx2vocab = list(labels) + [""]
+    cached_lm = {"": (0.0, 0.0, lm.get_start_state())} if lm is not None else {}
+    cached_partial, gaps = {}, []
+    beams = [("", "", "", None, 0.0)]
+    for t, col in enumerate(logits):
+        idx_list = set(np.where(col >= BO.DEFAULT_TOKEN_MIN_LOGP)[0]) | {int(col.argmax())}
+        new_beams = []
+        for idx in sorted(idx_list):
+            p_char, char = col[idx], idx2vocab[idx]
+            for text, next_word, word_part, last_char, logit_score in beams:
+                if char == "" or last_char == char:
+                    new_beams.append((text, next_word, word_part, char, logit_score + p_char))
+                elif char == " ":
+                    new_beams.append((text, word_part, "", char, logit_score + p_char))
+                else:
+                    new_beams.append((text, next_word, word_part + char, char, logit_score + p_char))
+        scored = BO._lm_beams(BO._merge_beams(new_beams), lm, cached_lm, cached_partial)
+        max_score = max(b[-1] for b in scored)
+        scored = [b for b in scored if b[-1] >= max_score + BO.DEFAULT_BEAM_PRUNE_LOGP]
+        scored.sort(key=lambda b: -b[-1])
+        if len(scored) > beam_width:
+            gaps.append((scored[beam_width - 1][-1] - scored[beam_width][-1], t, scored[beam_width - 1][-1]))
+            if t in flips:
+                scored[beam_width - 1], scored[beam_width] = scored[beam_width], scored[beam_width - 1]
+        beams = [b[:-1] for b in scored[:beam_width]]
+    final = [(text, word_part, "", None, logit_score) for text, _, word_part, _, logit_score in beams]
+    scored = BO._lm_beams(BO._merge_beams(final), lm, cached_lm, cached_partial, is_eos=True)
+    max_score = max(b[-1] for b in scored)
+    scored = [b for b in scored if b[-1] >= max_score + BO.DEFAULT_BEAM_PRUNE_LOGP]
+    scored.sort(key=lambda b: -b[-1])
+    return [(" ".join(b[0].split()), b[-2], b[-1]) for b in scored[:beam_width]], gaps
+
+
+def cut_near_tie(lp, bw, path, mode, alpha, beta, text, score):
+    """A disagreement is excused only CONSTRUCTIVELY: some frame's beam cut is a near-tie (the kept and the dropped beam closer than
+    2e-5 * max(1, |score| / 50): a hundredth of the score tolerance, the size of the kernels' float32 LM terms) AND the oracle with
+    that one cut broken the other way returns the device's text with the device's score.  Round-6 campaign, case 129510 (134 frames,
+    width 128): gap 4.2e-6 at score -193.57 on frame 108; flipped there, the oracle gives the device's -207.4049 to the digit."""
+    _, gaps = oracle_trace(lp, T.LABELS, bw, T.oracle_lm(path, mode, alpha, beta))
+    for gap, t, s in sorted(gaps)[:4]:
+        if gap >= 2e-5 * max(1.0, abs(s) / 50):
+            break
+        ref, _ = oracle_trace(lp, T.LABELS, bw, T.oracle_lm(path, mode, alpha, beta), flips={t})
+        if ref[0][0] == text and abs(score - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50):
+            return (gap, t, s)
+    return None
 
 
 def small_alphabet(Tn, V1, seed, k):
@@ -95,6 +149,9 @@ def _run_mode(case, kind, Tn, bw, lm_kind, alpha, beta, lp, x, path, mode, texts
     ok_score = (not ok_text) or text != ref[0][0] or abs(float(score[0]) - ref[0][2]) < 2e-3 * max(1.0, abs(ref[0][2]) / 50)
     if ok_text and ok_score:
         return None
+    if not ok_text and cut_near_tie(lp, bw, path, mode, alpha, beta, text, float(score[0])) is not None:
+        STATS["cut_near_tie_excuses"] += 1
+        return None
     mine = [q for q in ref if q[0] == text]
     return (f"case {case}: kind {kind} T {Tn} beam {bw} lm {lm_kind} {mode} a {alpha} b {beta}: device {text[-30:]!r} {float(score[0]):.4f} | "
             f"oracle {ref[0][0][-30:]!r} {ref[0][2]:.4f} | oracle's score of the device text {[round(float(q[2]), 4) for q in mine][:1]}")
@@ -113,4 +170,4 @@ if __name__ == "__main__":
         if msg:
             bad += 1
             print("MISMATCH", msg, flush=True)
-    print(f"{N} cases, {bad} mismatches, {STATS['near_tie_excuses']} decided by the near-tie allowance, {time.time() - t0:.0f} s")
+    print(f"{N} cases, {bad} mismatches, {STATS['near_tie_excuses']} decided by the near-tie allowance, {STATS['cut_near_tie_excuses']} by a near-tie at a beam cut (oracle re-run with that cut flipped), {time.time() - t0:.0f} s")

@@ -43,10 +43,20 @@ def frontend_case(case, tol=2e-4):
         return f"frontend case {case}: seq {seq.tolist()} vs {wseq.tolist()}"
     if mel.shape != want.shape or raw.shape != wraw.shape:
         return f"frontend case {case}: shape {tuple(mel.shape)} vs {tuple(want.shape)}"
-    # (1) log-mel before normalisation: bins far below the frame's energy carry the FFT's absolute rounding error, hence MEL_TOL
-    err = (raw - wraw).abs().max().item()
-    if err > tol:
-        return f"frontend case {case}: raw log-mel max err {err:.2e} (B {B} L {L} lens {lens.tolist()} amp {amp})"
+    # (1) log-mel before normalisation.  A float32 FFT's rounding error is ABSOLUTE -- a few 2^-24 of the frame's amplitude --, so a
+    # bin far below its frame's peak carries it as a large RELATIVE error, i.e. as an error of its logarithm: two correct float32
+    # front ends differ there (the float32 oracle itself is 2.5e-4 off the float64 front end at a bin 18 nats below the peak,
+    # round-6 campaign, case 100997).  Bound per element: tol + 16 * 2^-24 * (peak amplitude / bin amplitude) -- 1e-5 on top of tol for
+    # bins within 6 nats of the peak, where it matters.
+    d = (raw - wraw).abs()
+    peak = wraw.max(dim=1, keepdim=True).values
+    lim = tol + 16 * 2.0 ** -24 * torch.exp(0.5 * (peak - wraw).clamp(min=0.0).double()).float()
+    valid = (torch.arange(raw.shape[-1])[None, :] < wseq[:, None])[:, None, :]
+    over = (d > lim) & valid
+    if over.any():
+        b, f, t = [int(v) for v in torch.nonzero(over)[0]]
+        return (f"frontend case {case}: raw log-mel row {b} bin {f} frame {t}: {raw[b, f, t].item():.6f} vs {wraw[b, f, t].item():.6f} "
+                f"(limit {lim[b, f, t].item():.2e}, frame peak {peak[b, 0, t].item():.2f}; B {B} L {L} lens {lens.tolist()} amp {amp})")
     # (2) normalised: (x - mean) / (std + 1e-5) turns an error e of x into e / std, and rows whose log-mel barely moves
     # (digital silence: std = 0; bins under the log guard) have std << 1: the bound follows the row's own std
     nan_w, nan_m = torch.isnan(want), torch.isnan(mel)
@@ -58,7 +68,11 @@ def frontend_case(case, tol=2e-4):
             continue
         std = wraw[b, :, :n].double().std(dim=1) + 1e-5
         e_raw = (raw[b, :, :n] - wraw[b, :, :n]).abs().max(dim=1).values.double()      # what (1) let through for this bin
-        bound = (tol + (2 * e_raw + 4e-6) / std).float()[:, None]
+        # the reference's OWN mean is a float32 sum (features.py:21-23 -> ATen's vectorised cascade sum): on a row of 216 equal values
+        # -- digital silence: every frame log(2^-24) -- it is 3 ulp = 5.7e-6 off the value itself, which (x - mean) / (0 + 1e-5)
+        # turns into a constant -0.572 where the exact answer (and the device's, whose statistics are in double) is 0
+        e_mean = (wraw[b, :, :n].mean(dim=1).double() - wraw[b, :, :n].double().mean(dim=1)).abs()
+        bound = (tol + (2 * e_raw + 2 * e_mean + 4e-6) / std).float()[:, None]
         bad = ((mel[b, :, :n] - want[b, :, :n]).abs() > bound)
         if bad.any():
             f, t = [int(v[0]) for v in torch.nonzero(bad)[0:1].T]

@@ -462,6 +462,10 @@ def test_device_beam_search_randomised_cases(gpu):
     from test_gpu_parity import _record
     _record("beam_fuzz", **fuzz_beam.STATS)      # how many of the cases the < 1e-3 near-tie allowance decided
     assert fuzz_beam.STATS["near_tie_excuses"] == 0     # measured (round 5): none of 2 400 cases; the allowance stays for other hosts' numpy
+    # round 6: a 34 738-case campaign met ONE disagreement -- a beam cut whose kept and dropped beams were 4.2e-6 apart at score
+    # -193.57; the oracle re-run with that one cut broken the other way returned the device's text and score to the digit
+    # (fuzz_beam.cut_near_tie).  None of these 400 cases needs that analysis:
+    assert fuzz_beam.STATS["cut_near_tie_excuses"] == 0
 
 
 @pytest.mark.gpu
