@@ -1,4 +1,5 @@
 """-m gpu: HIP path (through the C ABI) vs the golden fixtures of the real reference and vs the oracle."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -561,6 +562,21 @@ def test_random_architectures_and_shapes_match_oracle(gpu, seed, gemm):
     top2 = want.topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 2 * logp_tol(want)   # a flip needs both leading classes inside the tolerance
     assert (r["pred"].cpu()[clear] == ref["pred"][clear]).all()
+
+
+def test_random_architectures_in_batches_of_every_size_class(gpu):
+    """Thirty cases of tests/devtools/fuzz_encoder.py: the random block lists of the test above, half of them with a stack of
+    256-channel K = 33 / 39 sub-blocks, in ragged batches of 1-5 / 6-20 / 21-72 rows of short clips and a randomly drawn GEMM
+    arithmetic -- through the PRODUCT library's own kernel choice (the batch <= 5 latency GEMM, the 512 x 128 ... 128 x 64 tile
+    rule, the fused kernel where it fills the chip).  Round-6 campaign: 2 133 such cases, worst error 0.09 x the tolerance
+    (profiles/r06_fuzz_campaign.txt)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    import fuzz_encoder
+    bad = [m for m in (fuzz_encoder.encoder_case(c) for c in range(30)) if m]
+    assert not bad, bad
+    _record("encoder_fuzz", **{k: (v if not isinstance(v, list) else str(v)) for k, v in fuzz_encoder.STATS.items()})
+    assert min(fuzz_encoder.STATS["by_batch_class"]) > 0
 
 
 def test_five_minute_signal_in_one_pass_matches_oracle(gpu):
