@@ -40,6 +40,15 @@ def blocks_from_config(jasper_cfg):
     return out
 
 
+def _pcm_to_float(s):
+    """Integer PCM -> float32 scaled by 2^-(bits - 1) (AudioSegment._convert_samples_to_float32, parts/segment.py:61-74; exact for
+    int16); anything else unchanged."""
+    dt = getattr(s, "dtype", None)
+    if dt is not None and dt.kind == "i":
+        return s.astype(np.float32) * np.float32(1.0 / 2 ** (8 * dt.itemsize - 1))
+    return s
+
+
 class QuartzNetCTC:
     def __init__(self, model_definition, encoder_state, decoder_state, device="cuda:0", gemm=None):
         """gemm: None (library default: "f16x2"), "f16x2", "bf16x3", "fp32" or the reduced-precision opt-in "bf16x2" --
@@ -141,7 +150,7 @@ class QuartzNetCTC:
                              f"per signal (got {min(lens)})")
         batch = np.zeros((len(signals), max(lens)), dtype=np.float32)
         for i, s in enumerate(signals):
-            batch[i, : lens[i]] = s
+            batch[i, : lens[i]] = _pcm_to_float(s)
         r = self.forward(torch.from_numpy(batch).to(self.device), torch.tensor(lens, device=self.device),
                          want_logp=True, want_pred=False, row_independent=row_independent)
         own = [self.frames(n)[1] for n in lens] if row_independent else None
@@ -351,6 +360,11 @@ class _Slot:
             self._reserve(B, nbytes, t1, pcm16)
             host = self.pin[:nbytes].view(dtype).view(B, L).numpy()
             for i, s in enumerate(signals):
+                if not pcm16:
+                    # a MIXED batch (the serving queue merges whatever arrives): integer PCM rows are scaled here as
+                    # AudioSegment does -- assigned raw they would sit 2^15 too loud next to the float rows (found by
+                    # tests/devtools/stress_serving.py, round 6)
+                    s = _pcm_to_float(s)
                 host[i, : lens[i]] = s
                 host[i, lens[i]:] = 0
             self.pin_len[:B] = torch.tensor(lens, dtype=torch.int64)
