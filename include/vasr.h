@@ -234,7 +234,10 @@ VASR_API int vasr_set_row_independent(vasr_handle* h, int on);
 /* Compute units that another kernel of the caller's keeps busy while this handle's kernels run -- e.g. the beam search of
  * the previous batch on a side stream, one workgroup per utterance (engine.forward_beam).  The GEMM tile choice then
  * fills whole rounds of the REMAINING units: with 64 of 256 taken, 512 x 128 workgroups (one per CU) would need two
- * rounds, the second a third full; 256 x 64 ones quantise four times finer.  0 (default) = the whole device. */
+ * rounds, the second a third full; 256 x 64 ones quantise four times finer.  0 (default) = the whole device.
+ * RESULTS DO NOT DEPEND ON THE HINT: it selects only between forms that give the same bits (GEMM tile shapes, the fused kernel's
+ * tile width); whether a sub-block runs fused follows the batch shape alone (round 6: the hint follows a concurrent kernel's
+ * progress, and with it in that decision the log-probs of a batch depended on timing). */
 VASR_API int vasr_set_busy_cus(vasr_handle* h, int cus);
 
 /* ---- beam search (+ n-gram LM) ------------------------------------------------------------ */

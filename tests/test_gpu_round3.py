@@ -238,6 +238,76 @@ print("FUSED_FUZZ_OK" if not bad else "FUSED_FUZZ_BAD %r" % bad)
 """
 
 
+_FUSED_WIDTHS = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import viet_asr_amd
+from viet_asr_amd import configs, synth
+from viet_asr_amd.engine import QuartzNetCTC
+cfg = configs.builtin("quartznet15x5")
+jas = cfg["JasperEncoder"]["jasper"]
+eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 2), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 2))
+sig, lens = synth.audio_batch(7, 52000, 2, ragged=True)
+eng.handle.profile_begin()
+r = eng.forward(torch.from_numpy(sig).cuda(), torch.from_numpy(lens).cuda(), want_logp=True)
+torch.cuda.synchronize()
+assert eng.handle.profile_end()["fused"]["launches"] == 30
+np.save({out!r}, r["logp"].cpu().numpy())
+"""
+
+
+def test_fused_kernel_gives_the_same_bits_on_64_and_128_frame_tiles(gpu, tmp_path):
+    """The busy-unit hint of an overlapped beam search (vasr_set_busy_cus) may only choose between forms that give the SAME BITS --
+    GEMM tile shapes (test_results_do_not_depend_on_batch_size_or_tile_shape) and the fused kernel's tile WIDTH; whether a sub-block
+    is fused at all follows the batch shape alone (round 6: with the hint in that decision, overlapped and serial runs of one batch
+    differed).  Here the 15x5 model with every 256-channel sub-block forced through the fused kernel on 64-frame and on 128-frame
+    tiles (devtools build): log-probs bit for bit."""
+    import subprocess
+    import sys
+    from viet_asr_amd import _lib
+    dev = os.path.join(os.path.dirname(_lib.LIB_PATH), "libvasr_hip_dev.so")
+    outs = []
+    for tile in ("64", "128"):
+        out = str(tmp_path / f"logp{tile}.npy")
+        code = _FUSED_WIDTHS.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out=out)
+        p = subprocess.run([sys.executable, "-c", code], env={**os.environ, "VASR_LIB_PATH": dev, "VASR_FUSED_MIN_TILES": "1", "VASR_FUSED_TILE": tile},
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+        outs.append(np.load(out))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+
+
+def test_overlapped_beam_search_equals_the_serial_run(gpu, tmp_path):
+    """engine.forward_beam(overlap=True): the search of batch k on a side stream under the acoustic pass of batch k + 1, which is
+    told the busy compute units.  A sequence of batches of changing size, back to back without a synchronisation, against the same
+    batches with overlap=False -- ids, lengths, scores bit for bit (tests/devtools/stress_beam_overlap.py runs this for minutes)."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.beam import BeamSearchDecoder
+    from viet_asr_amd.engine import QuartzNetCTC
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 5))
+    arpa = str(tmp_path / "lm.arpa")
+    synth.synthetic_arpa(arpa, cfg["labels"], n_words=2000, n_bigrams=6000, n_trigrams=6000, seed=1)
+    dec = BeamSearchDecoder(cfg["labels"], lm_path=arpa, alpha=0.5, beta=1.5)
+    rng = np.random.default_rng(1)
+    for _ in range(6):
+        seq = []
+        for B in (40, 46, 13, 64, 47, 1, 33):
+            sig, lens = synth.audio_batch(B, int(rng.integers(9000, 36000)), int(rng.integers(0, 1 << 30)), ragged=True)
+            seq.append((torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu), int(rng.choice([8, 32, 128]))))
+        torch.cuda.synchronize()
+        out = [eng.forward_beam(w, n, dec, bw, overlap=True) for w, n, bw in seq]
+        torch.cuda.synchronize()
+        for (w, n, bw), a in zip(seq, out):
+            r = eng.forward_beam(w, n, dec, bw, overlap=False)
+            torch.cuda.synchronize()
+            assert torch.equal(a["id_len"], r["id_len"]) and torch.equal(a["score"], r["score"]), (w.shape, bw)
+            for b in range(w.shape[0]):
+                k = int(r["id_len"][b])
+                assert torch.equal(a["ids"][b, :k], r["ids"][b, :k]), (w.shape, bw, b)
+
+
 @pytest.mark.parametrize("tile", ["128", "64"])
 def test_fused_depthwise_pointwise_kernel_on_random_shapes(gpu, tile):
     """The fused sub-block kernel -- its 128-frame and (round 4) its 64-frame tile -- forced onto small random workloads

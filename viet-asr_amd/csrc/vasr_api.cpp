@@ -650,8 +650,20 @@ int run_encoder(vasr_handle* h, const float* x, int64_t x_ld, int64_t T, const i
       // 192 CUs a 64-utterance search leaves free are 1.33 rounds)
       const int f_cus = h->busy_cus > 0 && h->busy_cus < n_cu - 32 ? n_cu - h->busy_cus : n_cu;
       const int64_t f_tiles = (int64_t)batch * (cur_ld / kTimeTile);
-      const int f_rule = fused_tile_choice(f_tiles, f_cus);
-      const int f_cols = fused_tile == 64 || fused_tile == 128 ? fused_tile : (f_rule ? f_rule : 128);
+      // WHETHER a sub-block is fused is a function of the batch's shape ALONE (the whole chip's unit count): the fused and the
+      // two-kernel form round differently, and the busy-unit hint follows a concurrent kernel's progress -- with the hint in this
+      // decision the log-probs of one and the same batch depended on whether the previous search had finished (round 6,
+      // tests/devtools/stress_beam_overlap.py: 196 of 11 594 overlapped batches differed from their serial run).  The hint only
+      // picks the TILE WIDTH of a sub-block that is fused anyway: 64- and 128-frame tiles give the same bits.
+      const int f_rule = fused_tile_choice(f_tiles, n_cu);
+      int f_auto = f_rule ? f_rule : 128;
+      if (f_rule && f_cus < n_cu) {
+        // lock-stepped rounds on the free units: a 64-frame tile costs ~0.6 of a 128-frame one (17 vs 29.7 us a round); 256 tiles on
+        // the 192 units a 64-utterance search leaves: 2 rounds of 128 frames = 2.0 against 3 rounds of 64 = 1.8
+        const int64_t r128 = (f_tiles + f_cus - 1) / f_cus, r64 = (2 * f_tiles + f_cus - 1) / f_cus;
+        f_auto = 0.6 * (double)r64 < (double)r128 ? 64 : 128;
+      }
+      const int f_cols = fused_tile == 64 || fused_tile == 128 ? fused_tile : f_auto;
       const bool f_fill = fused_min_tiles > 0 ? f_tiles >= fused_min_tiles : (fused_tile ? f_rule == fused_tile : f_rule != 0);
       const bool fuse_res = last_sub && B.fused_res;
       const ConvLayer& WF = fuse_res ? B.fused : S.pw;
