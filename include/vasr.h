@@ -216,7 +216,9 @@ VASR_API int vasr_resample_f32(const float* d_in, int64_t ld_in, const int64_t* 
 /* The fused call can cut the batch into `slices` contiguous parts (1..4; default 1 = off, because on MI355X it
  * measured slower: 11.7 -> 13.5 ms at 2 slices) and run each on its own
  * internal HIP stream, forked from / joined to `stream` with events: one part's HBM-bound kernels (depthwise,
- * GEMM epilogue stores) then overlap another part's MFMA-bound GEMM main loops.  Results do not depend on it. */
+ * GEMM epilogue stores) then overlap another part's MFMA-bound GEMM main loops.  In row-independent mode results do not depend
+ * on it; in the default mode every slice is a batch of its own for the shape-dependent choice between the fused and the
+ * two-kernel form of a 256-channel sub-block (same tolerance, different rounding: vasr_set_gemm_mode, mode 3). */
 VASR_API int vasr_set_slices(vasr_handle* h, int slices);
 
 /* Row-independent batching (net-new; default off = the reference's batched semantics).  The reference's results

@@ -277,6 +277,30 @@ def test_fused_kernel_gives_the_same_bits_on_64_and_128_frame_tiles(gpu, tmp_pat
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
 
+def test_default_mode_is_run_to_run_deterministic(gpu):
+    """The same batch through the default (batched, fused where it pays) path twenty times, a second stream keeping part of the chip
+    busy half of the time: log-probs, predictions and ids bit for bit every time (maxima are published as integer max, nothing on the
+    greedy path accumulates through float atomics)."""
+    from viet_asr_amd import configs, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    cfg = configs.builtin("quartznet15x5")
+    jas = cfg["JasperEncoder"]["jasper"]
+    eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 4), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 4))
+    sig, lens = synth.audio_batch(40, 40000, 4, ragged=True)
+    w, n = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    first = eng.forward(w, n, want_logp=True)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=gpu)
+    for i in range(20):
+        if i % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    junk = (junk @ junk).clamp_(-1, 1)
+        r = eng.forward(w, n, want_logp=True)
+        assert torch.equal(r["logp"], first["logp"]) and torch.equal(r["pred"], first["pred"]) and torch.equal(r["id_len"], first["id_len"]), i
+    torch.cuda.synchronize()
+
+
 def test_overlapped_beam_search_equals_the_serial_run(gpu, tmp_path):
     """engine.forward_beam(overlap=True): the search of batch k on a side stream under the acoustic pass of batch k + 1, which is
     told the busy compute units.  A sequence of batches of changing size, back to back without a synchronisation, against the same
