@@ -134,7 +134,11 @@ VASR_API int vasr_encoder_f32(vasr_handle* h, const float* d_mel, const int64_t*
                      vasr_stream stream);
 
 /* JasperDecoderForCTC.forward (jasper.py:253-254): conv1x1+bias -> transpose -> log_softmax.
- *   d_enc [B][dec_feat_in][T'] f32 contiguous -> d_logp [B][T'][V+1] f32 */
+ *   d_enc [B][dec_feat_in][T'] f32 contiguous -> d_logp [B][T'][V+1] f32
+ * Workspace: align256(B * dec_feat_in * ld * 4) + B * (V+1) * ld * 4 bytes with ld = vasr_padded_frames(T'); with
+ * align256(that) + B * 1024 bytes the maxima of the port tensor are taken first and the head GEMM runs in the handle's GEMM mode
+ * like the fused path's (the same bits as vasr_transcribe_greedy_f32 on the same encoder output); with less, mode 3 falls back
+ * to the 3 x bf16 form (same tolerance). */
 VASR_API int vasr_decoder_logsoftmax_f32(vasr_handle* h, const float* d_enc, int batch, int64_t enc_frames,
                                 float* d_logp, void* d_workspace, size_t workspace_bytes, vasr_stream stream);
 

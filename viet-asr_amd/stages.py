@@ -75,6 +75,7 @@ def decoder(handle, encoder_output):
     V = handle.num_classes
     ld = int(_lib.lib().vasr_padded_frames(T1))
     need = ((B * C * ld * 4 + 255) // 256) * 256 + B * V * ld * 4
+    need = ((need + 255) // 256) * 256 + B * 1024       # + the maxima table of the port tensor (fp16-split head, vasr.h)
     ws = _workspace(x.device, need)
     logp = torch.empty((B, T1, V), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().vasr_decoder_logsoftmax_f32(handle.h, x.data_ptr(), B, T1, logp.data_ptr(),
