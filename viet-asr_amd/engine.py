@@ -212,7 +212,10 @@ class QuartzNetCTC:
         ``chunk_frames`` OUTPUT frames, each extended by the receptive-field halo on both sides (``halo_mel_frames``;
         zero padding only where the recording really ends), ``rows_per_pass`` windows at a time as the rows of one batch.
         Frames inside a window's halo are discarded, the kept ones see exactly the inputs of the one-pass computation:
-        same predictions, same log-probs.  Returns dict(ids, id_len, pred, enc_len, logp or None, workspace_bytes)."""
+        the same log-probs and predictions BIT FOR BIT in the fp32 and 3 x bf16 arithmetics; in the default 2 x fp16 one the operand
+        scale follows the row a kernel works on (a window here, the recording there), the log-probs agree within the parity
+        tolerance and a frame whose two best classes are closer than that may decode differently (round-6 campaign,
+        tests/devtools/fuzz_long.py: 14 444 exact cases bit-equal; 2 such frames in 7 048 f16x2 recordings).  Returns dict(ids, id_len, pred, enc_len, logp or None, workspace_bytes)."""
         from . import stages
         if wav.dim() != 1 or wav.device.type != "cuda" or wav.dtype != torch.float32:
             raise ValueError("wav must be a 1-D float32 cuda tensor")
