@@ -36,6 +36,42 @@ def asr_for(model):
     return _ASR[model]
 
 
+_BEAM = {}
+
+
+def beam_asr_for(model):
+    if model not in _BEAM:
+        cfg = configs.builtin(model)
+        jas = cfg["JasperEncoder"]["jasper"]
+        d = tempfile.mkdtemp(prefix="vasr_dagb_")
+        enc_p, dec_p = os.path.join(d, "JasperEncoder-STEP-1.pt"), os.path.join(d, "JasperDecoderForCTC-STEP-1.pt")
+        torch.save({k: torch.as_tensor(v) for k, v in synth.encoder_state_dict(jas, 64, 8).items()}, enc_p)
+        torch.save({k: torch.as_tensor(v) for k, v in synth.decoder_state_dict(jas[-1]["filters"], len(cfg["labels"]) + 1, 8).items()}, dec_p)
+        arpa = os.path.join(d, "lm.arpa")
+        synth.synthetic_arpa(arpa, cfg["labels"], n_words=3000, n_bigrams=8000, n_trigrams=8000, seed=8)
+        _BEAM[model] = VietASR(model, enc_p, dec_p, device="gpu", decoder="beam", lm_path=arpa, beam_width=16)
+    return _BEAM[model]
+
+
+def dag_beam_case(case):
+    """The beam wiring (infer.py:132-160: BeamSearchDecoderWithLM behind the decoder module, one utterance per call) against
+    transcribe_batch(decoder="beam", row_independent=True), which promises "the transcripts of batch-1 calls"."""
+    rng = np.random.default_rng(400000 + case)
+    asr = beam_asr_for("quartznet12x1_vi")
+    B = int(rng.choice([1, int(rng.integers(2, 7)), int(rng.integers(7, 20))]))
+    sigs = [(float(rng.choice([0.004, 0.06, 0.5])) * rng.standard_normal(int(rng.integers(3200, 64000)))).astype(np.float32) for _ in range(B)]
+    fused = asr.transcribe_batch(sigs, decoder="beam", row_independent=True)
+    STATS["cases"] += 1
+    for i, s in enumerate(sigs):
+        one = asr.transcribe(s)
+        STATS["signals"] += 1
+        STATS["chars"] += len(one)
+        if one != fused[i]:
+            STATS["differ"] += 1
+            return f"dag beam case {case}: row {i} of {B} (n {len(s)}): DAG {one[:40]!r} vs batch {fused[i][:40]!r}"
+    return None
+
+
 def dag_case(case):
     rng = np.random.default_rng(300000 + case)
     asr = asr_for(str(rng.choice(["quartznet12x1_vi", "quartznet12x1_vi", "quartznet15x5"])))
@@ -65,11 +101,12 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+    fn = dag_beam_case if len(sys.argv) > 4 and sys.argv[4] == "beam" else dag_case
     t0, bad = time.time(), 0
     for case in range(S0, S0 + N):
         if time.time() - t0 > LIMIT:
             break
-        msg = dag_case(case)
+        msg = fn(case)
         if msg:
             bad += 1
             if bad <= 12:
