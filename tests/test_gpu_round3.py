@@ -277,6 +277,60 @@ def test_fused_kernel_gives_the_same_bits_on_64_and_128_frame_tiles(gpu, tmp_pat
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
 
+def test_results_hold_next_to_foreign_matrix_kernels_and_across_threads(gpu):
+    """Round 6: a second stream running 16-bit matrix kernels -- torch's own fp16 bmm, or this library from another handle -- made
+    the front end return wrong values: packed-FP32 vector instructions (the FFT) and FP64 arithmetic (the normalisation statistics)
+    of a wavefront are not safe on MI355X while such a kernel shares its compute unit (profiles/r06_concurrency.txt; nothing goes
+    through memory).  The STFT kernel is now built without packed-FP32 instructions, the normalisation kernels run alone on their
+    compute unit.  Here: the front end, whole forwards in two arithmetics and a beam search, 1.5 s each next to the attacker
+    (tests/devtools/stress_attack.py runs every entry point for longer); then two host threads on two handles and two streams
+    (stress_threads.py), every result against the idle-device one, bit for bit."""
+    import sys
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    import stress_attack
+    from viet_asr_amd import configs, stages, synth
+    from viet_asr_amd.engine import QuartzNetCTC
+    cfg = configs.builtin("quartznet12x1_vi")
+    jas = cfg["JasperEncoder"]["jasper"]
+    sd = synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 5)
+    eng, eng_b = QuartzNetCTC(cfg, sd[0], sd[1]), QuartzNetCTC(cfg, sd[0], sd[1], gemm="bf16x3")
+    sig, lens = synth.audio_batch(8, 48000, 3, ragged=True)
+    w, n = torch.from_numpy(sig).to(gpu), torch.from_numpy(lens).to(gpu)
+    for name, fn in (("melspec", lambda: stages.melspec(eng.handle, w, n)), ("forward f16x2", lambda: eng.forward(w, n, want_logp=True)),
+                     ("forward bf16x3", lambda: eng_b.forward(w, n, want_logp=True))):
+        calls, wrong = stress_attack.attack(fn, 1.5)
+        assert calls > 50 and wrong == 0, (name, calls, wrong)
+    # two threads, two handles, two streams
+    pool = []
+    for i, (B, L) in enumerate([(1, 30000), (5, 20000), (14, 12000), (40, 9000)]):
+        s_, l_ = synth.audio_batch(B, L, 50 + i, ragged=True)
+        pool.append((torch.from_numpy(s_).to(gpu), torch.from_numpy(l_).to(gpu)))
+    want = [eng.forward(a, b, want_logp=True)["logp"].clone() for a, b in pool]
+    torch.cuda.synchronize()
+    eng2 = QuartzNetCTC(cfg, sd[0], sd[1])
+    stop, wrong, calls = [False], [0, 0], [0, 0]
+
+    def worker(k, e):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            while not stop[0]:
+                for i, (a, b) in enumerate(pool):
+                    r = e.forward(a, b, want_logp=True)
+                    st.synchronize()
+                    calls[k] += 1
+                    wrong[k] += int(not torch.equal(r["logp"], want[i]))
+    ths = [threading.Thread(target=worker, args=(0, eng)), threading.Thread(target=worker, args=(1, eng2))]
+    for t in ths:
+        t.start()
+    import time
+    time.sleep(3.0)
+    stop[0] = True
+    for t in ths:
+        t.join()
+    assert min(calls) > 100 and wrong == [0, 0], (calls, wrong)
+
+
 def test_default_mode_is_run_to_run_deterministic(gpu):
     """The same batch through the default (batched, fused where it pays) path twenty times, a second stream keeping part of the chip
     busy half of the time: log-probs, predictions and ids bit for bit every time (maxima are published as integer max, nothing on the

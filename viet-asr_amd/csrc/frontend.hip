@@ -9,6 +9,8 @@
 // 256-point complex radix-4 Stockham FFT (4 LDS-exchanged stages, 4 points per lane) and the
 // even/odd split.  The 64 mel filters map one-per-lane; the [64 mel][32 frame] tile goes
 // back to HBM as 128-byte row segments.
+#include <atomic>
+
 #include "vasr_internal.h"
 #include "len_chain.h"
 
@@ -201,8 +203,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // of its own (5-10 us of dependent scalar arithmetic) in front of the encoder.
 __device__ __forceinline__ int64_t seq_of(int64_t len, int hop) { return (int64_t)ceilf((float)len / (float)hop); }
 
+// (kRowsPerWg rows per workgroup, four wavefronts each: the workgroup is alone on its compute unit -- launch_normalize below --, so
+// it brings its own occupancy.  `red`: the row group's eight doubles.)
+constexpr int kRowsPerWg = 4;
 __device__ __forceinline__ void normalize_row(float* __restrict__ x, int n, int frames, int normalize, double* red) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
   float mean = 0.f, stdv = 1.f;
   if (normalize) {
     double s = 0.0;
@@ -227,13 +232,14 @@ __device__ __forceinline__ void normalize_row(float* __restrict__ x, int n, int 
   }
 }
 
-__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ mel, int64_t ld,
-                                                        const int64_t* __restrict__ seq, int rows, int n_mels,
-                                                        int frames, int normalize) {
-  __shared__ double red[8];
-  const int row = blockIdx.x;
+__global__ __launch_bounds__(256 * kRowsPerWg) void normalize_kernel(float* __restrict__ mel, int64_t ld,
+                                                                     const int64_t* __restrict__ seq, int rows, int n_mels,
+                                                                     int frames, int normalize) {
+  __shared__ double red[kRowsPerWg][8];
+  const int grp = threadIdx.x >> 8;
+  const int row = min((int)blockIdx.x * kRowsPerWg + grp, rows - 1);   // (rows = batch x 64: a multiple of four; clamped, not skipped: barriers)
   const int64_t n64 = seq[row / n_mels];
-  normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red);
+  normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red[grp]);
 }
 
 // normalize_batch("all_features") (features.py:31-39): ONE mean and one unbiased std per utterance over every mel bin and
@@ -266,21 +272,22 @@ __global__ __launch_bounds__(256) void normalize_all_kernel(float* __restrict__ 
     for (int t = tid; t < n; t += 256) x[(int64_t)f * ld + t] = (x[(int64_t)f * ld + t] - mean) / stdv;
 }
 
-__global__ __launch_bounds__(256) void normalize_chain_kernel(float* __restrict__ mel, int64_t ld,
+__global__ __launch_bounds__(256 * kRowsPerWg) void normalize_chain_kernel(float* __restrict__ mel, int64_t ld,
                                                               const int64_t* __restrict__ len, int hop, int batch, int n_mels,
                                                               int frames, int normalize, int64_t* __restrict__ seq,
                                                               const LenStep* __restrict__ steps, int n_steps,
                                                               int32_t* __restrict__ lens_tab, float* __restrict__ enc_len,
                                                               const int64_t* __restrict__ wav_len, int frames_cap) {
-  __shared__ double red[8];
-  const int rows = batch * n_mels;
-  if ((int)blockIdx.x < rows) {
-    const int row = blockIdx.x;
+  __shared__ double red[kRowsPerWg][8];
+  const int rows = batch * n_mels, row_wgs = (rows + kRowsPerWg - 1) / kRowsPerWg;
+  if ((int)blockIdx.x < row_wgs) {
+    const int grp = threadIdx.x >> 8;
+    const int row = min((int)blockIdx.x * kRowsPerWg + grp, rows - 1);
     const int64_t n64 = seq_of(len[row / n_mels], hop);
-    normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red);
+    normalize_row(mel + (int64_t)row * ld, (int)(n64 < 0 ? 0 : (n64 > frames ? frames : n64)), frames, normalize, red[grp]);
     return;
   }
-  const int b = ((int)blockIdx.x - rows) * 256 + (int)threadIdx.x;
+  const int b = ((int)blockIdx.x - row_wgs) * 256 * kRowsPerWg + (int)threadIdx.x;
   const int64_t l0 = b < batch ? seq_of(len[b], hop) : 0;
   if (b < batch) seq[b] = l0;
   len_chain_body(b, l0, batch, steps, n_steps, lens_tab, enc_len, wav_len, hop, frames_cap);
@@ -313,21 +320,38 @@ void launch_seq_len(const int64_t* len, int batch, int hop, int64_t* seq, hipStr
   hipLaunchKernelGGL(seq_len_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, len, batch, hop, seq);
 }
 
+// The normalisation kernels keep their statistics in double (ATen's accumulation type: the reference's bits), and on MI355X a
+// wavefront's FP64 arithmetic returned WRONG VALUES while a wavefront of a 16-bit MFMA kernel from ANOTHER stream shared its compute
+// unit (round 6, tests/devtools/stress_attack.py: the per-row mean / std came out wrong in 1.5-8 % of the calls next to torch's own
+// fp16 bmm; profiles/r06_concurrency.txt).  These kernels are small (four wavefronts, 64 bytes of LDS), i.e. exactly what the
+// dispatcher slots in beside somebody else's workgroups.  They therefore ask for (almost) a whole compute unit's LDS, which keeps
+// every workgroup that needs LDS of its own -- a matrix kernel stages its operands there -- off the unit while one of them runs:
+// four rows per 1 024-thread workgroup keep the unit as full as four 256-thread workgroups did.
+constexpr int kAloneLds = 152 * 1024;   // + <= 4 160 bytes static; the unit has 160 KB
+
 void launch_normalize_all(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames, hipStream_t st) {
-  hipLaunchKernelGGL(normalize_all_kernel, dim3(batch), dim3(256), 0, st, mel, mel_ld, seq, n_mels, frames);
+  static std::atomic<uint64_t> opted{0};
+  (void)dyn_lds_opt_in(reinterpret_cast<const void*>(normalize_all_kernel), kAloneLds, opted);
+  hipLaunchKernelGGL(normalize_all_kernel, dim3(batch), dim3(256), kAloneLds, st, mel, mel_ld, seq, n_mels, frames);
 }
 
 void launch_normalize(float* mel, int64_t mel_ld, const int64_t* seq, int batch, int n_mels, int frames,
                       int normalize, hipStream_t st) {
   const int rows = batch * n_mels;
-  hipLaunchKernelGGL(normalize_kernel, dim3(rows), dim3(256), 0, st, mel, mel_ld, seq, rows, n_mels, frames, normalize);
+  static std::atomic<uint64_t> opted{0};
+  (void)dyn_lds_opt_in(reinterpret_cast<const void*>(normalize_kernel), kAloneLds, opted);
+  hipLaunchKernelGGL(normalize_kernel, dim3((rows + kRowsPerWg - 1) / kRowsPerWg), dim3(256 * kRowsPerWg), normalize ? kAloneLds : 0, st, mel, mel_ld,
+                     seq, rows, n_mels, frames, normalize);
 }
 
 void launch_normalize_chain(float* mel, int64_t mel_ld, const int64_t* len, int hop, int batch, int n_mels, int frames,
                             int normalize, int64_t* seq, const LenStep* d_steps, int n_steps, int32_t* lens_tab,
                             float* enc_len, const int64_t* wav_len, int frames_cap, hipStream_t st) {
   const int rows = batch * n_mels;
-  hipLaunchKernelGGL(normalize_chain_kernel, dim3(rows + (batch + 255) / 256), dim3(256), 0, st, mel, mel_ld, len, hop, batch,
+  static std::atomic<uint64_t> opted{0};
+  (void)dyn_lds_opt_in(reinterpret_cast<const void*>(normalize_chain_kernel), kAloneLds, opted);
+  const int wg = 256 * kRowsPerWg;
+  hipLaunchKernelGGL(normalize_chain_kernel, dim3((rows + kRowsPerWg - 1) / kRowsPerWg + (batch + wg - 1) / wg), dim3(wg), normalize ? kAloneLds : 0, st, mel, mel_ld, len, hop, batch,
                      n_mels, frames, normalize, seq, d_steps, n_steps, lens_tab, enc_len, wav_len, frames_cap);
 }
 
