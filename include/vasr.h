@@ -13,6 +13,11 @@
  * thread-local human readable message for the last failure.
  * Re-entrancy: calls on distinct handles, or on one handle with distinct workspaces and
  * streams, may run concurrently; there is no global mutable state besides the error string.
+ * Round 6 made that true ON THE DEVICE as well: next to 16-bit matrix kernels of another stream -- a second handle of this
+ * library, or anybody else's GEMM -- packed-FP32 and FP64 vector arithmetic of a small kernel returned wrong values on MI355X
+ * (profiles/r06_concurrency.txt); the front end no longer contains the first and runs the second alone on its compute unit.
+ * tests/devtools/stress_attack.py and stress_threads.py are the harnesses: every entry point next to torch's fp16 bmm, and
+ * N host threads on N streams, each result against the idle-device one bit for bit.
  */
 #ifndef VASR_H_
 #define VASR_H_
