@@ -119,11 +119,22 @@ def attack(fn, secs, attacker=None):
     return calls[0], bad[0]
 
 
+def attackers():
+    dev = "cuda"
+    ab = torch.randn(512, 64, 64, device=dev, dtype=torch.float16)
+    a16, b16 = torch.randn(5120, 256, device=dev, dtype=torch.bfloat16), torch.randn(256, 256, device=dev, dtype=torch.bfloat16)
+    a8, b8 = torch.randn(2048, 1024, device=dev, dtype=torch.float16), torch.randn(1024, 128, device=dev, dtype=torch.float16)
+    return {"bmm16": lambda: torch.bmm(ab, ab), "matmul_bf16": lambda: a16 @ b16, "matmul_f16_thin": lambda: a8 @ b8}
+
+
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+    which = sys.argv[2] if len(sys.argv) > 2 else "bmm16"      # bmm16 | matmul_bf16 | matmul_f16_thin
+    att = attackers()[which]
+    print(f"attacker: {which}")
     total_bad = 0
     for name, fn in cases():
-        calls, bad = attack(fn, secs)
+        calls, bad = attack(fn, secs, att)
         total_bad += bad
         print(f"{name:70s}: calls {calls:6d} wrong {bad}", flush=True)
     print(f"TOTAL wrong {total_bad}")
