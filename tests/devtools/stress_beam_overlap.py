@@ -26,7 +26,8 @@ from viet_asr_amd.engine import QuartzNetCTC  # noqa: E402
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    cfg = configs.builtin("quartznet12x1_vi")
+    model = sys.argv[3] if len(sys.argv) > 3 else "quartznet12x1_vi"      # quartznet15x5: BASELINE configs[3]'s own model and batch sizes
+    cfg = configs.builtin(model)
     jas = cfg["JasperEncoder"]["jasper"]
     eng = QuartzNetCTC(cfg, synth.encoder_state_dict(jas, 64, 5), synth.decoder_state_dict(1024, len(cfg["labels"]) + 1, 5))
     arpa = os.path.join(tempfile.mkdtemp(prefix="vasr_stress_"), "lm.arpa")
@@ -39,6 +40,8 @@ def main():
         for _ in range(int(rng.integers(3, 12))):
             B = int(rng.choice([1, int(rng.integers(2, 16)), int(rng.integers(16, 71))]))
             L = int(rng.integers(8000, 96000)) if B < 16 else int(rng.integers(8000, 40000))
+            if model == "quartznet15x5" and rng.random() < 0.5:
+                B, L = 64, 160000                                                    # configs[3] itself
             sig, lens = synth.audio_batch(B, L, int(rng.integers(0, 1 << 30)), ragged=True)
             seq.append((torch.from_numpy(sig).cuda(), torch.from_numpy(lens).cuda(), int(rng.choice([8, 32, 128]))))
         torch.cuda.synchronize()
@@ -56,7 +59,7 @@ def main():
             batches += 1
             rows += int(w.shape[0])
         rounds += 1
-    print(json.dumps({"seconds": round(time.time() - t0, 1), "sequences": rounds, "batches": batches, "rows": rows, "differences": len(diffs), "first": diffs[:4]}))
+    print(json.dumps({"model": model, "seconds": round(time.time() - t0, 1), "sequences": rounds, "batches": batches, "rows": rows, "differences": len(diffs), "first": diffs[:4]}))
 
 
 if __name__ == "__main__":
