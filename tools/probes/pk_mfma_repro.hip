@@ -72,7 +72,7 @@ int run(const char* name, bool attack, int launches) {
   hipMemcpy(want.data(), d_out, want.size() * 4, hipMemcpyDeviceToHost);
   int bad_launches = 0; long bad_values = 0;
   for (int l = 0; l < launches; ++l) {
-    if (attack) for (int k = 0; k < 6; ++k) hipLaunchKernelGGL(attacker, dim3(2048), dim3(128), 24 * 1024, sb, d_sink, 4000);
+    if (attack) for (int k = 0; k < 40; ++k) hipLaunchKernelGGL(attacker, dim3(2048), dim3(128), 24 * 1024, sb, d_sink, 600);
     hipLaunchKernelGGL(victim<MODE>, dim3(blocks), dim3(512), 0, sa, d_out, iters);
     hipStreamSynchronize(sa);
     hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost);
