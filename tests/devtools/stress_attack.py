@@ -124,12 +124,28 @@ def attackers():
     ab = torch.randn(512, 64, 64, device=dev, dtype=torch.float16)
     a16, b16 = torch.randn(5120, 256, device=dev, dtype=torch.bfloat16), torch.randn(256, 256, device=dev, dtype=torch.bfloat16)
     a8, b8 = torch.randn(2048, 1024, device=dev, dtype=torch.float16), torch.randn(1024, 128, device=dev, dtype=torch.float16)
-    return {"bmm16": lambda: torch.bmm(ab, ab), "matmul_bf16": lambda: a16 @ b16, "matmul_f16_thin": lambda: a8 @ b8}
+    out = {"bmm16": lambda: torch.bmm(ab, ab), "matmul_bf16": lambda: a16 @ b16, "matmul_f16_thin": lambda: a8 @ b8}
+    # "mfma": tools/probes/mfma_attacker.hip -- nothing but v_mfma_f32_32x32x16_f16 in a loop, 128-thread workgroups with 24 KB (or
+    # "mfma0": no) LDS; against the front end of commit 25e1455 the most reliable attacker of all (6 210 of 6 213 calls wrong).
+    # Compiled on first use (hipcc is on the GPU box) into the system's temporary directory.
+    def synthetic(lds):
+        import ctypes as C, subprocess, tempfile
+        so = os.path.join(tempfile.gettempdir(), "vasr_mfma_attacker.so")
+        src = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "probes", "mfma_attacker.hip")
+        if not os.path.exists(so):
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", src, "-o", so], check=True, capture_output=True)
+        lib = C.CDLL(so)
+        lib.mfma_attacker_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        sink = torch.zeros(1 << 18, device=dev)
+        return lambda: lib.mfma_attacker_launch(2048, lds, 600, 0, sink.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    out["mfma"] = lambda f=[None]: (f.__setitem__(0, f[0] or synthetic(24576)), f[0]())[1]
+    out["mfma0"] = lambda f=[None]: (f.__setitem__(0, f[0] or synthetic(0)), f[0]())[1]
+    return out
 
 
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-    which = sys.argv[2] if len(sys.argv) > 2 else "bmm16"      # bmm16 | matmul_bf16 | matmul_f16_thin
+    which = sys.argv[2] if len(sys.argv) > 2 else "bmm16"      # bmm16 | matmul_bf16 | matmul_f16_thin | mfma | mfma0
     att = attackers()[which]
     print(f"attacker: {which}")
     total_bad = 0
