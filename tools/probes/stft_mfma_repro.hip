@@ -9,11 +9,16 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #include "vasr_internal.h"
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+#ifndef MODE_NORMALIZE
+#define MODE_NORMALIZE 0
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
 
 __global__ __launch_bounds__(128, 2) void attacker(float* sink, int iters) {
@@ -32,7 +37,8 @@ __global__ __launch_bounds__(128, 2) void attacker(float* sink, int iters) {
 
 template <class T> static T* up(const std::vector<T>& v) { T* d = nullptr; hipMalloc(&d, v.size() * sizeof(T)); hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return d; }
 
-int main() {
+int main(int argc, char** argv) {
+  const int pace_us = argc > 1 ? atoi(argv[1]) : 0;
   const int B = 64, L = 160000, hop = 160, T = 1 + L / hop;
   // front-end tables as vasr_api.cpp build_frontend makes them: hann(320) centred in 512, the two twiddle tables, 64 triangular filters
   std::vector<float> win(512, 0.f), tw256(512), tw512(2 * 258, 0.f), mw(64 * vasr::kMelTaps, 0.f);
@@ -48,10 +54,23 @@ int main() {
   float* d_wav = up(wav);
   float *d_mel, *d_sink;
   CK(hipMalloc(&d_mel, (size_t)B * 64 * T * 4)); CK(hipMalloc(&d_sink, 4096));
-  hipStream_t sa, sb;
-  CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  // (HIP deals streams to a few hardware queues in turn: several are created and two far apart are used, so that victim and attacker do
+  //  not end up serialised behind each other in one queue)
+  hipStream_t pool[8];
+  for (auto& q : pool) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+  hipStream_t sa = pool[1], sb = pool[2 + (argc > 2 ? atoi(argv[2]) : 0)];
   std::vector<float> want((size_t)B * 64 * T), got(want.size());
-  vasr::launch_stft_logmel(tb, d_wav, false, B, L, nullptr, hop, 0.97f, 5.9604645e-8f, d_mel, T, T, sa);
+  // the three launches of vasr_melspec_f32 (normalisation off: the third one only masks the frames past each row's length)
+  std::vector<int64_t> lens(B, L);
+  int64_t* d_len = up(lens);
+  int64_t* d_seq = nullptr;
+  CK(hipMalloc(&d_seq, B * 8));
+  auto melspec = [&]() {
+    vasr::launch_seq_len(d_len, B, hop, d_seq, sa);
+    vasr::launch_stft_logmel(tb, d_wav, false, B, L, nullptr, hop, 0.97f, 5.9604645e-8f, d_mel, T, T, sa);
+    vasr::launch_normalize(d_mel, T, d_seq, B, 64, T, MODE_NORMALIZE, sa);
+  };
+  melspec();
   CK(hipStreamSynchronize(sa));
   CK(hipMemcpy(want.data(), d_mel, want.size() * 4, hipMemcpyDeviceToHost));
   for (int phase = 0; phase < 2; ++phase) {
@@ -62,11 +81,15 @@ int main() {
       while (phase && !stop.load()) {
         hipLaunchKernelGGL(attacker, dim3(2048), dim3(128), 24 * 1024, sb, d_sink, 600);
         (void)hipStreamSynchronize(sb);
+        if (pace_us) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));   // a Python client's pace between launches
       }
     });
+    double dev_us = 0;
     for (int l = 0; l < launches; ++l) {
-      vasr::launch_stft_logmel(tb, d_wav, false, B, L, nullptr, hop, 0.97f, 5.9604645e-8f, d_mel, T, T, sa);
+      const auto t0 = std::chrono::steady_clock::now();
+      melspec();
       CK(hipStreamSynchronize(sa));
+      dev_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       CK(hipMemcpy(got.data(), d_mel, got.size() * 4, hipMemcpyDeviceToHost));
       long n = 0;
       for (size_t i = 0; i < got.size(); ++i) n += memcmp(&got[i], &want[i], 4) != 0;
@@ -75,8 +98,8 @@ int main() {
     stop.store(true);
     other.join();
     CK(hipStreamSynchronize(sb));
-    printf("stft_logmel_kernel, 64 x 10 s, %-32s: %d launches, %d with a wrong value (%ld of %zu values per launch on average)\n",
-           phase ? "next to the f16 MFMA kernel" : "idle device", launches, bad_launches, bad_launches ? bad_values / bad_launches : 0, got.size());
+    printf("seq_len + stft_logmel + mask kernels, 64 x 10 s, %-32s: %d launches, %d with a wrong value (%ld of %zu values per launch on average), %.0f us per victim call\n",
+           phase ? "next to the f16 MFMA kernel" : "idle device", launches, bad_launches, bad_launches ? bad_values / bad_launches : 0, got.size(), dev_us / launches);
   }
   return 0;
 }

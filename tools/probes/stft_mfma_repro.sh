@@ -8,5 +8,5 @@ for v in slp noslp; do
   /opt/rocm/bin/hipcc $F $X -c $R/viet-asr_amd/csrc/frontend.hip -o $O/repro_frontend_$v.o 2>/dev/null || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $O/repro_main.o $O/repro_frontend_$v.o -lpthread -o $O/stft_mfma_repro_$v || exit 1
   echo "== frontend.hip built $([ $v = slp ] && echo 'WITH the SLP vectoriser (packed-FP32 instructions: until round 6)' || echo 'with -fno-slp-vectorize (as shipped)')"
-  $O/stft_mfma_repro_$v
+  for q in 0 1 3; do $O/stft_mfma_repro_$v 0 $q | sed "s/^/[attacker stream $q] /"; done
 done
