@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -50,6 +51,23 @@ int main(int argc, char** argv) {
   std::vector<float> wav((size_t)B * L);
   unsigned s = 12345u;
   for (auto& v : wav) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 9) - (1 << 22)) * (0.1f / (1 << 22)); }
+  // optional: the library's REAL inputs, dumped by tools/probes/stft_mfma_repro_dump.py -- <dir>/wav.bin [64][160000] f32, win.bin [320] f32,
+  // fb.bin [64][257] f32 (tables then built as vasr_api.cpp build_frontend builds them)
+  if (argc > 3) {
+    const std::string d = argv[3];
+    auto rd = [&](const char* name, float* dst, size_t n) { FILE* f = fopen((d + "/" + name).c_str(), "rb"); if (!f || fread(dst, 4, n, f) != n) { printf("cannot read %s\n", name); exit(3); } fclose(f); };
+    std::vector<float> w320(320), fb(64 * 257);
+    rd("wav.bin", wav.data(), wav.size()); rd("win.bin", w320.data(), 320); rd("fb.bin", fb.data(), fb.size());
+    std::fill(win.begin(), win.end(), 0.f); std::fill(mw.begin(), mw.end(), 0.f);
+    for (int i = 0; i < 320; ++i) win[96 + i] = w320[i];
+    for (int f = 0; f < 64; ++f) {
+      int first = -1, last = -1;
+      for (int k = 0; k < 257; ++k) if (fb[f * 257 + k] != 0.f) { if (first < 0) first = k; last = k; }
+      lo[f] = first < 0 ? 0 : first;
+      for (int k = first; first >= 0 && k <= last; ++k) mw[f * vasr::kMelTaps + (k - first)] = fb[f * 257 + k];
+    }
+    printf("(real inputs from %s)\n", d.c_str());
+  }
   vasr::FrontendTables tb{up(win), up(tw256), up(tw512), up(mw), up(lo), 0};
   float* d_wav = up(wav);
   float *d_mel, *d_sink;
